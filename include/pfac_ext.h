@@ -1,0 +1,75 @@
+/*
+ * pfac_ext.h -- small extension surface next to the reference-compatible ABI
+ * in PFAC.h.  Nothing here exists in the reference; every function is
+ * prefixed PFACX_ so a drop-in user never sees it.  The extensions exist so
+ * that tests and the bench harness can (a) exercise the host-side pattern
+ * compiler on a machine without a GPU, (b) compare the compiled tables
+ * byte-for-byte with the oracle, (c) read the facts a multi-GPU driver needs
+ * (maximum pattern length = slice overlap, reference omp_PFAC.cpp:324) and
+ * (d) A/B the kernel variants.
+ */
+#ifndef PFAC_EXT_H_
+#define PFAC_EXT_H_
+
+#include "PFAC.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Like PFAC_create() but binds no device and loads no kernel module: only
+ * the host pattern compiler and the CPU platforms work.  Any GPU entry point
+ * on such a handle returns PFAC_STATUS_LIB_NOT_EXIST -- there is no silent
+ * CPU fallback for the GPU platform.  The platform is preset to
+ * PFAC_PLATFORM_CPU. */
+PFAC_status_t PFACX_createHostOnly(PFAC_handle_t *handle);
+
+typedef struct {
+    int numOfPatterns;        /* F                                             */
+    int numOfStates;          /* includes the unused state 0 (ref PFAC.cpp:704) */
+    int numOfFinalStates;     /* == numOfPatterns                               */
+    int initialState;         /* F + 1                                          */
+    int maxPatternLen;
+    int numOfLeaves;
+    int perfMode;             /* PFAC_perfMode_t                                */
+    int textureMode;          /* PFAC_textureMode_t as currently stored         */
+    int platform;             /* PFAC_platform_t                                */
+    int hasDevice;            /* 0 for PFACX_createHostOnly handles             */
+    size_t numOfTableEntry;   /* ref PFAC_P.h:131-133                           */
+    size_t sizeOfTableEntry;
+    size_t sizeOfTableInBytes;
+    /* prefilter (this implementation only; see DESIGN.md "filter") */
+    int filterLog2Bits;       /* 3-gram bitmap has 2^filterLog2Bits bits        */
+    int filterHasShort;       /* 1 if some pattern is shorter than 3 bytes      */
+    size_t filterBitsSet;     /* population of the 3-gram bitmap                */
+    int kernelVariant;        /* PFACX_KERNEL_*                                 */
+    int multiProcessorCount;
+} PFACX_info_t;
+
+PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
+
+/* Host copies of the compiled tables, owned by the handle (valid until the
+ * next readPatternFromFile / setPerfMode / destroy). */
+typedef enum {
+    PFACX_TABLE_DENSE        = 0,  /* int[numOfStates*256]           (TIME_DRIVEN)  */
+    PFACX_TABLE_HASH_ROWPTR  = 1,  /* int2[numOfStates]              (SPACE_DRIVEN) */
+    PFACX_TABLE_HASH_VALPTR  = 2,  /* int2[numOfTableEntry]          (SPACE_DRIVEN) */
+    PFACX_TABLE_INITIAL_ROW  = 3,  /* int[256], both modes                          */
+    PFACX_TABLE_FILTER_GRAM3 = 4,  /* uint32[2^filterLog2Bits / 32]                 */
+    PFACX_TABLE_FILTER_SHORT = 5   /* uint32[2048] (65536 bits)                     */
+} PFACX_table_t;
+
+PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const void **ptr,
+                             size_t *bytes);
+
+/* Kernel variants of the GPU match path. */
+#define PFACX_KERNEL_FILTER 0   /* default: 3-gram LDS prefilter + compacted walkers      */
+#define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic) */
+
+PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PFAC_EXT_H_ */

@@ -1,0 +1,249 @@
+/*
+ * pattern_compiler.cpp -- pattern file -> failureless trie (host side).
+ *
+ * Behavioural contract = the reference's parsePatternFile
+ * (PFAC/src/PFAC_reorder_Table.cpp:121-231), pattern_cmp_functor (:37-72)
+ * and create_PFACTable_spaceDriven (:256-329) as driven by
+ * PFAC_readPatternFromFile (PFAC/src/PFAC.cpp:674-722):
+ *   - one pattern per '\n'-terminated line, IDs 1..F in file order, bytes
+ *     after the last '\n' ignored;
+ *   - patterns inserted in (signed char, proper-prefix-first) order;
+ *   - final states are the pattern IDs 1..F, the initial state is F+1,
+ *     internal states are numbered from F+2 in insertion order;
+ *   - the last byte of a pattern is appended to its parent WITHOUT a lookup.
+ * The state numbering matters for PFAC_dumpTransitionTable and for the
+ * layout of the hashed table, both of which are compared byte-for-byte with
+ * the oracle.  The data structures are this implementation's own: edges are
+ * kept in per-state singly linked lists during construction (O(1) append,
+ * insertion-order scan) and flattened to CSR.
+ *
+ * Inputs the reference leaves undefined are rejected with a status instead:
+ *   - a blank line followed by another pattern (reference: assert at
+ *     PFAC_reorder_Table.cpp:291)            -> PFAC_STATUS_INVALID_PARAMETER
+ *   - duplicate patterns (reference: comparator is not a strict weak order;
+ *     hashed build fails, PFAC.cpp:543-551)  -> PFAC_STATUS_INTERNAL_ERROR
+ */
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "pfac_host.h"
+
+namespace pfac {
+
+namespace {
+
+struct PatRef { int off; int len; int id; };
+
+/* signed-char lexicographic, shorter-is-first on a tie (ref :37-72) */
+struct PatLess {
+    const unsigned char *base;
+    bool operator()(const PatRef &a, const PatRef &b) const
+    {
+        const int n = a.len < b.len ? a.len : b.len;
+        const signed char *s = reinterpret_cast<const signed char *>(base + a.off);
+        const signed char *t = reinterpret_cast<const signed char *>(base + b.off);
+        for (int i = 0; i < n; i++) {
+            if (s[i] != t[i]) return s[i] < t[i];
+        }
+        return a.len < b.len;
+    }
+};
+
+/* growable trie with per-state linked edge lists */
+class TrieBuilder {
+public:
+    explicit TrieBuilder(int firstStates) { grow(firstStates); }
+
+    int find(int state, int ch) const
+    {
+        for (int e = head_[state]; e >= 0; e = link_[e])
+            if (ch_[e] == ch) return to_[e];
+        return kTrapState;
+    }
+    void append(int state, int ch, int to)
+    {
+        const int e = (int)ch_.size();
+        ch_.push_back((unsigned char)ch);
+        to_.push_back(to);
+        link_.push_back(-1);
+        if (tail_[state] < 0) head_[state] = e; else link_[tail_[state]] = e;
+        tail_[state] = e;
+        count_[state]++;
+    }
+    void grow(int states)
+    {
+        if ((int)head_.size() >= states) return;
+        head_.resize(states, -1); tail_.resize(states, -1); count_.resize(states, 0);
+    }
+    int fanout(int state) const { return count_[state]; }
+
+    void flatten(int numStates, Automaton &fa) const
+    {
+        fa.edgeBegin.assign((size_t)numStates + 1, 0);
+        for (int s = 0; s < numStates; s++) fa.edgeBegin[s + 1] = fa.edgeBegin[s] + count_[s];
+        fa.edgeCh.resize(ch_.size());
+        fa.edgeNext.resize(ch_.size());
+        for (int s = 0; s < numStates; s++) {
+            int w = fa.edgeBegin[s];
+            for (int e = head_[s]; e >= 0; e = link_[e]) { fa.edgeCh[w] = ch_[e]; fa.edgeNext[w] = to_[e]; w++; }
+        }
+    }
+
+private:
+    std::vector<int> head_, tail_, count_, link_, to_;
+    std::vector<unsigned char> ch_;
+};
+
+} // namespace
+
+PFAC_status_t compilePatternFile(const char *filename, Automaton &fa)
+{
+    fa = Automaton();
+    if (!filename) return PFAC_STATUS_INVALID_PARAMETER;
+    FILE *fp = std::fopen(filename, "rb");
+    if (!fp) return PFAC_STATUS_FILE_OPEN_ERROR;
+    std::fseek(fp, 0, SEEK_END);
+    long fsz = std::ftell(fp);
+    std::rewind(fp);
+    if (fsz < 0) { std::fclose(fp); return PFAC_STATUS_FILE_OPEN_ERROR; }
+    try {
+        fa.file.resize((size_t)fsz);
+    } catch (...) { std::fclose(fp); return PFAC_STATUS_ALLOC_FAILED; }
+    size_t got = fsz ? std::fread(fa.file.data(), 1, (size_t)fsz, fp) : 0;
+    std::fclose(fp);
+    fa.file.resize(got);
+
+    /* split into lines; `start` only moves past a NON-empty line (ref :181-190),
+     * so a blank line poisons the next pattern -- reported, not asserted. */
+    std::vector<PatRef> pats;
+    const unsigned char *buf = fa.file.data();
+    int start = 0, cur = 0;
+    for (size_t i = 0; i < got; i++) {
+        if (buf[i] != '\n') { cur++; continue; }
+        if (i > 0 && buf[i - 1] != '\n') {
+            if (buf[start] == '\n') return PFAC_STATUS_INVALID_PARAMETER;
+            pats.push_back(PatRef{start, cur, (int)pats.size() + 1});
+            start = (int)i + 1;
+        }
+        cur = 0;
+    }
+
+    const int F = (int)pats.size();
+    fa.numPatterns = F;
+    fa.patternOff.assign((size_t)F + 1, 0);
+    fa.patternLen.assign((size_t)F + 1, 0);
+    fa.maxPatternLen = 0;
+    for (const PatRef &p : pats) {
+        fa.patternOff[p.id] = p.off;
+        fa.patternLen[p.id] = p.len;
+        fa.maxPatternLen = std::max(fa.maxPatternLen, p.len);
+    }
+    std::sort(pats.begin(), pats.end(), PatLess{buf});
+    fa.sortedId.resize(F);
+    for (int i = 0; i < F; i++) fa.sortedId[i] = pats[i].id;
+
+    fa.initialState = F + 1;                       /* ref PFAC.cpp:693 */
+    int nextId = F + 2;                            /* ref PFAC.cpp:703 */
+    TrieBuilder trie(F + 2);
+    for (const PatRef &p : pats) {
+        int state = fa.initialState;
+        for (int j = 0; j < p.len; j++) {
+            const int ch = buf[p.off + j];
+            if (j == p.len - 1) {
+                /* an existing edge here can only come from an identical pattern */
+                if (trie.find(state, ch) != kTrapState) return PFAC_STATUS_INTERNAL_ERROR;
+                trie.append(state, ch, p.id);
+            } else {
+                int nx = trie.find(state, ch);
+                if (nx == kTrapState) {
+                    nx = nextId++;
+                    trie.grow(nextId);
+                    trie.append(state, ch, nx);
+                }
+                state = nx;
+            }
+        }
+    }
+    fa.numStates = nextId;
+    trie.grow(nextId);
+    fa.numLeaves = 0;                              /* ref PFAC.cpp:716-722 */
+    for (int s = 1; s <= F; s++)
+        if (trie.fanout(s) == 0) fa.numLeaves++;
+    trie.flatten(fa.numStates, fa);
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* 256-entry transition row of the initial state: what the reference keeps in
+ * shared memory as phi_s02s1 (PFAC_kernel.cu:398-403) and, for the hashed
+ * mode, in d_tableOfInitialState (PFAC.cpp:564-594). */
+void buildInitialRow(const Automaton &fa, std::vector<int> &row)
+{
+    row.assign(kCharSet, kTrapState);
+    const int s = fa.initialState;
+    for (int e = fa.edgeBegin[s]; e < fa.edgeBegin[s + 1]; e++) row[fa.edgeCh[e]] = fa.edgeNext[e];
+}
+
+/*
+ * Prefilter bitmaps (this implementation only).
+ *
+ * A start position j can report a non-zero pattern only if
+ *   (a) a pattern of length 1 or 2 matches at j                -> shortBits
+ *   (b) the walk from j survives three transitions             -> gram3
+ * because every match of length >= 3 passes through a depth-3 state.  The
+ * kernel tests (a)/(b) from LDS and only positions that pass are walked
+ * through the real table, so false positives cost time, never correctness.
+ * shortBits is exact over (c0,c1); a 1-byte pattern sets all 256 c1 slots of
+ * its c0.  gram3 is a one-hash Bloom filter over c0|c1<<8|c2<<16 sized so
+ * that at most ~1/128 of its bits are set, within 8 Kbit .. 512 Kbit (1 .. 64 KiB of LDS).
+ */
+void buildFilter(const Automaton &fa, Filter &f)
+{
+    f = Filter();
+    f.shortBits.assign(65536 / 32, 0);
+    const int F = fa.numPatterns;
+    const int init = fa.initialState;
+
+    size_t depth3 = 0;
+    for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
+        const int s1 = fa.edgeNext[e1];
+        for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
+            const int s2 = fa.edgeNext[e2];
+            depth3 += (size_t)(fa.edgeBegin[s2 + 1] - fa.edgeBegin[s2]);
+        }
+    }
+    int lg = 13;
+    while (lg < 19 && (size_t(1) << lg) < depth3 * 128) lg++;
+    f.log2Bits = lg;
+    f.gram3.assign((size_t(1) << lg) / 32, 0);
+
+    for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
+        const uint32_t c0 = fa.edgeCh[e1];
+        const int s1 = fa.edgeNext[e1];
+        if (s1 <= F) {                              /* 1-byte pattern */
+            f.hasShort = true;
+            for (uint32_t c1 = 0; c1 < 256; c1++) {
+                const uint32_t idx = c0 | (c1 << 8);
+                f.shortBits[idx >> 5] |= 1u << (idx & 31);
+            }
+        }
+        for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
+            const uint32_t c1 = fa.edgeCh[e2];
+            const int s2 = fa.edgeNext[e2];
+            if (s2 <= F) {                          /* 2-byte pattern */
+                f.hasShort = true;
+                const uint32_t idx = c0 | (c1 << 8);
+                f.shortBits[idx >> 5] |= 1u << (idx & 31);
+            }
+            for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
+                const uint32_t key = c0 | (c1 << 8) | ((uint32_t)fa.edgeCh[e3] << 16);
+                const uint32_t h = gram3Hash(key, lg);
+                f.gram3[h >> 5] |= 1u << (h & 31);
+            }
+        }
+    }
+    f.bitsSet = 0;
+    for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
+}
+
+} // namespace pfac

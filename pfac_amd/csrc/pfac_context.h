@@ -1,0 +1,115 @@
+/*
+ * pfac_context.h -- private state behind PFAC_handle_t, shared by libpfac.so
+ * (host side) and the kernel module libpfac_gfx950.so.
+ *
+ * Plays the role of the reference's struct PFAC_context
+ * (PFAC/include/PFAC_P.h:94-178) but is laid out for this implementation:
+ * the automaton is kept as a CSR edge list in insertion order (the reference
+ * keeps vector<vector<TableEle>>), and the context additionally owns the
+ * LDS prefilter bitmaps that only this implementation has.
+ */
+#ifndef PFAC_CONTEXT_H_
+#define PFAC_CONTEXT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "PFAC.h"
+#include "pfac_ext.h"
+#include "pfac_module.h"
+
+namespace pfac {
+
+constexpr int kCharSet = 256;                 /* ref CHAR_SET, PFAC_P.h:181 */
+constexpr int kTrapState = -1;                /* ref TRAP_STATE 0xFFFFFFFF, PFAC_P.h:182 */
+constexpr int kHashP = 257;                   /* ref hash_p, PFAC.cpp:439 */
+constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX, PFAC.cpp:69 */
+constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
+
+struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
+
+/* One compiled pattern set: patterns + trie.  Independent of perfMode. */
+struct Automaton {
+    std::vector<unsigned char> file;          /* raw pattern-file bytes                          */
+    int numPatterns = 0;                      /* F                                               */
+    std::vector<int> patternOff;              /* [F+1] by ID, byte offset into file              */
+    std::vector<int> patternLen;              /* [F+1] by ID ([0] = 0)                           */
+    std::vector<int> sortedId;                /* [F] IDs in (signed-char, prefix-first) order    */
+    int maxPatternLen = 0;
+    int initialState = 0;                     /* F+1                                             */
+    int numStates = 0;                        /* next unused id; counts unused state 0           */
+    int numLeaves = 0;
+    /* CSR over states; edges of a state are in insertion order */
+    std::vector<int> edgeBegin;               /* [numStates+1]                                   */
+    std::vector<unsigned char> edgeCh;
+    std::vector<int> edgeNext;
+};
+
+/* 3-gram prefilter (DESIGN.md "filter"): a position can only produce a
+ * non-zero result if its first three bytes hit gram3, or -- when patterns
+ * shorter than 3 bytes exist -- its first two bytes hit shortBits. */
+struct Filter {
+    int log2Bits = 13;
+    bool hasShort = false;
+    size_t bitsSet = 0;
+    std::vector<uint32_t> gram3;              /* 2^log2Bits bits                                 */
+    std::vector<uint32_t> shortBits;          /* 65536 bits, index c0 | c1<<8                    */
+};
+
+constexpr uint32_t kGram3Mul = 0x797A0Bu;     /* 24-bit odd multiplier of the 3-gram hash, picked by
+                                                 scanning 150 candidates for the lowest false-positive
+                                                 rate on text, binary and near-miss streams */
+inline uint32_t gram3Hash(uint32_t key24, int log2Bits)
+{
+    return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (32 - log2Bits);
+}
+
+} // namespace pfac
+
+struct PFAC_context {
+    /* compiled pattern set */
+    pfac::Automaton fa;
+    pfac::Filter filter;
+    bool isPatternsReady = false;
+    std::string patternFile;
+
+    /* host tables (ref h_PFAC_table / h_hashRowPtr / h_hashValPtr / h_tableOfInitialState) */
+    std::vector<int> h_dense;
+    std::vector<pfac::Int2> h_hashRow;
+    std::vector<pfac::Int2> h_hashVal;
+    std::vector<int> h_initialRow;            /* 256 ints, valid in both modes */
+
+    /* device tables */
+    int *d_dense = nullptr;
+    pfac::Int2 *d_hashRow = nullptr;
+    pfac::Int2 *d_hashVal = nullptr;
+    int *d_initialRow = nullptr;
+    uint32_t *d_gram3 = nullptr;
+    uint32_t *d_shortBits = nullptr;
+
+    /* ref numOfTableEntry / sizeOfTableEntry / sizeOfTableInBytes, PFAC_P.h:131-133 */
+    size_t numOfTableEntry = 0;
+    size_t sizeOfTableEntry = 0;
+    size_t sizeOfTableInBytes = 0;
+
+    /* kernel module seam (ref PFAC_P.h:136-146) */
+    void *module = nullptr;
+    PFAC_kernel_protoType kernel_time_driven_ptr = nullptr;
+    PFAC_kernel_protoType kernel_space_driven_ptr = nullptr;
+    PFAC_reduce_kernel_protoType reduce_kernel_ptr = nullptr;
+    PFAC_reduce_kernel_protoType reduce_inplace_kernel_ptr = nullptr;
+
+    int platform = PFAC_PLATFORM_GPU;
+    int perfMode = PFAC_TIME_DRIVEN;
+    int textureMode = PFAC_AUTOMATIC;
+    int kernelVariant = PFACX_KERNEL_FILTER;
+
+    bool hasDevice = false;
+    int device = -1;
+    int multiProcessorCount = 0;
+    std::string archName;
+};
+
+#endif /* PFAC_CONTEXT_H_ */

@@ -1,0 +1,27 @@
+/*
+ * pfac_host.h -- internal declarations of the host side of libpfac.so.
+ */
+#ifndef PFAC_HOST_H_
+#define PFAC_HOST_H_
+
+#include "pfac_context.h"
+
+namespace pfac {
+
+/* pattern_compiler.cpp */
+PFAC_status_t compilePatternFile(const char *filename, Automaton &fa);
+void buildInitialRow(const Automaton &fa, std::vector<int> &row);
+void buildFilter(const Automaton &fa, Filter &f);
+
+/* tables.cpp */
+PFAC_status_t buildDenseTable(const Automaton &fa, std::vector<int> &dense);
+PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
+                             std::vector<Int2> &valPtr);
+
+/* cpu_engine.cpp: PFAC_PLATFORM_CPU / PFAC_PLATFORM_CPU_OMP */
+PFAC_status_t matchOnCpu(const PFAC_context *ctx, const unsigned char *in, size_t n, int *out,
+                         bool useOpenMP);
+
+} // namespace pfac
+
+#endif

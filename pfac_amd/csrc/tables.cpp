@@ -1,0 +1,108 @@
+/*
+ * tables.cpp -- materialise the two transition-table layouts from the trie.
+ *
+ *  dense  ("time-driven"):  int[numStates][256], TRAP (-1) filled
+ *                           ref PFAC_create2DTable, PFAC/src/PFAC.cpp:345-402
+ *  hashed ("space-driven"): rowPtr int2[numStates] = {offset, (k<<16)|(S-1)}
+ *                           valPtr int2[sum S]     = {nextState, ch}, empty = {-1,-1}
+ *                           ref PFAC_createHashTable, PFAC/src/PFAC.cpp:422-562
+ *
+ * The hashed layout is reproduced exactly (bucket ladder, smallest
+ * collision-free multiplier, running offsets in state order) so that the
+ * device tables are byte-identical to what the reference would upload; the
+ * parity tests compare them with the oracle's.
+ */
+#include <cstring>
+#include <new>
+
+#include "pfac_host.h"
+
+namespace pfac {
+
+PFAC_status_t buildDenseTable(const Automaton &fa, std::vector<int> &dense)
+{
+    try {
+        dense.assign((size_t)fa.numStates * kCharSet, kTrapState);
+    } catch (const std::bad_alloc &) {
+        dense.clear();
+        return PFAC_STATUS_ALLOC_FAILED;
+    }
+    for (int s = 0; s < fa.numStates; s++) {
+        int *row = dense.data() + (size_t)s * kCharSet;
+        for (int e = fa.edgeBegin[s]; e < fa.edgeBegin[s + 1]; e++) row[fa.edgeCh[e]] = fa.edgeNext[e];
+    }
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* bucket count for a state with `fanout` valid transitions (ref PFAC.cpp:449-473) */
+static int bucketCount(int fanout)
+{
+    if (fanout == 0) return 0;
+    if (fanout == 1) return 1;
+    if (fanout == 2) return 4;
+    if (fanout <= 4) return 16;
+    if (fanout == 5) return 32;
+    if (fanout <= 8) return 64;
+    if (fanout <= 11) return 128;
+    if (fanout <= 255) return 256;
+    return -1;
+}
+
+static inline int slotOf(int k, int ch, int buckets) { return ((k * ch) % kHashP) % buckets; }
+
+PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
+                             std::vector<Int2> &valPtr)
+{
+    const int S = fa.numStates;
+    try {
+        rowPtr.assign((size_t)S, Int2{-1, -1});
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+
+    size_t total = 0;
+    for (int s = 0; s < S; s++) {
+        const int fan = fa.edgeBegin[s + 1] - fa.edgeBegin[s];
+        const int buckets = bucketCount(fan);
+        if (buckets < 0) { rowPtr.clear(); return PFAC_STATUS_INTERNAL_ERROR; }
+        if (buckets == 0) continue;
+        rowPtr[s].x = (int)total;
+        rowPtr[s].y = buckets - 1;
+        total += (size_t)buckets;
+    }
+    try {
+        valPtr.assign(total, Int2{-1, -1});        /* ref memset 0xFF, PFAC.cpp:496 */
+    } catch (const std::bad_alloc &) { rowPtr.clear(); return PFAC_STATUS_ALLOC_FAILED; }
+
+    for (int s = 0; s < S; s++) {
+        const int b = fa.edgeBegin[s], e = fa.edgeBegin[s + 1];
+        if (b == e) continue;
+        const int buckets = rowPtr[s].y + 1;
+        int k = -1;
+        if (buckets == 1 || buckets == 256) {
+            k = 1;                                 /* ref PFAC.cpp:506-519 */
+        } else {
+            /* smallest k in [1,256] whose slots are pairwise distinct (ref :520-542) */
+            for (int cand = 1; cand <= 256 && k < 0; cand++) {
+                uint64_t used[4] = {0, 0, 0, 0};
+                bool ok = true;
+                for (int i = b; i < e; i++) {
+                    const int slot = slotOf(cand, fa.edgeCh[i], buckets);
+                    const uint64_t bit = uint64_t(1) << (slot & 63);
+                    if (used[slot >> 6] & bit) { ok = false; break; }
+                    used[slot >> 6] |= bit;
+                }
+                if (ok) k = cand;
+            }
+            if (k < 0) { rowPtr.clear(); valPtr.clear(); return PFAC_STATUS_INTERNAL_ERROR; }
+        }
+        Int2 *bucket = valPtr.data() + rowPtr[s].x;
+        for (int i = b; i < e; i++) {
+            Int2 &v = bucket[slotOf(k, fa.edgeCh[i], buckets)];
+            v.x = fa.edgeNext[i];
+            v.y = fa.edgeCh[i];
+        }
+        rowPtr[s].y |= (k << 16);                  /* HASH_KEY_K_MASKBITS, PFAC_P.h:89-91 */
+    }
+    return PFAC_STATUS_SUCCESS;
+}
+
+} // namespace pfac

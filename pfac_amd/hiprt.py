@@ -1,0 +1,61 @@
+"""Minimal ctypes view of the HIP runtime for the bench harness: events on the NULL stream
+(the stream the PFAC library launches on, like the reference's default-stream launches,
+PFAC_kernel.cu:188-220) and a device synchronize.  Plumbing only."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+_hip = None
+
+
+def _rt():
+    global _hip
+    if _hip is None:
+        for name in ("libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                _hip = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _hip is None:
+            raise ImportError("HIP runtime (libamdhip64.so) not found")
+        _hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        _hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        _hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        _hip.hipEventDestroy.argtypes = [C.c_void_p]
+    return _hip
+
+
+def _ok(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what} failed with hipError {err}")
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        _ok(_rt().hipEventCreate(C.byref(self.h)), "hipEventCreate")
+
+    def record(self, stream: int = 0):
+        _ok(_rt().hipEventRecord(self.h, C.c_void_p(stream)), "hipEventRecord")
+
+    def synchronize(self):
+        _ok(_rt().hipEventSynchronize(self.h), "hipEventSynchronize")
+
+    def elapsed_ms(self, later: "Event") -> float:
+        ms = C.c_float()
+        _ok(_rt().hipEventElapsedTime(C.byref(ms), self.h, later.h), "hipEventElapsedTime")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _rt().hipEventDestroy(self.h)
+        except Exception:
+            pass
+
+
+def device_synchronize():
+    _ok(_rt().hipDeviceSynchronize(), "hipDeviceSynchronize")

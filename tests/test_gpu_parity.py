@@ -1,0 +1,209 @@
+"""GPU parity tests: HIP match path (through the C ABI) == oracle, bit for bit.
+
+Modelled on the reference's example programs: PFAC/test/simple_example.cpp
+(matchFromHost), README.md example 2 (matchFromDevice) and the only
+self-checking reference test, PFAC/test/omp_PFAC.cpp:396-439 (sliced run ==
+single run).  Device memory comes from torch; the match itself never does.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from pfac_amd import api  # noqa: E402
+
+MODES = [
+    (api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_OFF, "dense-global"),
+    (api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON, "dense-buffer"),
+    (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF, "hash-global"),
+    (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, "hash-buffer"),
+]
+VARIANTS = [(api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "GPU tests need a device; there is no CPU fallback to test"
+    torch.cuda.set_device(0)
+
+
+def make_handle(pattern_file, perf, tex, variant=api.PFACX_KERNEL_FILTER):
+    h = api.PFAC.create()
+    h.setPerfMode(perf)
+    h.setTextureMode(tex)
+    h.setKernelVariant(variant)
+    h.readPatternFromFile(pattern_file)
+    return h
+
+
+def device_match(h, data, in_offset=0, out_offset=0):
+    """matchFromDevice with poisoned output; optional byte/int offsets to misalign the pointers."""
+    n = int(data.size)
+    d_in = torch.zeros(n + in_offset + 64, dtype=torch.uint8, device="cuda:0")
+    d_in[in_offset:in_offset + n] = torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
+    d_out = torch.full((n + out_offset + 64,), -5, dtype=torch.int32, device="cuda:0")
+    h.matchFromDevice(d_in.data_ptr() + in_offset, n, d_out.data_ptr() + 4 * out_offset)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.all(out[:out_offset] == -5) and np.all(out[out_offset + n:] == -5), "wrote outside [0, n)"
+    return out[out_offset:out_offset + n]
+
+
+def assert_same(got, want, what):
+    if not np.array_equal(got, want):
+        bad = np.nonzero(got != want)[0]
+        raise AssertionError(f"{what}: {bad.size} mismatches; first at {bad[0]}: got {got[bad[0]]} want {want[bad[0]]}")
+
+
+@pytest.mark.parametrize("perf,tex,mode_name", MODES)
+@pytest.mark.parametrize("variant,variant_name", VARIANTS)
+@pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
+def test_match_from_device_equals_oracle(workloads, oracle_results, name, perf, tex, mode_name, variant, variant_name):
+    w = workloads[name]
+    h = make_handle(w.pattern_file, perf, tex, variant)
+    try:
+        got = device_match(h, w.data)
+    finally:
+        h.destroy()
+    assert_same(got, oracle_results[name], f"{name}/{mode_name}/{variant_name}")
+
+
+def test_readme_example_known_answer(golden_dir):
+    """README.md:113-120 through matchFromHost on the GPU platform (simple_example.cpp)."""
+    import json, os
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))["example1"]
+    data = np.fromfile(os.path.join(golden_dir, ka["input_file"]), dtype=np.uint8)
+    for perf in (api.PFAC_TIME_DRIVEN, api.PFAC_SPACE_DRIVEN):
+        h = api.PFAC.create()
+        h.setPerfMode(perf)
+        h.readPatternFromFile(os.path.join(golden_dir, ka["pattern_file"]))
+        got = h.match_host_array(data)
+        h.destroy()
+        assert got.tolist() == ka["result_full"]
+        pos = np.nonzero(got)[0]
+        assert pos.tolist() == ka["reduce_pos"] and got[pos].tolist() == ka["reduce_id"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 63, 64, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 16385, 65537])
+def test_ragged_sizes(workloads, n):
+    """Tile / dword / tail boundaries of the vector path (H6 in SURVEY.md): matches that end
+    exactly at n, start in the last bytes, or would need bytes beyond n."""
+    from oracle import binding as ob
+    w = workloads["dense_hits"]
+    reps = (n // w.data.size) + 2
+    data = np.tile(w.data, reps)[17:17 + n].copy()
+    o = ob.Oracle(w.pattern_file, hashed=False)
+    want = o.match(data)
+    o.close()
+    for perf, tex, mode_name in MODES[::2]:
+        h = make_handle(w.pattern_file, perf, tex)
+        try:
+            assert_same(device_match(h, data), want, f"n={n}/{mode_name}")
+        finally:
+            h.destroy()
+
+
+@pytest.mark.parametrize("in_off,out_off", [(1, 0), (2, 0), (3, 0), (0, 1), (0, 2), (0, 3), (1, 1), (4, 4), (8, 0)])
+def test_misaligned_pointers(workloads, oracle_results, in_off, out_off):
+    """The reference casts the input to int* (PFAC_kernel.cu:203); this build accepts any alignment."""
+    w = workloads["c3"]
+    data = w.data[: 200001]
+    from oracle import binding as ob
+    o = ob.Oracle(w.pattern_file, hashed=False)
+    want = o.match(data)
+    o.close()
+    h = make_handle(w.pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        assert_same(device_match(h, data, in_off, out_off), want, f"offsets {in_off},{out_off}")
+    finally:
+        h.destroy()
+
+
+def test_size_zero_and_argument_checks(workloads):
+    """Status codes and check order of PFAC_matchFromDevice (ref PFAC.cpp:846-861)."""
+    w = workloads["c1"]
+    h = api.PFAC.create()
+    buf = torch.zeros(64, dtype=torch.int32, device="cuda:0")
+    assert h.matchFromDevice(buf.data_ptr(), 16, buf.data_ptr(), check=False) == api.STATUS.PATTERNS_NOT_READY
+    h.readPatternFromFile(w.pattern_file)
+    assert h.matchFromDevice(0, 16, buf.data_ptr(), check=False) == api.STATUS.INVALID_PARAMETER
+    assert h.matchFromDevice(buf.data_ptr(), 16, 0, check=False) == api.STATUS.INVALID_PARAMETER
+    buf.fill_(-3)
+    assert h.matchFromDevice(buf.data_ptr(), 0, buf.data_ptr(), check=False) == api.STATUS.SUCCESS
+    torch.cuda.synchronize()
+    assert int((buf == -3).sum()) == 64, "size 0 must not write"
+    assert h.info().hasDevice == 1
+    h.destroy()
+
+
+def test_set_perf_mode_after_load_rebuilds_tables(workloads, oracle_results):
+    """ref PFAC_setPerfMode, PFAC.cpp:794-814."""
+    w = workloads["c2"]
+    h = make_handle(w.pattern_file, api.PFAC_TIME_DRIVEN, api.PFAC_AUTOMATIC)
+    try:
+        assert_same(device_match(h, w.data), oracle_results["c2"], "dense")
+        h.setPerfMode(api.PFAC_SPACE_DRIVEN)
+        assert h.info().sizeOfTableEntry == 8
+        assert_same(device_match(h, w.data), oracle_results["c2"], "hash after switch")
+        h.setPerfMode(api.PFAC_TIME_DRIVEN)
+        assert_same(device_match(h, w.data), oracle_results["c2"], "dense after switch back")
+        assert h.info().textureMode == api.PFAC_TEXTURE_ON, "AUTOMATIC resolves to ON below 2^27 entries (ref PFAC.cpp:819-833)"
+    finally:
+        h.destroy()
+
+
+def test_reload_patterns_replaces_previous_set(workloads, oracle_results):
+    """ref PFAC_readPatternFromFile, PFAC.cpp:663-666."""
+    h = make_handle(workloads["c2"].pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        h.readPatternFromFile(workloads["ex2"].pattern_file)
+        assert h.info().numOfPatterns == 10
+        assert_same(device_match(h, workloads["ex2"].data), oracle_results["ex2"], "after reload")
+    finally:
+        h.destroy()
+
+
+def test_cpu_platforms_agree_with_gpu(workloads, oracle_results):
+    """PFAC_setPlatform: same handle, CPU / CPU_OMP / GPU all give the oracle's answer."""
+    w = workloads["c3"]
+    h = make_handle(w.pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        for platform in (api.PFAC_PLATFORM_GPU, api.PFAC_PLATFORM_CPU, api.PFAC_PLATFORM_CPU_OMP):
+            h.setPlatform(platform)
+            assert_same(h.match_host_array(w.data), oracle_results["c3"], f"platform {platform}")
+    finally:
+        h.destroy()
+
+
+def test_slices_with_overlap_equal_single_call(workloads, oracle_results):
+    """The reference's own self-check (omp_PFAC.cpp:319-439): chunks with a max_patternLen+1 tail,
+    only [start,end) kept, must reproduce the single-call result."""
+    from pfac_amd import sharding
+    w = workloads["c3"]
+    h = make_handle(w.pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON)
+    try:
+        overlap = sharding.overlap_bytes(h.info().maxPatternLen)
+        n = w.data.size
+        got = np.empty(n, dtype=np.int32)
+        for s in sharding.plan_slices(n, 7, overlap):
+            part = device_match(h, w.data[s.start:s.read_end])
+            got[s.start:s.end] = part[: s.end - s.start]
+        assert_same(got, oracle_results["c3"], "7 slices")
+    finally:
+        h.destroy()
+
+
+def test_two_handles_interleaved(workloads, oracle_results):
+    """Two handles with different pattern sets used alternately (SimpleMultiGPU_pthread.cpp idea)."""
+    a = make_handle(workloads["c2"].pattern_file, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON)
+    b = make_handle(workloads["c5"].pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        for _ in range(2):
+            assert_same(device_match(a, workloads["c2"].data), oracle_results["c2"], "handle a")
+            assert_same(device_match(b, workloads["c5"].data), oracle_results["c5"], "handle b")
+    finally:
+        a.destroy()
+        b.destroy()

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t x = __builtin_amdgcn_alignbyte(nxt, d[k], i);   /* bytes pos..pos+3 */
-                const uint32_t h = __umul24(x, pfac::kGram3Mul) >> hashShift;
+                const uint32_t h = (uint32_t)__umul24(x, pfac::kGram3Mul) >> hashShift;   /* __umul24 returns int: shift must be logical */
                 uint32_t bit = (sGram[h >> 5] >> (h & 31)) & 1u;
                 if (HAS_SHORT) {
                     const uint32_t idx = x & 0xFFFFu;

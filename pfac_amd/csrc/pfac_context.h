@@ -29,6 +29,7 @@ constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX,
 constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
+struct Int4 { int x, y, z, w; };              /* fat hashed slot: {next, ch, next.offset, next.k|S-1} */
 
 /* One compiled pattern set: patterns + trie.  Independent of perfMode. */
 struct Automaton {
@@ -86,6 +87,8 @@ struct PFAC_context {
     pfac::Int2 *d_hashRow = nullptr;
     pfac::Int2 *d_hashVal = nullptr;
     int *d_initialRow = nullptr;
+    pfac::Int4 *d_hashFat = nullptr;          /* device-only layout derived from hashRow/hashVal (scan_gfx950.hip) */
+    pfac::Int2 *d_initialRowInfo = nullptr;   /* hashRow[initialRow[c]] for the 256 bytes */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
 

@@ -25,13 +25,19 @@
  *      non-temporal stores, 1 KiB contiguous per wave instruction, with no
  *      dependence on the input.
  *   3. WALK  (compacted).  Surviving positions (a few %) are compacted into a
- *      per-wave LDS queue with ballot/mbcnt and walked 64 at a time, one lane
- *      per position: first transition from the initial-state row in LDS, the
- *      rest from the dense or hashed table in global memory (plain loads or
- *      buffer-resource loads = the "texture" mode).  All walkers of a pass are
- *      at the same depth, so one wave ballot ends the pass when every lane has
- *      hit the trap state.  Non-zero results are stored after the wave has
- *      drained its zero stores (s_waitcnt vmcnt(0)), so they land on top.
+ *      per-wave LDS queue with ballot/mbcnt; the queue accumulates over up to
+ *      64 tiles and is drained by 64 walker lanes, one position per lane:
+ *      first transition from the initial-state row in LDS, the rest from the
+ *      dense or hashed table in global memory (plain loads or buffer-resource
+ *      loads = the "texture" mode).  A lane whose walk hits the trap state
+ *      immediately takes the next queue entry (ballot + mbcnt hand out the
+ *      entries), so lanes stay busy although walk depths differ; one wave
+ *      ballot ends the drain when every lane is dead and the queue is empty.
+ *      The hashed mode walks a device-side "fat" copy of the reference's hash
+ *      table in which every slot also carries the row descriptor of its next
+ *      state: one dependent 16 B load per transition instead of two.
+ *      Non-zero results are stored after the wave has drained its zero stores
+ *      (s_waitcnt vmcnt(0)), so they land on top.
  *
  *   Blocks are persistent (grid = CUs x resident blocks) and stride over tiles,
  *   so the LDS tables are filled once per block.  No MFMA: nothing here is a
@@ -68,8 +74,10 @@ struct ScanArgs {
     const int *dense;
     const Int2 *hashRow;
     const Int2 *hashVal;
-    uint32_t denseBytes, hashRowBytes, hashValBytes;   /* buffer-resource extents */
+    const i32x4 *hashFat;                              /* {next, ch, next.offset, next.k|S-1} per slot */
+    uint32_t denseBytes, hashRowBytes, hashValBytes, hashFatBytes;   /* buffer-resource extents */
     const int *initialRow;
+    const Int2 *initialRowInfo;                        /* hashed: row descriptor of initialRow[c] */
     const uint32_t *gram3;
     const uint32_t *shortBits;
     int log2Bits;
@@ -163,17 +171,163 @@ __device__ __forceinline__ uint64_t loadWindow(const unsigned char *in, size_t p
     return w;
 }
 
+/* ------------------------------------------------------------ walk policies */
+
+/* Cursor of one walker lane.  `off`/`ks` are only live in the hashed modes: they are the
+ * reference's hashRowPtr entry {offset, (k<<16)|(S-1)} of the CURRENT state, carried along so a
+ * transition needs one dependent load (the fat slot) instead of two (rowPtr, then valPtr). */
+struct Cursor { int state, off, ks; };
+
+template <int MODE> struct Walk;
+
+template <> struct Walk<DENSE_GLOBAL> {
+    const int *table; const int *sInit;
+    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *) : table(a.dense), sInit(init) {}
+    __device__ __forceinline__ bool first(Cursor &c, int ch) const { c.state = sInit[ch]; return c.state != kTrap; }
+    __device__ __forceinline__ bool step(Cursor &c, int ch) const
+    {
+        const int s = table[(size_t)(uint32_t)c.state * pfac::kCharSet + (uint32_t)ch];
+        if (s == kTrap) return false;
+        c.state = s;
+        return true;
+    }
+};
+
+template <> struct Walk<DENSE_BUFFER> {
+    __amdgpu_buffer_rsrc_t rsrc; const int *sInit;
+    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.dense), 0, (int)a.denseBytes, 0x00020000)), sInit(init) {}
+    __device__ __forceinline__ bool first(Cursor &c, int ch) const { c.state = sInit[ch]; return c.state != kTrap; }
+    __device__ __forceinline__ bool step(Cursor &c, int ch) const
+    {
+        const uint32_t off = ((uint32_t)c.state * pfac::kCharSet + (uint32_t)ch) * 4u;
+        const int s = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
+        if (s == kTrap || s == 0) return false;        /* 0 = out-of-range clamp: never a valid next state */
+        c.state = s;
+        return true;
+    }
+};
+
+template <> struct Walk<HASH_GLOBAL> {
+    const i32x4 *fat; const int *sInit; const Int2 *sInitRow;
+    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *initRow) : fat(a.hashFat), sInit(init), sInitRow(initRow) {}
+    __device__ __forceinline__ bool first(Cursor &c, int ch) const
+    {
+        c.state = sInit[ch];
+        const Int2 r = sInitRow[ch];
+        c.off = r.x; c.ks = r.y;
+        return c.state != kTrap;
+    }
+    __device__ __forceinline__ bool step(Cursor &c, int ch) const
+    {
+        if (c.off < 0) return false;                   /* state without outgoing transitions */
+        const i32x4 v = fat[(uint32_t)c.off + (uint32_t)hashSlot(c.ks, ch)];
+        if (v.y != ch) return false;                   /* empty slot (ch = -1) or another byte's slot */
+        c.state = v.x; c.off = v.z; c.ks = v.w;
+        return true;
+    }
+};
+
+template <> struct Walk<HASH_BUFFER> {
+    __amdgpu_buffer_rsrc_t rsrc; const int *sInit; const Int2 *sInitRow;
+    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *initRow)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(a.hashFat), 0, (int)a.hashFatBytes, 0x00020000)),
+          sInit(init), sInitRow(initRow) {}
+    __device__ __forceinline__ bool first(Cursor &c, int ch) const
+    {
+        c.state = sInit[ch];
+        const Int2 r = sInitRow[ch];
+        c.off = r.x; c.ks = r.y;
+        return c.state != kTrap;
+    }
+    __device__ __forceinline__ bool step(Cursor &c, int ch) const
+    {
+        if (c.off < 0) return false;
+        const uint32_t slot = (uint32_t)c.off + (uint32_t)hashSlot(c.ks, ch);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(slot * 16u), 0, 0);
+        if ((int)v.y != ch) return false;
+        c.state = (int)v.x; c.off = (int)v.z; c.ks = (int)v.w;
+        return true;
+    }
+};
+
 /* --------------------------------------------------------- filter kernel */
+
+constexpr uint32_t kQueueCap = 1024;          /* entries per wave (uint16: tile-slot << 10 | offset) */
+constexpr uint32_t kMaxSlots = 64;            /* tiles a queue may span: 6 bits of the entry         */
+
+__device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* Walk every queued position.  Entry e refers to byte (tile0 + (e>>10)*tileStride)*1024 + (e&1023).
+ * Lanes are refilled from the queue as soon as their walk ends. */
+template <int MODE>
+__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const uint16_t *sQueue,
+                                           uint32_t qn, size_t tile0, size_t tileStride)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t n = a.n;
+    uint32_t qhead = 0;                         /* wave-uniform */
+    bool alive = false;
+    size_t pos = 0;
+    Cursor cur{kTrap, -1, -1};
+    int match = 0;
+    uint64_t win = 0;
+    uint32_t depth = 0;
+    for (;;) {
+        const uint64_t idle = __ballot(!alive);
+        if (idle && qhead < qn) {
+            const uint32_t idx = qhead + laneRankIn(idle);
+            if (!alive && idx < qn) {
+                const uint32_t e = sQueue[idx];
+                pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
+                win = loadWindow(a.in, pos, n);
+                alive = walk.first(cur, (int)(win & 0xFF));   /* ref phi_s02s1, PFAC_kernel.cu:259 */
+                win >>= 8;
+                match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
+                depth = 1;
+            }
+            qhead += (uint32_t)__popcll(idle);
+        }
+        if (!__ballot(alive)) {                 /* every lane dead: done when the queue is empty too */
+            if (qhead >= qn) break;
+            continue;
+        }
+        if (alive) {
+            if ((depth & 7u) == 0) win = loadWindow(a.in, pos + depth, n);
+            const int ch = (int)(win & 0xFF);
+            win >>= 8;
+            if (pos + depth < n && walk.step(cur, ch)) {
+                if (cur.state <= a.numFinal) match = cur.state;
+                depth++;
+            } else {
+                alive = false;
+                if (match != 0) {
+                    /* the zero stores covering this position were issued earlier by this wave;
+                     * they must have reached L2 before the patch goes out */
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    a.out[pos] = match;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   /* queue memory is reused */
+}
 
 template <int MODE, bool HAS_SHORT>
 __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 {
+    constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int gramWords = 1 << (a.log2Bits - 5);
     uint32_t *sGram = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sShort = sGram + gramWords;
     int *sInit = reinterpret_cast<int *>(sShort + (HAS_SHORT ? 2048 : 0));
-    uint16_t *sQueueAll = reinterpret_cast<uint16_t *>(sInit + pfac::kCharSet);
+    Int2 *sInitRow = reinterpret_cast<Int2 *>(sInit + pfac::kCharSet);
+    uint16_t *sQueueAll = reinterpret_cast<uint16_t *>(sInitRow + (kHashed ? pfac::kCharSet : 0));
 
     const int tid = threadIdx.x;
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
@@ -185,14 +339,17 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             u32x4 *s2 = reinterpret_cast<u32x4 *>(sShort);
             for (int i = tid; i < 2048 / 4; i += kBlockThreads) s2[i] = g2[i];
         }
-        if (tid < pfac::kCharSet) sInit[tid] = a.initialRow[tid];
+        if (tid < pfac::kCharSet) {
+            sInit[tid] = a.initialRow[tid];
+            if (kHashed) sInitRow[tid] = a.initialRowInfo[tid];
+        }
     }
     __syncthreads();
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    uint16_t *sQueue = sQueueAll + wave * kTileBytes;
-    const Lookup<MODE> lookup(a);
+    uint16_t *sQueue = sQueueAll + wave * kQueueCap;
+    const Walk<MODE> walk(a, sInit, sInitRow);
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const size_t n = a.n;
     const size_t numTiles = (n + kTileBytes - 1) / kTileBytes;
@@ -200,10 +357,15 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     const uint32_t hashShift = 32u - (uint32_t)a.log2Bits;
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
 
+    uint32_t qn = 0;                                /* queued positions (wave-uniform)             */
+    uint32_t slot = 0;                              /* tiles since the queue was last empty        */
+    size_t tile0 = 0;                               /* tile of slot 0                              */
+
     for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < numTiles; tile += totalWaves) {
         const size_t base = tile * kTileBytes;
         const size_t dwBase = tile * (kTileBytes / 4);
         const bool full = base + kTileBytes <= n;            /* wave-uniform */
+        if (slot == 0) tile0 = tile;
 
         /* ---- 1. input: 4 coalesced dword loads per lane + 1 halo dword per wave */
         uint32_t d[4];
@@ -265,59 +427,32 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             hits &= valid;
         }
 
-        /* ---- 4. compact surviving positions into the wave's queue */
-        uint32_t qn = 0;
+        /* ---- 4. append surviving positions to the wave's queue (ballot + mbcnt compaction) */
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
+            if (qn + 64 > kQueueCap) {                      /* full: walk what is queued, restart at this tile */
+                drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
+                qn = 0; slot = 0; tile0 = tile;
+            }
             const bool has = hits != 0;
             const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
-            const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(pending >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)pending, 0u));
+            const uint32_t at = qn + laneRankIn(pending);
             if (has) {
-                sQueue[slot] = (uint16_t)(((b >> 2) << 8) + (lane << 2) + (b & 3));
+                sQueue[at] = (uint16_t)((slot << 10) + ((b >> 2) << 8) + (lane << 2) + (b & 3));
                 hits &= hits - 1;
             }
             qn += (uint32_t)__popcll(pending);
             pending = __ballot(hits != 0);
         }
-        if (qn == 0) continue;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        slot++;
 
-        /* ---- 5. walk the survivors, one lane per position, in lock step */
-        for (uint32_t qb = 0; qb < qn; qb += 64) {
-            const uint32_t qi = qb + lane;
-            const bool act = qi < qn;
-            const size_t pos = base + (act ? sQueue[qi] : 0);
-            uint64_t win = act ? loadWindow(a.in, pos, n) : 0;
-            int state = sInit[win & 0xFF];                  /* ref phi_s02s1, PFAC_kernel.cu:259 */
-            win >>= 8;
-            bool alive = act && state != kTrap;
-            int match = (alive && state <= a.numFinal) ? state : 0;
-            uint32_t depth = 1;
-            while (__ballot(alive)) {                       /* all 64 lanes dead -> leave */
-                if ((depth & 7u) == 0) win = alive ? loadWindow(a.in, pos + depth, n) : 0;
-                const int ch = (int)(win & 0xFF);
-                win >>= 8;
-                if (alive) {
-                    if (pos + depth < n) {
-                        const int s = lookup(state, ch);
-                        if (s == kTrap) alive = false;
-                        else { state = s; if (s <= a.numFinal) match = s; }
-                    } else {
-                        alive = false;
-                    }
-                }
-                depth++;
-            }
-            if (__ballot(match != 0)) {
-                /* zero stores of this tile must have reached L2 before the patch */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (match != 0) a.out[pos] = match;
-            }
+        /* ---- 5. walk when the queue spans the maximum number of tiles */
+        if (slot == kMaxSlots) {
+            if (qn) drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
+            qn = 0; slot = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   /* queue is reused next tile */
     }
+    if (qn) drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -355,7 +490,8 @@ size_t filterLdsBytes(const PFAC_context *c)
     size_t bytes = (size_t(1) << c->filter.log2Bits) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * kTileBytes * sizeof(uint16_t);
+    if (c->perfMode == PFAC_SPACE_DRIVEN) bytes += pfac::kCharSet * sizeof(Int2);
+    bytes += (size_t)kWavesPerBlock * kQueueCap * sizeof(uint16_t);
     return bytes;
 }
 
@@ -403,7 +539,8 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     const PFAC_context *c = handle;
     if (!c->d_initialRow || !c->d_gram3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
-    if (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense) return PFAC_STATUS_INTERNAL_ERROR;
+    if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_hashFat || !c->d_initialRowInfo) : !c->d_dense)
+        return PFAC_STATUS_INTERNAL_ERROR;
 
     ScanArgs a{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
@@ -415,6 +552,9 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     a.denseBytes = clampExtent(c->h_dense.size() * sizeof(int));
     a.hashRowBytes = clampExtent(c->h_hashRow.size() * sizeof(Int2));
     a.hashValBytes = clampExtent(c->h_hashVal.size() * sizeof(Int2));
+    a.hashFat = reinterpret_cast<const i32x4 *>(c->d_hashFat);
+    a.hashFatBytes = clampExtent(c->h_hashVal.size() * sizeof(pfac::Int4));
+    a.initialRowInfo = c->d_initialRowInfo;
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;
     a.shortBits = c->d_shortBits;
@@ -427,7 +567,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
      * same way (PFAC_kernel.cu:139-142) */
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
     if (tex) {
-        const size_t biggest = hashed ? c->h_hashVal.size() * sizeof(Int2) : c->h_dense.size() * sizeof(int);
+        const size_t biggest = hashed ? c->h_hashVal.size() * sizeof(pfac::Int4) : c->h_dense.size() * sizeof(int);
         if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
     const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 3u) == 0) &&

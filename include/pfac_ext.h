@@ -44,6 +44,9 @@ typedef struct {
     size_t filterBitsSet;     /* population of the 3-gram bitmap                */
     int kernelVariant;        /* PFACX_KERNEL_*                                 */
     int multiProcessorCount;
+    int filterLog2Bits4;      /* 4-gram bitmap has 2^filterLog2Bits4 bits        */
+    int filterLog2BitsFinal3; /* length-3-pattern bitmap                         */
+    size_t filterBitsSet4;
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -56,7 +59,9 @@ typedef enum {
     PFACX_TABLE_HASH_VALPTR  = 2,  /* int2[numOfTableEntry]          (SPACE_DRIVEN) */
     PFACX_TABLE_INITIAL_ROW  = 3,  /* int[256], both modes                          */
     PFACX_TABLE_FILTER_GRAM3 = 4,  /* uint32[2^filterLog2Bits / 32]                 */
-    PFACX_TABLE_FILTER_SHORT = 5   /* uint32[2048] (65536 bits)                     */
+    PFACX_TABLE_FILTER_SHORT = 5,  /* uint32[2048] (65536 bits)                     */
+    PFACX_TABLE_FILTER_GRAM4 = 6,  /* uint32[2^filterLog2Bits4 / 32]                */
+    PFACX_TABLE_FILTER_FINAL3 = 7  /* uint32[2^filterLog2BitsFinal3 / 32]           */
 } PFACX_table_t;
 
 PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const void **ptr,

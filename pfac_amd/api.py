@@ -26,7 +26,7 @@ PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE = 0, 1
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
- PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT) = range(6)
+ PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_GRAM4, PFACX_TABLE_FILTER_FINAL3) = range(8)
 
 
 class STATUS:
@@ -58,6 +58,7 @@ class PFACX_info(C.Structure):
         ("numOfTableEntry", C.c_size_t), ("sizeOfTableEntry", C.c_size_t), ("sizeOfTableInBytes", C.c_size_t),
         ("filterLog2Bits", C.c_int), ("filterHasShort", C.c_int), ("filterBitsSet", C.c_size_t),
         ("kernelVariant", C.c_int), ("multiProcessorCount", C.c_int),
+        ("filterLog2Bits4", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSet4", C.c_size_t),
     ]
 
 
@@ -253,7 +254,7 @@ class PFAC:
         ptr = C.c_void_p()
         nbytes = C.c_size_t()
         self._ret(self._lib.PFACX_getTable(self._h, which, C.byref(ptr), C.byref(nbytes)), "PFACX_getTable", True)
-        dtype = np.uint32 if which in (PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT) else np.int32
+        dtype = np.uint32 if which >= PFACX_TABLE_FILTER_GRAM3 else np.int32
         if nbytes.value == 0:
             return np.zeros(0, dtype=dtype)
         buf = (C.c_char * nbytes.value).from_address(ptr.value)

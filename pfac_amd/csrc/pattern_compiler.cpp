@@ -188,62 +188,80 @@ void buildInitialRow(const Automaton &fa, std::vector<int> &row)
  * Prefilter bitmaps (this implementation only).
  *
  * A start position j can report a non-zero pattern only if
- *   (a) a pattern of length 1 or 2 matches at j                -> shortBits
+ *   (a) a pattern of length 1 or 2 matches at j                -> shortBits (exact over c0,c1;
+ *       a 1-byte pattern sets all 256 c1 slots of its c0)
  *   (b) the walk from j survives three transitions             -> gram3
- * because every match of length >= 3 passes through a depth-3 state.  The
- * kernel tests (a)/(b) from LDS and only positions that pass are walked
- * through the real table, so false positives cost time, never correctness.
- * shortBits is exact over (c0,c1); a 1-byte pattern sets all 256 c1 slots of
- * its c0.  gram3 is a one-hash Bloom filter over c0|c1<<8|c2<<16 sized so
- * that at most ~1/128 of its bits are set, within 8 Kbit .. 512 Kbit (1 .. 64 KiB of LDS).
+ * because every match of length >= 3 passes through a depth-3 state; and, one level deeper, only if
+ *   (c) (a), or a pattern of length exactly 3 matches at j     -> final3
+ *   (d) or the walk survives four transitions                  -> gram4.
+ * The kernel tests (a)/(b) from LDS for every position and (c)/(d) for the survivors; only positions
+ * that pass both are walked through the real table, so false positives cost time, never
+ * correctness.  gram3 / gram4 / final3 are one-hash Bloom filters sized for <= ~1/64 density
+ * within the LDS budget (gram3, gram4: 1..32 KiB each).
  */
+static int sizeLog2(size_t keys, int lo, int hi)
+{
+    int lg = lo;
+    while (lg < hi && (size_t(1) << lg) < keys * 64) lg++;
+    return lg;
+}
+
 void buildFilter(const Automaton &fa, Filter &f)
 {
     f = Filter();
     f.shortBits.assign(65536 / 32, 0);
     const int F = fa.numPatterns;
     const int init = fa.initialState;
+    auto fanout = [&](int s) { return (size_t)(fa.edgeBegin[s + 1] - fa.edgeBegin[s]); };
 
-    size_t depth3 = 0;
+    size_t depth3 = 0, depth4 = 0, len3 = 0;
     for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
         const int s1 = fa.edgeNext[e1];
         for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
             const int s2 = fa.edgeNext[e2];
-            depth3 += (size_t)(fa.edgeBegin[s2 + 1] - fa.edgeBegin[s2]);
+            depth3 += fanout(s2);
+            for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
+                const int s3 = fa.edgeNext[e3];
+                depth4 += fanout(s3);
+                if (s3 <= F) len3++;
+            }
         }
     }
-    int lg = 13;
-    while (lg < 19 && (size_t(1) << lg) < depth3 * 128) lg++;
-    f.log2Bits = lg;
-    f.gram3.assign((size_t(1) << lg) / 32, 0);
+    f.log2Bits = sizeLog2(depth3, 13, 18);
+    f.log2Bits4 = sizeLog2(depth4, 13, 18);
+    f.log2BitsF3 = sizeLog2(len3, 10, 16);
+    f.gram3.assign((size_t(1) << f.log2Bits) / 32, 0);
+    f.gram4.assign((size_t(1) << f.log2Bits4) / 32, 0);
+    f.final3.assign((size_t(1) << f.log2BitsF3) / 32, 0);
+    auto setBit = [](std::vector<uint32_t> &v, uint32_t h) { v[h >> 5] |= 1u << (h & 31); };
 
     for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
         const uint32_t c0 = fa.edgeCh[e1];
         const int s1 = fa.edgeNext[e1];
         if (s1 <= F) {                              /* 1-byte pattern */
             f.hasShort = true;
-            for (uint32_t c1 = 0; c1 < 256; c1++) {
-                const uint32_t idx = c0 | (c1 << 8);
-                f.shortBits[idx >> 5] |= 1u << (idx & 31);
-            }
+            for (uint32_t c1 = 0; c1 < 256; c1++) setBit(f.shortBits, c0 | (c1 << 8));
         }
         for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
             const uint32_t c1 = fa.edgeCh[e2];
             const int s2 = fa.edgeNext[e2];
             if (s2 <= F) {                          /* 2-byte pattern */
                 f.hasShort = true;
-                const uint32_t idx = c0 | (c1 << 8);
-                f.shortBits[idx >> 5] |= 1u << (idx & 31);
+                setBit(f.shortBits, c0 | (c1 << 8));
             }
             for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
-                const uint32_t key = c0 | (c1 << 8) | ((uint32_t)fa.edgeCh[e3] << 16);
-                const uint32_t h = gram3Hash(key, lg);
-                f.gram3[h >> 5] |= 1u << (h & 31);
+                const uint32_t key3 = c0 | (c1 << 8) | ((uint32_t)fa.edgeCh[e3] << 16);
+                const int s3 = fa.edgeNext[e3];
+                setBit(f.gram3, gram3Hash(key3, f.log2Bits));
+                if (s3 <= F) setBit(f.final3, final3Hash(key3, f.log2BitsF3));   /* 3-byte pattern */
+                for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++)
+                    setBit(f.gram4, gram4Hash(key3 | ((uint32_t)fa.edgeCh[e4] << 24), f.log2Bits4));
             }
         }
     }
-    f.bitsSet = 0;
+    f.bitsSet = f.bitsSet4 = 0;
     for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
+    for (uint32_t w : f.gram4) f.bitsSet4 += (size_t)__builtin_popcount(w);
 }
 
 } // namespace pfac

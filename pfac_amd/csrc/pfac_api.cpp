@@ -51,6 +51,8 @@ void freeResources(PFAC_context *c)
     devFree(c->d_initialRow);
     devFree(c->d_gram3);
     devFree(c->d_shortBits);
+    devFree(c->d_gram4);
+    devFree(c->d_final3);
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();
     c->isPatternsReady = false;
@@ -144,6 +146,8 @@ PFAC_status_t bindCommon(PFAC_context *c)
     PFAC_status_t st = upload(c->d_initialRow, c->h_initialRow.data(), c->h_initialRow.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram3, c->filter.gram3.data(), c->filter.gram3.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram4, c->filter.gram4.data(), c->filter.gram4.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
     return st;
 }
 
@@ -473,6 +477,9 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
     info->filterHasShort = handle->filter.hasShort ? 1 : 0;
     info->filterBitsSet = handle->filter.bitsSet;
     info->kernelVariant = handle->kernelVariant;
+    info->filterLog2Bits4 = handle->filter.log2Bits4;
+    info->filterLog2BitsFinal3 = handle->filter.log2BitsF3;
+    info->filterBitsSet4 = handle->filter.bitsSet4;
     info->multiProcessorCount = handle->multiProcessorCount;
     return PFAC_STATUS_SUCCESS;
 }
@@ -496,6 +503,10 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.gram3.data(); *bytes = handle->filter.gram3.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_SHORT:
         *ptr = handle->filter.shortBits.data(); *bytes = handle->filter.shortBits.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_GRAM4:
+        *ptr = handle->filter.gram4.data(); *bytes = handle->filter.gram4.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_FINAL3:
+        *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
     default: return PFAC_STATUS_INVALID_PARAMETER;
     }
     return PFAC_STATUS_SUCCESS;

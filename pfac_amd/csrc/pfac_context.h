@@ -48,23 +48,38 @@ struct Automaton {
     std::vector<int> edgeNext;
 };
 
-/* 3-gram prefilter (DESIGN.md "filter"): a position can only produce a
- * non-zero result if its first three bytes hit gram3, or -- when patterns
- * shorter than 3 bytes exist -- its first two bytes hit shortBits. */
+/* Two-level prefilter (DESIGN.md "filter").  Level 1, tested for every input position: a start
+ * position can only produce a non-zero result if its first three bytes hit gram3, or -- when
+ * patterns shorter than 3 bytes exist -- its first two bytes hit shortBits.  Level 2, tested only
+ * for the survivors just before they would touch the transition table: the first four bytes must
+ * hit gram4, or the first three must hit final3 (a pattern of length exactly 3), or shortBits.
+ * All bitmaps are supersets of the exact sets, so a miss proves the result is 0. */
 struct Filter {
-    int log2Bits = 13;
+    int log2Bits = 13;                        /* gram3  */
+    int log2Bits4 = 13;                       /* gram4  */
+    int log2BitsF3 = 10;                      /* final3 */
     bool hasShort = false;
-    size_t bitsSet = 0;
-    std::vector<uint32_t> gram3;              /* 2^log2Bits bits                                 */
+    size_t bitsSet = 0;                       /* population of gram3 */
+    size_t bitsSet4 = 0;
+    std::vector<uint32_t> gram3;              /* 2^log2Bits bits, key c0|c1<<8|c2<<16            */
+    std::vector<uint32_t> gram4;              /* 2^log2Bits4 bits, key c0|c1<<8|c2<<16|c3<<24    */
+    std::vector<uint32_t> final3;             /* 2^log2BitsF3 bits, 3-byte patterns              */
     std::vector<uint32_t> shortBits;          /* 65536 bits, index c0 | c1<<8                    */
 };
 
 constexpr uint32_t kGram3Mul = 0x797A0Bu;     /* 24-bit odd multiplier of the 3-gram hash, picked by
                                                  scanning 150 candidates for the lowest false-positive
                                                  rate on text, binary and near-miss streams */
+constexpr uint32_t kGram4Mul = 0x9E3779B1u;   /* 32-bit odd multiplier of the 4-gram hash */
+constexpr uint32_t kFinal3Mul = 0x85EBCBu;    /* 24-bit odd multiplier of the length-3 hash */
 inline uint32_t gram3Hash(uint32_t key24, int log2Bits)
 {
     return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (32 - log2Bits);
+}
+inline uint32_t gram4Hash(uint32_t key32, int log2Bits) { return (uint32_t)(key32 * kGram4Mul) >> (32 - log2Bits); }
+inline uint32_t final3Hash(uint32_t key24, int log2Bits)
+{
+    return (uint32_t)((key24 & 0xFFFFFFu) * kFinal3Mul) >> (32 - log2Bits);
 }
 
 } // namespace pfac
@@ -91,6 +106,8 @@ struct PFAC_context {
     pfac::Int2 *d_initialRowInfo = nullptr;   /* hashRow[initialRow[c]] for the 256 bytes */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
+    uint32_t *d_gram4 = nullptr;
+    uint32_t *d_final3 = nullptr;
 
     /* ref numOfTableEntry / sizeOfTableEntry / sizeOfTableInBytes, PFAC_P.h:131-133 */
     size_t numOfTableEntry = 0;

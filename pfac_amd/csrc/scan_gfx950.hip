@@ -33,6 +33,10 @@
  *      immediately takes the next queue entry (ballot + mbcnt hand out the
  *      entries), so lanes stay busy although walk depths differ; one wave
  *      ballot ends the drain when every lane is dead and the queue is empty.
+ *      The queue keeps the first four bytes of each position, so a walker
+ *      first re-tests them against a 4-gram bitmap in LDS (second filter
+ *      level: no memory traffic for the ~half that fail) and needs no input
+ *      load for its first four transitions.
  *      The hashed mode walks a device-side "fat" copy of the reference's hash
  *      table in which every slot also carries the row descriptor of its next
  *      state: one dependent 16 B load per transition instead of two.
@@ -79,8 +83,10 @@ struct ScanArgs {
     const int *initialRow;
     const Int2 *initialRowInfo;                        /* hashed: row descriptor of initialRow[c] */
     const uint32_t *gram3;
+    const uint32_t *gram4;
+    const uint32_t *final3;
     const uint32_t *shortBits;
-    int log2Bits;
+    int log2Bits, log2Bits4, log2BitsF3;
     int numFinal;
     int initialState;
 };
@@ -152,24 +158,6 @@ template <> struct Lookup<HASH_BUFFER> {
         return (int)v.y == ch ? (int)v.x : kTrap;
     }
 };
-
-/* ------------------------------------------------------------ input bytes */
-
-/* 8 input bytes starting at pos (little endian), zero beyond n.  The input
- * base may have any alignment here; gfx950 global loads are byte-addressable. */
-__device__ __forceinline__ uint64_t loadWindow(const unsigned char *in, size_t pos, size_t n)
-{
-    if (pos + 8 <= n) {
-        uint32_t lo, hi;
-        __builtin_memcpy(&lo, in + pos, 4);
-        __builtin_memcpy(&hi, in + pos + 4, 4);
-        return ((uint64_t)hi << 32) | lo;
-    }
-    uint64_t w = 0;
-    for (int i = 0; i < 8; i++)
-        if (pos + i < n) w |= (uint64_t)in[pos + i] << (8 * i);
-    return w;
-}
 
 /* ------------------------------------------------------------ walk policies */
 
@@ -253,23 +241,50 @@ template <> struct Walk<HASH_BUFFER> {
 
 /* --------------------------------------------------------- filter kernel */
 
-constexpr uint32_t kQueueCap = 1024;          /* entries per wave (uint16: tile-slot << 10 | offset) */
-constexpr uint32_t kMaxSlots = 64;            /* tiles a queue may span: 6 bits of the entry         */
+constexpr uint32_t kQueueCap = 512;           /* entries per wave                                     */
+constexpr uint32_t kMaxSlots = 64;            /* tiles a queue may span: 6 bits of the position entry */
 
 __device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-/* Walk every queued position.  Entry e refers to byte (tile0 + (e>>10)*tileStride)*1024 + (e&1023).
- * Lanes are refilled from the queue as soon as their walk ends. */
-template <int MODE>
-__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const uint16_t *sQueue,
-                                           uint32_t qn, size_t tile0, size_t tileStride)
+__device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) { return (bitmap[h >> 5] >> (h & 31)) & 1u; }
+
+/* LDS view of one block */
+struct Lds {
+    const uint32_t *gram3, *gram4, *final3, *shortBits;
+    const int *init;
+    const Int2 *initRow;
+    uint32_t shift3, shift4, shiftF3;
+};
+
+/* 8 input bytes starting at byte `pos` from aligned dword loads (input base is 4-byte aligned on
+ * this path); dwords at or beyond numDwords read as 0. */
+__device__ __forceinline__ uint64_t loadWindowAligned(const uint32_t *in32, size_t pos, size_t numDwords)
+{
+    const size_t w = pos >> 2;
+    const uint32_t sh = (uint32_t)pos & 3u;
+    const uint32_t w0 = w < numDwords ? in32[w] : 0u;
+    const uint32_t w1 = w + 1 < numDwords ? in32[w + 1] : 0u;
+    const uint32_t w2 = w + 2 < numDwords ? in32[w + 2] : 0u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+/* Walk every queued position.  Entry i is byte (tile0 + (qPos[i]>>10)*tileStride)*1024 + (qPos[i]&1023)
+ * and qBytes[i] holds its first four input bytes.  Lanes are refilled from the queue as soon as
+ * their walk ends; a refilled lane first applies the second filter level (LDS only). */
+template <int MODE, bool HAS_SHORT>
+__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const Lds &lds,
+                                           const uint16_t *qPos, const uint32_t *qBytes, uint32_t qn,
+                                           size_t tile0, size_t tileStride, size_t numDwords)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const size_t n = a.n;
+    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     uint32_t qhead = 0;                         /* wave-uniform */
     bool alive = false;
     size_t pos = 0;
@@ -282,13 +297,19 @@ __device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &
         if (idle && qhead < qn) {
             const uint32_t idx = qhead + laneRankIn(idle);
             if (!alive && idx < qn) {
-                const uint32_t e = sQueue[idx];
-                pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
-                win = loadWindow(a.in, pos, n);
-                alive = walk.first(cur, (int)(win & 0xFF));   /* ref phi_s02s1, PFAC_kernel.cu:259 */
-                win >>= 8;
-                match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
-                depth = 1;
+                const uint32_t x = qBytes[idx];
+                /* level 2: survives four transitions, or a pattern of length <= 3 can match here */
+                uint32_t pass = testBit(lds.gram4, (x * pfac::kGram4Mul) >> lds.shift4);
+                pass |= testBit(lds.final3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
+                if (HAS_SHORT) pass |= testBit(lds.shortBits, x & 0xFFFFu);
+                if (pass) {
+                    const uint32_t e = qPos[idx];
+                    pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
+                    alive = walk.first(cur, (int)(x & 0xFF));     /* ref phi_s02s1, PFAC_kernel.cu:259 */
+                    match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
+                    win = x >> 8;
+                    depth = 1;
+                }
             }
             qhead += (uint32_t)__popcll(idle);
         }
@@ -297,7 +318,7 @@ __device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &
             continue;
         }
         if (alive) {
-            if ((depth & 7u) == 0) win = loadWindow(a.in, pos + depth, n);
+            if ((depth & 7u) == 4u) win = loadWindowAligned(in32, pos + depth, numDwords);
             const int ch = (int)(win & 0xFF);
             win >>= 8;
             if (pos + depth < n && walk.step(cur, ch)) {
@@ -322,23 +343,27 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 {
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int gramWords = 1 << (a.log2Bits - 5);
-    uint32_t *sGram = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *sShort = sGram + gramWords;
+    const int words3 = 1 << (a.log2Bits - 5), words4 = 1 << (a.log2Bits4 - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
+    uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *sGram4 = sGram3 + words3;
+    uint32_t *sFinal3 = sGram4 + words4;
+    uint32_t *sShort = sFinal3 + wordsF3;
     int *sInit = reinterpret_cast<int *>(sShort + (HAS_SHORT ? 2048 : 0));
     Int2 *sInitRow = reinterpret_cast<Int2 *>(sInit + pfac::kCharSet);
-    uint16_t *sQueueAll = reinterpret_cast<uint16_t *>(sInitRow + (kHashed ? pfac::kCharSet : 0));
+    uint32_t *sQBytesAll = reinterpret_cast<uint32_t *>(sInitRow + (kHashed ? pfac::kCharSet : 0));
+    uint16_t *sQPosAll = reinterpret_cast<uint16_t *>(sQBytesAll + kWavesPerBlock * kQueueCap);
 
     const int tid = threadIdx.x;
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
-        const u32x4 *g = reinterpret_cast<const u32x4 *>(a.gram3);
-        u32x4 *s = reinterpret_cast<u32x4 *>(sGram);
-        for (int i = tid; i < gramWords / 4; i += kBlockThreads) s[i] = g[i];
-        if (HAS_SHORT) {
-            const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.shortBits);
-            u32x4 *s2 = reinterpret_cast<u32x4 *>(sShort);
-            for (int i = tid; i < 2048 / 4; i += kBlockThreads) s2[i] = g2[i];
-        }
+        auto copy16 = [&](uint32_t *dst, const uint32_t *src, int words) {
+            const u32x4 *g = reinterpret_cast<const u32x4 *>(src);
+            u32x4 *s = reinterpret_cast<u32x4 *>(dst);
+            for (int i = tid; i < words / 4; i += kBlockThreads) s[i] = g[i];
+        };
+        copy16(sGram3, a.gram3, words3);
+        copy16(sGram4, a.gram4, words4);
+        copy16(sFinal3, a.final3, wordsF3);
+        if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if (tid < pfac::kCharSet) {
             sInit[tid] = a.initialRow[tid];
             if (kHashed) sInitRow[tid] = a.initialRowInfo[tid];
@@ -348,13 +373,15 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    uint16_t *sQueue = sQueueAll + wave * kQueueCap;
+    uint32_t *qBytes = sQBytesAll + wave * kQueueCap;
+    uint16_t *qPos = sQPosAll + wave * kQueueCap;
     const Walk<MODE> walk(a, sInit, sInitRow);
+    const Lds lds{sGram3, sGram4, sFinal3, sShort, sInit, sInitRow,
+                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const size_t n = a.n;
     const size_t numTiles = (n + kTileBytes - 1) / kTileBytes;
     const size_t numDwords = (n + 3) >> 2;          /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
-    const uint32_t hashShift = 32u - (uint32_t)a.log2Bits;
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
 
     uint32_t qn = 0;                                /* queued positions (wave-uniform)             */
@@ -398,22 +425,20 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             }
         }
 
-        /* ---- 3. filter: one LDS bit test per start position */
+        /* ---- 3. filter level 1: one LDS bit test per start position */
         uint32_t hits = 0;
+        uint32_t nxt[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t nxt = (uint32_t)__shfl_down((int)d[k], 1);
+            nxt[k] = (uint32_t)__shfl_down((int)d[k], 1);
             const uint32_t wrap = (k < 3) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d[(k + 1) & 3]) : halo;
-            if (lane == 63) nxt = wrap;
+            if (lane == 63) nxt[k] = wrap;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t x = __builtin_amdgcn_alignbyte(nxt, d[k], i);   /* bytes pos..pos+3 */
-                const uint32_t h = (uint32_t)__umul24(x, pfac::kGram3Mul) >> hashShift;   /* __umul24 returns int: shift must be logical */
-                uint32_t bit = (sGram[h >> 5] >> (h & 31)) & 1u;
-                if (HAS_SHORT) {
-                    const uint32_t idx = x & 0xFFFFu;
-                    bit |= (sShort[idx >> 5] >> (idx & 31)) & 1u;
-                }
+                const uint32_t x = __builtin_amdgcn_alignbyte(nxt[k], d[k], i);   /* bytes pos..pos+3 */
+                /* __umul24 returns int: the shift must be logical */
+                uint32_t bit = testBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul) >> lds.shift3);
+                if (HAS_SHORT) bit |= testBit(sShort, x & 0xFFFFu);
                 hits |= bit << (k * 4 + i);
             }
         }
@@ -427,18 +452,22 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             hits &= valid;
         }
 
-        /* ---- 4. append surviving positions to the wave's queue (ballot + mbcnt compaction) */
+        /* ---- 4. append surviving positions (+ their first 4 bytes) to the wave's queue */
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
             if (qn + 64 > kQueueCap) {                      /* full: walk what is queued, restart at this tile */
-                drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
+                drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
                 qn = 0; slot = 0; tile0 = tile;
             }
             const bool has = hits != 0;
             const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
+            const uint32_t k = b >> 2;
+            const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
+            const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
             const uint32_t at = qn + laneRankIn(pending);
             if (has) {
-                sQueue[at] = (uint16_t)((slot << 10) + ((b >> 2) << 8) + (lane << 2) + (b & 3));
+                qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
+                qBytes[at] = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
                 hits &= hits - 1;
             }
             qn += (uint32_t)__popcll(pending);
@@ -448,11 +477,11 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 
         /* ---- 5. walk when the queue spans the maximum number of tiles */
         if (slot == kMaxSlots) {
-            if (qn) drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
+            if (qn) drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
             qn = 0; slot = 0;
         }
     }
-    if (qn) drainQueue<MODE>(a, walk, sQueue, qn, tile0, totalWaves);
+    if (qn) drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -487,11 +516,12 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 
 size_t filterLdsBytes(const PFAC_context *c)
 {
-    size_t bytes = (size_t(1) << c->filter.log2Bits) / 8;
+    size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
+                    (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += pfac::kCharSet * sizeof(int);
     if (c->perfMode == PFAC_SPACE_DRIVEN) bytes += pfac::kCharSet * sizeof(Int2);
-    bytes += (size_t)kWavesPerBlock * kQueueCap * sizeof(uint16_t);
+    bytes += (size_t)kWavesPerBlock * kQueueCap * (sizeof(uint16_t) + sizeof(uint32_t));
     return bytes;
 }
 
@@ -538,7 +568,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     const PFAC_context *c = handle;
-    if (!c->d_initialRow || !c->d_gram3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
+    if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
     if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_hashFat || !c->d_initialRowInfo) : !c->d_dense)
         return PFAC_STATUS_INTERNAL_ERROR;
 
@@ -558,7 +588,11 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;
     a.shortBits = c->d_shortBits;
+    a.gram4 = c->d_gram4;
+    a.final3 = c->d_final3;
     a.log2Bits = c->filter.log2Bits;
+    a.log2Bits4 = c->filter.log2Bits4;
+    a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.initialState = c->fa.initialState;
 

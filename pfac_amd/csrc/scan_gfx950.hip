@@ -33,10 +33,10 @@
  *      immediately takes the next queue entry (ballot + mbcnt hand out the
  *      entries), so lanes stay busy although walk depths differ; one wave
  *      ballot ends the drain when every lane is dead and the queue is empty.
- *      The queue keeps the first four bytes of each position, so a walker
- *      first re-tests them against a 4-gram bitmap in LDS (second filter
- *      level: no memory traffic for the ~half that fail) and needs no input
- *      load for its first four transitions.
+ *      Before a level-1 survivor is queued its first four bytes are tested
+ *      against a 4-gram bitmap in LDS (second filter level, only executed by
+ *      the few lanes that hold a hit); the queue keeps those four bytes, so a
+ *      walker needs no input load for its first four transitions.
  *      The hashed mode walks a device-side "fat" copy of the reference's hash
  *      table in which every slot also carries the row descriptor of its next
  *      state: one dependent 16 B load per transition instead of two.
@@ -275,9 +275,9 @@ __device__ __forceinline__ uint64_t loadWindowAligned(const uint32_t *in32, size
 
 /* Walk every queued position.  Entry i is byte (tile0 + (qPos[i]>>10)*tileStride)*1024 + (qPos[i]&1023)
  * and qBytes[i] holds its first four input bytes.  Lanes are refilled from the queue as soon as
- * their walk ends; a refilled lane first applies the second filter level (LDS only). */
+ * their walk ends. */
 template <int MODE, bool HAS_SHORT>
-__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const Lds &lds,
+__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const Lds &,
                                            const uint16_t *qPos, const uint32_t *qBytes, uint32_t qn,
                                            size_t tile0, size_t tileStride, size_t numDwords)
 {
@@ -298,18 +298,12 @@ __device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &
             const uint32_t idx = qhead + laneRankIn(idle);
             if (!alive && idx < qn) {
                 const uint32_t x = qBytes[idx];
-                /* level 2: survives four transitions, or a pattern of length <= 3 can match here */
-                uint32_t pass = testBit(lds.gram4, (x * pfac::kGram4Mul) >> lds.shift4);
-                pass |= testBit(lds.final3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
-                if (HAS_SHORT) pass |= testBit(lds.shortBits, x & 0xFFFFu);
-                if (pass) {
-                    const uint32_t e = qPos[idx];
-                    pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
-                    alive = walk.first(cur, (int)(x & 0xFF));     /* ref phi_s02s1, PFAC_kernel.cu:259 */
-                    match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
-                    win = x >> 8;
-                    depth = 1;
-                }
+                const uint32_t e = qPos[idx];
+                pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
+                alive = walk.first(cur, (int)(x & 0xFF));     /* ref phi_s02s1, PFAC_kernel.cu:259 */
+                match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
+                win = x >> 8;
+                depth = 1;
             }
             qhead += (uint32_t)__popcll(idle);
         }
@@ -464,13 +458,26 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             const uint32_t k = b >> 2;
             const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
             const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
-            const uint32_t at = qn + laneRankIn(pending);
+            const uint32_t x = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
+            /* filter level 2 (only lanes holding a level-1 hit): the walk survives four transitions,
+             * or a pattern of length <= 3 can match here */
+            bool keep = false;
             if (has) {
-                qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
-                qBytes[at] = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
+                uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
+                pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
+                if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
+                keep = pass != 0;
                 hits &= hits - 1;
             }
-            qn += (uint32_t)__popcll(pending);
+            const uint64_t keepMask = __ballot(keep);
+            if (keepMask) {
+                const uint32_t at = qn + laneRankIn(keepMask);
+                if (keep) {
+                    qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
+                    qBytes[at] = x;
+                }
+                qn += (uint32_t)__popcll(keepMask);
+            }
             pending = __ballot(hits != 0);
         }
         slot++;

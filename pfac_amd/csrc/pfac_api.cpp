@@ -38,8 +38,9 @@ void freeTables(PFAC_context *c)
     devFree(c->d_dense);
     devFree(c->d_hashRow);
     devFree(c->d_hashVal);
-    devFree(c->d_hashFat);
-    devFree(c->d_initialRowInfo);
+    devFree(c->d_chainSlots);
+    devFree(c->d_rootSlots);
+    c->numChainSlots = 0;
     c->numOfTableEntry = c->sizeOfTableEntry = c->sizeOfTableInBytes = 0;
 }
 
@@ -74,31 +75,15 @@ PFAC_status_t upload(T *&dst, const T *src, size_t count)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* Device-only companion of the hashed table for the gfx950 walker: slot i of the reference's
- * hashValPtr {next, ch} is widened with hashRowPtr[next] = {offset, (k<<16)|(S-1)}, so a walker
- * that already holds the row descriptor of its current state needs ONE dependent 16-byte load per
- * transition (the reference needs rowPtr[state] and then valPtr[...], PFAC_kernel_spaceDriven.cu:
- * 76-124).  The 256 first transitions get the same treatment (initialRowInfo).  Derived data: the
- * host tables that tests compare with the oracle stay in the reference layout. */
-PFAC_status_t uploadFatHashTable(PFAC_context *c)
+/* upload the chained device form of the hashed table (tables.cpp: buildChainedHashTable) */
+PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 {
-    std::vector<pfac::Int4> fat;
-    std::vector<Int2> initInfo(pfac::kCharSet, Int2{-1, -1});
-    try {
-        fat.resize(c->h_hashVal.size());
-    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
-    for (size_t i = 0; i < fat.size(); i++) {
-        const Int2 v = c->h_hashVal[i];
-        Int2 r{-1, -1};
-        if (v.x >= 0 && (size_t)v.x < c->h_hashRow.size()) r = c->h_hashRow[v.x];
-        fat[i] = pfac::Int4{v.x, v.y, r.x, r.y};
-    }
-    for (int ch = 0; ch < pfac::kCharSet; ch++) {
-        const int s = c->h_initialRow[ch];
-        if (s >= 0 && (size_t)s < c->h_hashRow.size()) initInfo[ch] = c->h_hashRow[s];
-    }
-    PFAC_status_t st = upload(c->d_hashFat, fat.data(), fat.size());
-    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_initialRowInfo, initInfo.data(), initInfo.size());
+    std::vector<pfac::ChainSlot> slots, root;
+    PFAC_status_t st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, slots, root);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    c->numChainSlots = slots.size();
+    st = upload(c->d_chainSlots, slots.data(), slots.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_rootSlots, root.data(), root.size());
     return st;
 }
 
@@ -130,7 +115,7 @@ PFAC_status_t bindTable(PFAC_context *c)
         if (c->hasDevice && !c->d_hashRow) {
             st = upload(c->d_hashRow, c->h_hashRow.data(), c->h_hashRow.size());
             if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_hashVal, c->h_hashVal.data(), c->h_hashVal.size());
-            if (st == PFAC_STATUS_SUCCESS) st = uploadFatHashTable(c);
+            if (st == PFAC_STATUS_SUCCESS) st = uploadChainedHashTable(c);
             if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
         }
     }

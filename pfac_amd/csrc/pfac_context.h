@@ -29,7 +29,15 @@ constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX,
 constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
-struct Int4 { int x, y, z, w; };              /* fat hashed slot: {next, ch, next.offset, next.k|S-1} */
+constexpr int kChainMax = 11;                 /* bytes of single-successor chain folded into one slot */
+struct ChainSlot {                            /* 32-byte device slot of the chained hashed table        */
+    int end;                                  /* state after the edge byte and the whole chain          */
+    int meta;                                 /* edge byte | chain length << 8; -1 = empty slot         */
+    int endOff, endKS;                        /* hashRowPtr[end] = {offset, (k<<16)|(S-1)}              */
+    unsigned char chain[12];                  /* chain bytes (kChainMax used)                           */
+    int pad;
+};
+static_assert(sizeof(ChainSlot) == 32, "ChainSlot is read as two 16-byte loads");
 
 /* One compiled pattern set: patterns + trie.  Independent of perfMode. */
 struct Automaton {
@@ -102,8 +110,9 @@ struct PFAC_context {
     pfac::Int2 *d_hashRow = nullptr;
     pfac::Int2 *d_hashVal = nullptr;
     int *d_initialRow = nullptr;
-    pfac::Int4 *d_hashFat = nullptr;          /* device-only layout derived from hashRow/hashVal (scan_gfx950.hip) */
-    pfac::Int2 *d_initialRowInfo = nullptr;   /* hashRow[initialRow[c]] for the 256 bytes */
+    pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
+    pfac::ChainSlot *d_rootSlots = nullptr;   /* the 256 transitions of the initial state, same encoding           */
+    size_t numChainSlots = 0;
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_gram4 = nullptr;

@@ -37,9 +37,12 @@
  *      against a 4-gram bitmap in LDS (second filter level, only executed by
  *      the few lanes that hold a hit); the queue keeps those four bytes, so a
  *      walker needs no input load for its first four transitions.
- *      The hashed mode walks a device-side "fat" copy of the reference's hash
- *      table in which every slot also carries the row descriptor of its next
- *      state: one dependent 16 B load per transition instead of two.
+ *      The hashed mode walks a device-side "chained" copy of the reference's
+ *      hash table (tables.cpp): every 32-byte slot also carries the row
+ *      descriptor of its target state and the run of single-successor,
+ *      non-final states behind it, so one dependent memory round trip
+ *      consumes up to 12 input bytes (the reference needs two dependent loads
+ *      per byte).
  *      Non-zero results are stored after the wave has drained its zero stores
  *      (s_waitcnt vmcnt(0)), so they land on top.
  *
@@ -78,10 +81,10 @@ struct ScanArgs {
     const int *dense;
     const Int2 *hashRow;
     const Int2 *hashVal;
-    const i32x4 *hashFat;                              /* {next, ch, next.offset, next.k|S-1} per slot */
-    uint32_t denseBytes, hashRowBytes, hashValBytes, hashFatBytes;   /* buffer-resource extents */
+    const u32x4 *chainSlots;                           /* pfac::ChainSlot[], two 16-byte halves per slot */
+    const u32x4 *rootSlots;                            /* pfac::ChainSlot[256] of the initial state      */
+    uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
     const int *initialRow;
-    const Int2 *initialRowInfo;                        /* hashed: row descriptor of initialRow[c] */
     const uint32_t *gram3;
     const uint32_t *gram4;
     const uint32_t *final3;
@@ -159,90 +162,12 @@ template <> struct Lookup<HASH_BUFFER> {
     }
 };
 
-/* ------------------------------------------------------------ walk policies */
-
-/* Cursor of one walker lane.  `off`/`ks` are only live in the hashed modes: they are the
- * reference's hashRowPtr entry {offset, (k<<16)|(S-1)} of the CURRENT state, carried along so a
- * transition needs one dependent load (the fat slot) instead of two (rowPtr, then valPtr). */
-struct Cursor { int state, off, ks; };
-
-template <int MODE> struct Walk;
-
-template <> struct Walk<DENSE_GLOBAL> {
-    const int *table; const int *sInit;
-    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *) : table(a.dense), sInit(init) {}
-    __device__ __forceinline__ bool first(Cursor &c, int ch) const { c.state = sInit[ch]; return c.state != kTrap; }
-    __device__ __forceinline__ bool step(Cursor &c, int ch) const
-    {
-        const int s = table[(size_t)(uint32_t)c.state * pfac::kCharSet + (uint32_t)ch];
-        if (s == kTrap) return false;
-        c.state = s;
-        return true;
-    }
-};
-
-template <> struct Walk<DENSE_BUFFER> {
-    __amdgpu_buffer_rsrc_t rsrc; const int *sInit;
-    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.dense), 0, (int)a.denseBytes, 0x00020000)), sInit(init) {}
-    __device__ __forceinline__ bool first(Cursor &c, int ch) const { c.state = sInit[ch]; return c.state != kTrap; }
-    __device__ __forceinline__ bool step(Cursor &c, int ch) const
-    {
-        const uint32_t off = ((uint32_t)c.state * pfac::kCharSet + (uint32_t)ch) * 4u;
-        const int s = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
-        if (s == kTrap || s == 0) return false;        /* 0 = out-of-range clamp: never a valid next state */
-        c.state = s;
-        return true;
-    }
-};
-
-template <> struct Walk<HASH_GLOBAL> {
-    const i32x4 *fat; const int *sInit; const Int2 *sInitRow;
-    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *initRow) : fat(a.hashFat), sInit(init), sInitRow(initRow) {}
-    __device__ __forceinline__ bool first(Cursor &c, int ch) const
-    {
-        c.state = sInit[ch];
-        const Int2 r = sInitRow[ch];
-        c.off = r.x; c.ks = r.y;
-        return c.state != kTrap;
-    }
-    __device__ __forceinline__ bool step(Cursor &c, int ch) const
-    {
-        if (c.off < 0) return false;                   /* state without outgoing transitions */
-        const i32x4 v = fat[(uint32_t)c.off + (uint32_t)hashSlot(c.ks, ch)];
-        if (v.y != ch) return false;                   /* empty slot (ch = -1) or another byte's slot */
-        c.state = v.x; c.off = v.z; c.ks = v.w;
-        return true;
-    }
-};
-
-template <> struct Walk<HASH_BUFFER> {
-    __amdgpu_buffer_rsrc_t rsrc; const int *sInit; const Int2 *sInitRow;
-    __device__ Walk(const ScanArgs &a, const int *init, const Int2 *initRow)
-        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<i32x4 *>(a.hashFat), 0, (int)a.hashFatBytes, 0x00020000)),
-          sInit(init), sInitRow(initRow) {}
-    __device__ __forceinline__ bool first(Cursor &c, int ch) const
-    {
-        c.state = sInit[ch];
-        const Int2 r = sInitRow[ch];
-        c.off = r.x; c.ks = r.y;
-        return c.state != kTrap;
-    }
-    __device__ __forceinline__ bool step(Cursor &c, int ch) const
-    {
-        if (c.off < 0) return false;
-        const uint32_t slot = (uint32_t)c.off + (uint32_t)hashSlot(c.ks, ch);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(slot * 16u), 0, 0);
-        if ((int)v.y != ch) return false;
-        c.state = (int)v.x; c.off = (int)v.z; c.ks = (int)v.w;
-        return true;
-    }
-};
-
-/* --------------------------------------------------------- filter kernel */
+/* ------------------------------------------------------------------ walkers */
 
 constexpr uint32_t kQueueCap = 512;           /* entries per wave                                     */
 constexpr uint32_t kMaxSlots = 64;            /* tiles a queue may span: 6 bits of the position entry */
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
 {
@@ -254,56 +179,175 @@ __device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) 
 /* LDS view of one block */
 struct Lds {
     const uint32_t *gram3, *gram4, *final3, *shortBits;
-    const int *init;
-    const Int2 *initRow;
+    const int *init;                           /* dense modes: transition row of the initial state   */
+    const u32x4 *root;                         /* hashed modes: ChainSlot[256] of the initial state  */
     uint32_t shift3, shift4, shiftF3;
 };
 
-/* 8 input bytes starting at byte `pos` from aligned dword loads (input base is 4-byte aligned on
- * this path); dwords at or beyond numDwords read as 0. */
-__device__ __forceinline__ uint64_t loadWindowAligned(const uint32_t *in32, size_t pos, size_t numDwords)
+/* 16 input bytes from the 4-byte aligned address at or below byte `pos` (the input base is 4-byte
+ * aligned on this path); dwords at or beyond numDwords read as 0. */
+__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, size_t pos, size_t numDwords)
 {
     const size_t w = pos >> 2;
-    const uint32_t sh = (uint32_t)pos & 3u;
-    const uint32_t w0 = w < numDwords ? in32[w] : 0u;
-    const uint32_t w1 = w + 1 < numDwords ? in32[w + 1] : 0u;
-    const uint32_t w2 = w + 2 < numDwords ? in32[w + 2] : 0u;
-    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-    return ((uint64_t)hi << 32) | lo;
+    if (w + 4 <= numDwords) return *reinterpret_cast<const u32x4_a4 *>(in32 + w);
+    u32x4 r;
+    r.x = w < numDwords ? in32[w] : 0u;
+    r.y = w + 1 < numDwords ? in32[w + 1] : 0u;
+    r.z = w + 2 < numDwords ? in32[w + 2] : 0u;
+    r.w = w + 3 < numDwords ? in32[w + 3] : 0u;
+    return r;
 }
+
+/* 4 bytes of a 16-byte window starting at byte offset o (0..12) */
+__device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
+{
+    const uint32_t j = o >> 2;
+    const uint32_t lo = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+    const uint32_t hi = j == 0 ? w.y : j == 1 ? w.z : w.w;          /* j == 3 only with (o & 3) == 0 */
+    return __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
+}
+
+/*
+ * Per-lane walker over the DENSE table (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.
+ * The first four input bytes come from the queue; later ones are fetched 8 at a time.
+ */
+template <int MODE> struct Walker {
+    static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
+    const Lookup<MODE> lookup;
+    const uint32_t *in32;
+    size_t n, numDwords;
+    int numFinal;
+    const int *sInit;
+    /* lane state */
+    size_t pos;
+    int state, match;
+    uint64_t win;
+    uint32_t depth;
+
+    __device__ Walker(const ScanArgs &a, const Lds &lds, size_t numDw)
+        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
+          numFinal(a.numFinal), sInit(lds.init), pos(0), state(kTrap), match(0), win(0), depth(0) {}
+
+    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    {
+        pos = p;
+        state = sInit[x & 0xFF];                               /* ref phi_s02s1, PFAC_kernel.cu:259 */
+        match = (state != kTrap && state <= numFinal) ? state : 0;
+        win = x >> 8;
+        depth = 1;
+        return state != kTrap;
+    }
+    __device__ __forceinline__ bool step()
+    {
+        if ((depth & 7u) == 4u) {
+            const u32x4 w = loadWindow16(in32, pos + depth, numDwords);
+            const uint32_t o = (uint32_t)(pos + depth) & 3u;
+            win = ((uint64_t)windowDword(w, o + 4) << 32) | windowDword(w, o);
+        }
+        const int ch = (int)(win & 0xFF);
+        win >>= 8;
+        if (pos + depth >= n) return false;
+        int s = lookup(state, ch);
+        if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
+        if (s == kTrap) return false;
+        state = s;
+        if (s <= numFinal) match = s;
+        depth++;
+        return true;
+    }
+};
+
+/*
+ * Per-lane walker over the CHAINED hashed table (tables.cpp: buildChainedHashTable).  Each step
+ * consumes the edge byte plus the slot's single-successor chain (up to 11 bytes) with one
+ * dependent memory round trip: the 32-byte slot and the 16-byte input window are independent loads,
+ * and the window always contains the edge byte of the NEXT step (1 + 11 + 1 <= 13 usable bytes).
+ */
+template <int MODE> struct ChainWalker {
+    static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
+    const u32x4 *slots;
+    __amdgpu_buffer_rsrc_t rsrc;
+    const u32x4 *sRoot;
+    const uint32_t *in32;
+    size_t n, numDwords;
+    int numFinal;
+    /* lane state */
+    size_t pos;
+    int off, ks, match;
+    uint32_t b0, depth;
+
+    __device__ ChainWalker(const ScanArgs &a, const Lds &lds, size_t numDw)
+        : slots(a.chainSlots),
+          rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
+          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
+          numFinal(a.numFinal), pos(0), off(-1), ks(-1), match(0), b0(0), depth(0) {}
+
+    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    {
+        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = 0; ks = 0;
+        return true;                                           /* the first step reads the root slot from LDS */
+    }
+    __device__ __forceinline__ bool step()
+    {
+        const size_t p = pos + depth;                          /* position of the edge byte b0 */
+        if (p >= n) return false;
+        u32x4 s0, s1;
+        if (depth == 0) {
+            s0 = sRoot[b0 * 2];
+            s1 = sRoot[b0 * 2 + 1];
+        } else {
+            if (off < 0) return false;                         /* state without outgoing transitions */
+            const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
+            if (MODE == HASH_BUFFER) {
+                s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u), 0, 0);
+                s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u + 16u), 0, 0);
+            } else {
+                s0 = slots[(size_t)idx * 2];
+                s1 = slots[(size_t)idx * 2 + 1];
+            }
+        }
+        const u32x4 w = loadWindow16(in32, p, numDwords);
+        if ((s0.y & 0xFFu) != b0 || (int)s0.y < 0) return false;     /* empty slot or another byte's slot */
+        const uint32_t k = (s0.y >> 8) & 0xFFu;
+        if (p + 1 + k > n) return false;                       /* the chain would run past the input */
+        const uint32_t o = ((uint32_t)p & 3u) + 1u;             /* window offset of the first chain byte */
+        const uint32_t m0 = k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u);
+        const uint32_t m1 = k >= 8 ? 0xFFFFFFFFu : (k > 4 ? ((1u << (8 * (k - 4))) - 1u) : 0u);
+        const uint32_t m2 = k > 8 ? ((1u << (8 * (k - 8))) - 1u) : 0u;
+        const uint32_t diff = ((windowDword(w, o) ^ s1.x) & m0) | ((windowDword(w, o + 4) ^ s1.y) & m1) |
+                              ((windowDword(w, o + 8) ^ s1.z) & m2);
+        if (diff != 0) return false;                           /* mismatch inside the chain = trap */
+        const int end = (int)s0.x;
+        if (end <= numFinal) match = end;                      /* skipped chain states are never final */
+        off = (int)s0.z; ks = (int)s0.w;
+        depth += 1 + k;
+        b0 = windowDword(w, o + k) & 0xFFu;                    /* edge byte of the next step (o + k <= 15) */
+        return true;
+    }
+};
+
+template <int MODE> struct WalkerFor { using type = Walker<MODE>; };
+template <> struct WalkerFor<HASH_GLOBAL> { using type = ChainWalker<HASH_GLOBAL>; };
+template <> struct WalkerFor<HASH_BUFFER> { using type = ChainWalker<HASH_BUFFER>; };
 
 /* Walk every queued position.  Entry i is byte (tile0 + (qPos[i]>>10)*tileStride)*1024 + (qPos[i]&1023)
  * and qBytes[i] holds its first four input bytes.  Lanes are refilled from the queue as soon as
  * their walk ends. */
-template <int MODE, bool HAS_SHORT>
-__device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &walk, const Lds &,
-                                           const uint16_t *qPos, const uint32_t *qBytes, uint32_t qn,
-                                           size_t tile0, size_t tileStride, size_t numDwords)
+template <class W>
+__device__ __forceinline__ void drainQueue(const ScanArgs &a, W &w, const uint16_t *qPos, const uint32_t *qBytes,
+                                           uint32_t qn, size_t tile0, size_t tileStride)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const size_t n = a.n;
-    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     uint32_t qhead = 0;                         /* wave-uniform */
     bool alive = false;
-    size_t pos = 0;
-    Cursor cur{kTrap, -1, -1};
-    int match = 0;
-    uint64_t win = 0;
-    uint32_t depth = 0;
     for (;;) {
         const uint64_t idle = __ballot(!alive);
         if (idle && qhead < qn) {
             const uint32_t idx = qhead + laneRankIn(idle);
             if (!alive && idx < qn) {
-                const uint32_t x = qBytes[idx];
                 const uint32_t e = qPos[idx];
-                pos = (tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u);
-                alive = walk.first(cur, (int)(x & 0xFF));     /* ref phi_s02s1, PFAC_kernel.cu:259 */
-                match = (alive && cur.state <= a.numFinal) ? cur.state : 0;
-                win = x >> 8;
-                depth = 1;
+                alive = w.start((tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u), qBytes[idx]);
             }
             qhead += (uint32_t)__popcll(idle);
         }
@@ -312,20 +356,12 @@ __device__ __forceinline__ void drainQueue(const ScanArgs &a, const Walk<MODE> &
             continue;
         }
         if (alive) {
-            if ((depth & 7u) == 4u) win = loadWindowAligned(in32, pos + depth, numDwords);
-            const int ch = (int)(win & 0xFF);
-            win >>= 8;
-            if (pos + depth < n && walk.step(cur, ch)) {
-                if (cur.state <= a.numFinal) match = cur.state;
-                depth++;
-            } else {
-                alive = false;
-                if (match != 0) {
-                    /* the zero stores covering this position were issued earlier by this wave;
-                     * they must have reached L2 before the patch goes out */
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    a.out[pos] = match;
-                }
+            alive = w.step();
+            if (!alive && w.match != 0) {
+                /* the zero stores covering this position were issued earlier by this wave;
+                 * they must have reached L2 before the patch goes out */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                a.out[w.pos] = w.match;
             }
         }
     }
@@ -342,14 +378,13 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     uint32_t *sGram4 = sGram3 + words3;
     uint32_t *sFinal3 = sGram4 + words4;
     uint32_t *sShort = sFinal3 + wordsF3;
-    int *sInit = reinterpret_cast<int *>(sShort + (HAS_SHORT ? 2048 : 0));
-    Int2 *sInitRow = reinterpret_cast<Int2 *>(sInit + pfac::kCharSet);
-    uint32_t *sQBytesAll = reinterpret_cast<uint32_t *>(sInitRow + (kHashed ? pfac::kCharSet : 0));
+    uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
+    uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 8 : pfac::kCharSet);
     uint16_t *sQPosAll = reinterpret_cast<uint16_t *>(sQBytesAll + kWavesPerBlock * kQueueCap);
 
     const int tid = threadIdx.x;
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
-        auto copy16 = [&](uint32_t *dst, const uint32_t *src, int words) {
+        auto copy16 = [&](uint32_t *dst, const void *src, int words) {
             const u32x4 *g = reinterpret_cast<const u32x4 *>(src);
             u32x4 *s = reinterpret_cast<u32x4 *>(dst);
             for (int i = tid; i < words / 4; i += kBlockThreads) s[i] = g[i];
@@ -358,10 +393,8 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         copy16(sGram4, a.gram4, words4);
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
-        if (tid < pfac::kCharSet) {
-            sInit[tid] = a.initialRow[tid];
-            if (kHashed) sInitRow[tid] = a.initialRowInfo[tid];
-        }
+        if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 8);
+        else copy16(sFirst, a.initialRow, pfac::kCharSet);
     }
     __syncthreads();
 
@@ -369,13 +402,14 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     const int wave = tid >> 6;
     uint32_t *qBytes = sQBytesAll + wave * kQueueCap;
     uint16_t *qPos = sQPosAll + wave * kQueueCap;
-    const Walk<MODE> walk(a, sInit, sInitRow);
-    const Lds lds{sGram3, sGram4, sFinal3, sShort, sInit, sInitRow,
-                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const size_t n = a.n;
     const size_t numTiles = (n + kTileBytes - 1) / kTileBytes;
     const size_t numDwords = (n + 3) >> 2;          /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
+    const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
+                  reinterpret_cast<const u32x4 *>(sFirst),
+                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
+    typename WalkerFor<MODE>::type walker(a, lds, numDwords);
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
 
     uint32_t qn = 0;                                /* queued positions (wave-uniform)             */
@@ -450,7 +484,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
             if (qn + 64 > kQueueCap) {                      /* full: walk what is queued, restart at this tile */
-                drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
+                drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
                 qn = 0; slot = 0; tile0 = tile;
             }
             const bool has = hits != 0;
@@ -484,11 +518,11 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 
         /* ---- 5. walk when the queue spans the maximum number of tiles */
         if (slot == kMaxSlots) {
-            if (qn) drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
+            if (qn) drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
             qn = 0; slot = 0;
         }
     }
-    if (qn) drainQueue<MODE, HAS_SHORT>(a, walk, lds, qPos, qBytes, qn, tile0, totalWaves, numDwords);
+    if (qn) drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -526,8 +560,7 @@ size_t filterLdsBytes(const PFAC_context *c)
     size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
-    bytes += pfac::kCharSet * sizeof(int);
-    if (c->perfMode == PFAC_SPACE_DRIVEN) bytes += pfac::kCharSet * sizeof(Int2);
+    bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
     bytes += (size_t)kWavesPerBlock * kQueueCap * (sizeof(uint16_t) + sizeof(uint32_t));
     return bytes;
 }
@@ -576,7 +609,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     const PFAC_context *c = handle;
     if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
-    if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_hashFat || !c->d_initialRowInfo) : !c->d_dense)
+    if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_chainSlots || !c->d_rootSlots) : !c->d_dense)
         return PFAC_STATUS_INTERNAL_ERROR;
 
     ScanArgs a{};
@@ -589,9 +622,9 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     a.denseBytes = clampExtent(c->h_dense.size() * sizeof(int));
     a.hashRowBytes = clampExtent(c->h_hashRow.size() * sizeof(Int2));
     a.hashValBytes = clampExtent(c->h_hashVal.size() * sizeof(Int2));
-    a.hashFat = reinterpret_cast<const i32x4 *>(c->d_hashFat);
-    a.hashFatBytes = clampExtent(c->h_hashVal.size() * sizeof(pfac::Int4));
-    a.initialRowInfo = c->d_initialRowInfo;
+    a.chainSlots = reinterpret_cast<const u32x4 *>(c->d_chainSlots);
+    a.rootSlots = reinterpret_cast<const u32x4 *>(c->d_rootSlots);
+    a.chainBytes = clampExtent(c->numChainSlots * sizeof(pfac::ChainSlot));
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;
     a.shortBits = c->d_shortBits;
@@ -608,7 +641,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
      * same way (PFAC_kernel.cu:139-142) */
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
     if (tex) {
-        const size_t biggest = hashed ? c->h_hashVal.size() * sizeof(pfac::Int4) : c->h_dense.size() * sizeof(int);
+        const size_t biggest = hashed ? c->numChainSlots * sizeof(pfac::ChainSlot) : c->h_dense.size() * sizeof(int);
         if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
     const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 3u) == 0) &&

@@ -105,4 +105,56 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
     return PFAC_STATUS_SUCCESS;
 }
 
+/*
+ * Device-only "chained" form of the hashed table for the gfx950 walker (scan_gfx950.hip).
+ *
+ * Slot i corresponds 1:1 to slot i of the reference's hashValPtr.  Besides {next, ch} it carries
+ *   - the hashRowPtr entry of the state the walker will be in next, so a transition needs ONE
+ *     dependent load instead of the reference's two (rowPtr[state], then valPtr[...],
+ *     PFAC_kernel_spaceDriven.cu:76-124);
+ *   - the single-successor chain that follows `next`: while the current state is not final and has
+ *     exactly one outgoing transition, the byte of that transition is appended (up to
+ *     kChainMax bytes) and the state advances.  The walker compares the chain against the input
+ *     with masked dword compares and lands directly in `end`.  Skipping is exact: the skipped
+ *     states are not final, so they could not have changed the reported match, and a mismatch
+ *     anywhere in the chain is the trap state (PFAC_CPU.cpp:76-96).
+ * rootSlots is the same encoding for the 256 transitions of the initial state (kept in LDS).
+ */
+static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next)
+{
+    ChainSlot s;
+    std::memset(&s, 0xFF, sizeof(s));               /* empty: meta = -1 never equals a byte */
+    if (next < 0) return s;
+    int k = 0, cur = next;
+    unsigned char bytes[kChainMax];
+    while (k < kChainMax && cur > fa.numPatterns && fa.edgeBegin[cur + 1] - fa.edgeBegin[cur] == 1) {
+        bytes[k++] = fa.edgeCh[fa.edgeBegin[cur]];
+        cur = fa.edgeNext[fa.edgeBegin[cur]];
+    }
+    s.end = cur;
+    s.meta = ch | (k << 8);
+    s.endOff = rowPtr[cur].x;
+    s.endKS = rowPtr[cur].y;
+    std::memset(s.chain, 0, sizeof(s.chain));
+    std::memcpy(s.chain, bytes, (size_t)k);
+    s.pad = 0;
+    return s;
+}
+
+PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2> &rowPtr,
+                                    const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots,
+                                    std::vector<ChainSlot> &rootSlots)
+{
+    try {
+        slots.resize(valPtr.size());
+        rootSlots.resize(kCharSet);
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+    for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
+    for (int c = 0; c < kCharSet; c++) rootSlots[c] = makeChainSlot(fa, rowPtr, c, kTrapState);
+    const int init = fa.initialState;
+    for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
+        rootSlots[fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
+    return PFAC_STATUS_SUCCESS;
+}
+
 } // namespace pfac

@@ -412,20 +412,47 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     typename WalkerFor<MODE>::type walker(a, lds, numDwords);
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
 
-    uint32_t qn = 0;                                /* queued positions (wave-uniform)             */
+    /* Queue bookkeeping (all wave-uniform).  Entries [0, qv) passed both filter levels; entries
+     * [qv, qu) passed level 1 only and wait until a full wave of them can be tested at once. */
+    uint32_t qv = 0, qu = 0;
     uint32_t slot = 0;                              /* tiles since the queue was last empty        */
     size_t tile0 = 0;                               /* tile of slot 0                              */
 
-    for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < numTiles; tile += totalWaves) {
-        const size_t base = tile * kTileBytes;
-        const size_t dwBase = tile * (kTileBytes / 4);
-        const bool full = base + kTileBytes <= n;            /* wave-uniform */
-        if (slot == 0) tile0 = tile;
+    /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
+     * the walk survives four transitions, or a pattern of length <= 3 can match here */
+    auto verifyPending = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t w = qv;
+        for (uint32_t r = qv; r < qu; r += 64) {
+            const uint32_t idx = r + lane;
+            const bool act = idx < qu;
+            const uint32_t x = act ? qBytes[idx] : 0u;
+            const uint32_t e = act ? qPos[idx] : 0u;
+            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
+            pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
+            if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
+            const bool keep = act && pass != 0;
+            const uint64_t keepMask = __ballot(keep);
+            const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
+            if (keep) { qPos[at] = (uint16_t)e; qBytes[at] = x; }
+            w += (uint32_t)__popcll(keepMask);
+        }
+        qv = qu = w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    auto drainAll = [&]() {
+        if (qu > qv) verifyPending();
+        if (qv) drainQueue(a, walker, qPos, qBytes, qv, tile0, totalWaves);
+        qv = qu = 0;
+        slot = 0;
+    };
 
-        /* ---- 1. input: 4 coalesced dword loads per lane + 1 halo dword per wave */
-        uint32_t d[4];
-        uint32_t halo = 0;
-        if (full) {
+    /* one tile = 4 coalesced dword loads per lane + 1 halo dword per wave */
+    auto loadTile = [&](size_t t, uint32_t (&d)[4], uint32_t &halo) {
+        const size_t dwBase = t * (kTileBytes / 4);
+        halo = 0;
+        if ((t + 1) * kTileBytes <= n) {
 #pragma unroll
             for (int k = 0; k < 4; k++) d[k] = in32[dwBase + k * 64 + lane];
             if (dwBase + 256 < numDwords) halo = in32[dwBase + 256];
@@ -436,6 +463,21 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 d[k] = idx < numDwords ? in32[idx] : 0u;
             }
         }
+    };
+
+    size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    uint32_t d[4] = {0, 0, 0, 0}, halo = 0;
+    if (tile < numTiles) loadTile(tile, d, halo);
+
+    while (tile < numTiles) {
+        const size_t base = tile * kTileBytes;
+        const bool full = base + kTileBytes <= n;            /* wave-uniform */
+        if (slot == 0) tile0 = tile;
+
+        /* ---- 1. prefetch the next tile of this wave: its loads stay in flight during 2..5 */
+        const size_t nextTile = tile + totalWaves;
+        uint32_t nd[4] = {0, 0, 0, 0}, nhalo = 0;
+        if (nextTile < numTiles) loadTile(nextTile, nd, nhalo);
 
         /* ---- 2. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
         if (full) {
@@ -480,49 +522,42 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             hits &= valid;
         }
 
-        /* ---- 4. append surviving positions (+ their first 4 bytes) to the wave's queue */
+        /* ---- 4. append level-1 survivors (+ their first 4 bytes) to the wave's queue */
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
-            if (qn + 64 > kQueueCap) {                      /* full: walk what is queued, restart at this tile */
-                drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
-                qn = 0; slot = 0; tile0 = tile;
+            if (qu + 64 > kQueueCap) {
+                verifyPending();
+                if (qv + 64 > kQueueCap) {                  /* still full: walk what is queued, restart at this tile */
+                    drainQueue(a, walker, qPos, qBytes, qv, tile0, totalWaves);
+                    qv = qu = 0; slot = 0; tile0 = tile;
+                }
             }
             const bool has = hits != 0;
             const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
             const uint32_t k = b >> 2;
             const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
             const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
-            const uint32_t x = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
-            /* filter level 2 (only lanes holding a level-1 hit): the walk survives four transitions,
-             * or a pattern of length <= 3 can match here */
-            bool keep = false;
+            const uint32_t at = qu + laneRankIn(pending);
             if (has) {
-                uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
-                pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
-                if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
-                keep = pass != 0;
+                qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
+                qBytes[at] = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
                 hits &= hits - 1;
             }
-            const uint64_t keepMask = __ballot(keep);
-            if (keepMask) {
-                const uint32_t at = qn + laneRankIn(keepMask);
-                if (keep) {
-                    qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
-                    qBytes[at] = x;
-                }
-                qn += (uint32_t)__popcll(keepMask);
-            }
+            qu += (uint32_t)__popcll(pending);
             pending = __ballot(hits != 0);
         }
         slot++;
+        if (qu - qv >= 64) verifyPending();
 
         /* ---- 5. walk when the queue spans the maximum number of tiles */
-        if (slot == kMaxSlots) {
-            if (qn) drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
-            qn = 0; slot = 0;
-        }
+        if (slot == kMaxSlots) drainAll();
+
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = nd[k];
+        halo = nhalo;
+        tile = nextTile;
     }
-    if (qn) drainQueue(a, walker, qPos, qBytes, qn, tile0, totalWaves);
+    drainAll();
 }
 
 /* ---------------------------------------------------------- naive kernel */

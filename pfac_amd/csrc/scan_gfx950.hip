@@ -164,8 +164,7 @@ template <> struct Lookup<HASH_BUFFER> {
 
 /* ------------------------------------------------------------------ walkers */
 
-constexpr uint32_t kQueueCap = 512;           /* entries per wave                                     */
-constexpr uint32_t kMaxSlots = 64;            /* tiles a queue may span: 6 bits of the position entry */
+constexpr uint32_t kQueueCap = 512;           /* ring entries per wave (power of two)                 */
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -208,8 +207,13 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
 }
 
 /*
+ * Walkers are split-phase: issue() starts the loads of the next transition, consume() finishes it.
+ * The scan loop calls consume/refill/issue once per tile, so the (long, queueing-dominated) latency
+ * of the dependent table loads is hidden behind the streaming and filtering of the next tile
+ * instead of stalling the wave.
+ *
  * Per-lane walker over the DENSE table (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.
- * The first four input bytes come from the queue; later ones are fetched 8 at a time.
+ * Input bytes come 16 at a time; a step that runs out of window only refills the window.
  */
 template <int MODE> struct Walker {
     static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
@@ -221,38 +225,56 @@ template <int MODE> struct Walker {
     /* lane state */
     size_t pos;
     int state, match;
+    uint32_t depth, have;                      /* have = input bytes left in win */
     uint64_t win;
-    uint32_t depth;
+    /* in flight */
+    int loadedState;
+    u32x4 loadedWindow;
+    bool refilling;
+    bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
 
     __device__ Walker(const ScanArgs &a, const Lds &lds, size_t numDw)
         : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
-          numFinal(a.numFinal), sInit(lds.init), pos(0), state(kTrap), match(0), win(0), depth(0) {}
+          numFinal(a.numFinal), sInit(lds.init), pos(0), state(kTrap), match(0), depth(0), have(0), win(0),
+          loadedState(kTrap), loadedWindow{0, 0, 0, 0}, refilling(false), sawLoad(false) {}
 
+    /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
+     * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
     __device__ __forceinline__ bool start(size_t p, uint32_t x)
     {
-        pos = p;
-        state = sInit[x & 0xFF];                               /* ref phi_s02s1, PFAC_kernel.cu:259 */
+        pos = p; refilling = false; sawLoad = false;
+        state = sInit[x & 0xFF];
         match = (state != kTrap && state <= numFinal) ? state : 0;
-        win = x >> 8;
-        depth = 1;
+        win = x >> 8; have = 3; depth = 1;
         return state != kTrap;
     }
-    __device__ __forceinline__ bool step()
+    __device__ __forceinline__ bool issue()
     {
-        if ((depth & 7u) == 4u) {
-            const u32x4 w = loadWindow16(in32, pos + depth, numDwords);
-            const uint32_t o = (uint32_t)(pos + depth) & 3u;
-            win = ((uint64_t)windowDword(w, o + 4) << 32) | windowDword(w, o);
-        }
-        const int ch = (int)(win & 0xFF);
-        win >>= 8;
         if (pos + depth >= n) return false;
-        int s = lookup(state, ch);
+        if (have == 0) {                                       /* window exhausted: fetch 8 more bytes */
+            loadedWindow = loadWindow16(in32, pos + depth, numDwords);
+            refilling = true;
+            return true;
+        }
+        int s = lookup(state, (int)(win & 0xFF));
         if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
-        if (s == kTrap) return false;
-        state = s;
-        if (s <= numFinal) match = s;
-        depth++;
+        loadedState = s;
+        return true;
+    }
+    __device__ __forceinline__ bool consume()
+    {
+        sawLoad = true;
+        if (refilling) {
+            const uint32_t o = (uint32_t)(pos + depth) & 3u;
+            win = ((uint64_t)windowDword(loadedWindow, o + 4) << 32) | windowDword(loadedWindow, o);
+            have = 8;
+            refilling = false;
+            return true;
+        }
+        if (loadedState == kTrap) return false;
+        state = loadedState;
+        if (state <= numFinal) match = state;
+        win >>= 8; have--; depth++;
         return true;
     }
 };
@@ -275,24 +297,44 @@ template <int MODE> struct ChainWalker {
     size_t pos;
     int off, ks, match;
     uint32_t b0, depth;
+    /* in flight */
+    u32x4 s0, s1, w;
+    bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
 
     __device__ ChainWalker(const ScanArgs &a, const Lds &lds, size_t numDw)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
           sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
-          numFinal(a.numFinal), pos(0), off(-1), ks(-1), match(0), b0(0), depth(0) {}
+          numFinal(a.numFinal), pos(0), off(-1), ks(-1), match(0), b0(0), depth(0),
+          s0{0, 0, 0, 0}, s1{0, 0, 0, 0}, w{0, 0, 0, 0}, sawLoad(false) {}
 
+    /* The slots of the initial state live in LDS.  If the root slot's chain fits into the four
+     * bytes that came with the queue entry (chain length <= 2) the first transition is taken right
+     * here without touching memory; otherwise it goes through issue()/consume() like any other.
+     * Returns false if the walk is already over. */
     __device__ __forceinline__ bool start(size_t p, uint32_t x)
     {
-        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = 0; ks = 0;
-        return true;                                           /* the first step reads the root slot from LDS */
+        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = 0; ks = 0; sawLoad = false;
+        const u32x4 r0 = sRoot[b0 * 2];
+        if ((int)r0.y < 0) return false;                       /* no transition on this byte */
+        const uint32_t k = (r0.y >> 8) & 0xFFu;
+        if (k > 2) return true;                                /* long root chain: generic path */
+        if (p + 1 + k > n) return false;
+        const uint32_t chain = sRoot[b0 * 2 + 1].x;
+        const uint32_t mask = (1u << (8 * k)) - 1u;
+        if (((x >> 8) ^ chain) & mask) return false;
+        const int end = (int)r0.x;
+        if (end <= numFinal) match = end;
+        off = (int)r0.z; ks = (int)r0.w;
+        depth = 1 + k;
+        b0 = (x >> (8 * depth)) & 0xFFu;
+        return true;
     }
-    __device__ __forceinline__ bool step()
+    __device__ __forceinline__ bool issue()
     {
         const size_t p = pos + depth;                          /* position of the edge byte b0 */
         if (p >= n) return false;
-        u32x4 s0, s1;
-        if (depth == 0) {
+        if (depth == 0) {                                      /* initial state: its slots live in LDS */
             s0 = sRoot[b0 * 2];
             s1 = sRoot[b0 * 2 + 1];
         } else {
@@ -306,7 +348,13 @@ template <int MODE> struct ChainWalker {
                 s1 = slots[(size_t)idx * 2 + 1];
             }
         }
-        const u32x4 w = loadWindow16(in32, p, numDwords);
+        w = loadWindow16(in32, p, numDwords);
+        return true;
+    }
+    __device__ __forceinline__ bool consume()
+    {
+        const size_t p = pos + depth;
+        sawLoad = true;                                        /* the window load is always a global load */
         if ((s0.y & 0xFFu) != b0 || (int)s0.y < 0) return false;     /* empty slot or another byte's slot */
         const uint32_t k = (s0.y >> 8) & 0xFFu;
         if (p + 1 + k > n) return false;                       /* the chain would run past the input */
@@ -330,43 +378,7 @@ template <int MODE> struct WalkerFor { using type = Walker<MODE>; };
 template <> struct WalkerFor<HASH_GLOBAL> { using type = ChainWalker<HASH_GLOBAL>; };
 template <> struct WalkerFor<HASH_BUFFER> { using type = ChainWalker<HASH_BUFFER>; };
 
-/* Walk every queued position.  Entry i is byte (tile0 + (qPos[i]>>10)*tileStride)*1024 + (qPos[i]&1023)
- * and qBytes[i] holds its first four input bytes.  Lanes are refilled from the queue as soon as
- * their walk ends. */
-template <class W>
-__device__ __forceinline__ void drainQueue(const ScanArgs &a, W &w, const uint16_t *qPos, const uint32_t *qBytes,
-                                           uint32_t qn, size_t tile0, size_t tileStride)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t qhead = 0;                         /* wave-uniform */
-    bool alive = false;
-    for (;;) {
-        const uint64_t idle = __ballot(!alive);
-        if (idle && qhead < qn) {
-            const uint32_t idx = qhead + laneRankIn(idle);
-            if (!alive && idx < qn) {
-                const uint32_t e = qPos[idx];
-                alive = w.start((tile0 + (size_t)(e >> 10) * tileStride) * kTileBytes + (e & 1023u), qBytes[idx]);
-            }
-            qhead += (uint32_t)__popcll(idle);
-        }
-        if (!__ballot(alive)) {                 /* every lane dead: done when the queue is empty too */
-            if (qhead >= qn) break;
-            continue;
-        }
-        if (alive) {
-            alive = w.step();
-            if (!alive && w.match != 0) {
-                /* the zero stores covering this position were issued earlier by this wave;
-                 * they must have reached L2 before the patch goes out */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                a.out[w.pos] = w.match;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   /* queue memory is reused */
-}
+/* --------------------------------------------------------- filter kernel */
 
 template <int MODE, bool HAS_SHORT>
 __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     uint32_t *sShort = sFinal3 + wordsF3;
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 8 : pfac::kCharSet);
-    uint16_t *sQPosAll = reinterpret_cast<uint16_t *>(sQBytesAll + kWavesPerBlock * kQueueCap);
+    uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
 
     const int tid = threadIdx.x;
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
@@ -400,8 +412,8 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    uint32_t *qBytes = sQBytesAll + wave * kQueueCap;
-    uint16_t *qPos = sQPosAll + wave * kQueueCap;
+    uint32_t *qBytes = sQBytesAll + wave * kQueueCap;   /* ring: first four input bytes of the position   */
+    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: (tile sequence number << 10) | offset    */
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const size_t n = a.n;
     const size_t numTiles = (n + kTileBytes - 1) / kTileBytes;
@@ -411,12 +423,14 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                   32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
     typename WalkerFor<MODE>::type walker(a, lds, numDwords);
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
+    const size_t firstTile = (size_t)blockIdx.x * kWavesPerBlock + wave;
 
-    /* Queue bookkeeping (all wave-uniform).  Entries [0, qv) passed both filter levels; entries
-     * [qv, qu) passed level 1 only and wait until a full wave of them can be tested at once. */
-    uint32_t qv = 0, qu = 0;
-    uint32_t slot = 0;                              /* tiles since the queue was last empty        */
-    size_t tile0 = 0;                               /* tile of slot 0                              */
+    /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
+     *   [qh, qv)  passed both filter levels, waiting for a walker lane
+     *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
+    uint32_t qh = 0, qv = 0, qu = 0;
+    constexpr uint32_t kMask = kQueueCap - 1;
+    bool alive = false;                             /* this lane's walker is in the middle of a walk */
 
     /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
      * the walk survives four transitions, or a pattern of length <= 3 can match here */
@@ -424,29 +438,55 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t w = qv;
-        for (uint32_t r = qv; r < qu; r += 64) {
+        for (uint32_t r = qv; r != qu; r += (qu - r < 64 ? qu - r : 64)) {
             const uint32_t idx = r + lane;
-            const bool act = idx < qu;
-            const uint32_t x = act ? qBytes[idx] : 0u;
-            const uint32_t e = act ? qPos[idx] : 0u;
+            const bool act = idx - r < qu - r && lane < (int)(qu - r);
+            const uint32_t x = act ? qBytes[idx & kMask] : 0u;
+            const uint32_t e = act ? qPos[idx & kMask] : 0u;
             uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
             pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
             if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
             const bool keep = act && pass != 0;
             const uint64_t keepMask = __ballot(keep);
             const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
-            if (keep) { qPos[at] = (uint16_t)e; qBytes[at] = x; }
+            if (keep) { qPos[at & kMask] = e; qBytes[at & kMask] = x; }
             w += (uint32_t)__popcll(keepMask);
         }
         qv = qu = w;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
-    auto drainAll = [&]() {
-        if (qu > qv) verifyPending();
-        if (qv) drainQueue(a, walker, qPos, qBytes, qv, tile0, totalWaves);
-        qv = qu = 0;
-        slot = 0;
+
+    /* Zero stores and walker loads of one wave complete in issue order (a single in-order vmcnt
+     * counter), and a position is only walked after the loads issued behind its tile's zero stores
+     * have been consumed, so the patch always lands on top of the zero. */
+    auto finish = [&]() {
+        if (walker.match != 0) {
+            /* walks that ended without consuming a global load (patterns resolved from LDS alone) have
+             * no such ordering: drain this wave's stores first */
+            if (!walker.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.out[walker.pos] = walker.match;
+        }
     };
+    /* one split-phase step of all 64 walker lanes: finish the transition issued last time, hand
+     * queue entries to idle lanes, start the next transition */
+    auto walkStep = [&]() {
+        if (alive && !walker.consume()) { alive = false; finish(); }
+        const uint64_t idle = __ballot(!alive);
+        if (idle && qh != qv) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t rank = laneRankIn(idle);
+            if (!alive && rank < qv - qh) {
+                const uint32_t e = qPos[(qh + rank) & kMask];
+                alive = walker.start((firstTile + (size_t)(e >> 10) * totalWaves) * kTileBytes + (e & 1023u),
+                                     qBytes[(qh + rank) & kMask]);
+                if (!alive) finish();
+            }
+            const uint32_t taken = (uint32_t)__popcll(idle);
+            qh += taken < qv - qh ? taken : qv - qh;
+        }
+        if (alive && !walker.issue()) { alive = false; finish(); }
+    };
+    auto busy = [&]() { return __ballot(alive) != 0 || qh != qv; };
 
     /* one tile = 4 coalesced dword loads per lane + 1 halo dword per wave */
     auto loadTile = [&](size_t t, uint32_t (&d)[4], uint32_t &halo) {
@@ -465,14 +505,14 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         }
     };
 
-    size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    size_t tile = firstTile;
+    uint32_t seq = 0;                               /* tile = firstTile + seq * totalWaves */
     uint32_t d[4] = {0, 0, 0, 0}, halo = 0;
     if (tile < numTiles) loadTile(tile, d, halo);
 
     while (tile < numTiles) {
         const size_t base = tile * kTileBytes;
         const bool full = base + kTileBytes <= n;            /* wave-uniform */
-        if (slot == 0) tile0 = tile;
 
         /* ---- 1. prefetch the next tile of this wave: its loads stay in flight during 2..5 */
         const size_t nextTile = tile + totalWaves;
@@ -495,7 +535,10 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             }
         }
 
-        /* ---- 3. filter level 1: one LDS bit test per start position */
+        /* ---- 3. walkers: one split-phase step; its loads fly while this tile is filtered */
+        if (busy()) walkStep();
+
+        /* ---- 4. filter level 1: one LDS bit test per start position */
         uint32_t hits = 0;
         uint32_t nxt[4];
 #pragma unroll
@@ -522,42 +565,38 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             hits &= valid;
         }
 
-        /* ---- 4. append level-1 survivors (+ their first 4 bytes) to the wave's queue */
+        /* ---- 5. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
-            if (qu + 64 > kQueueCap) {
+            if (qu - qh + 64 > kQueueCap) {
                 verifyPending();
-                if (qv + 64 > kQueueCap) {                  /* still full: walk what is queued, restart at this tile */
-                    drainQueue(a, walker, qPos, qBytes, qv, tile0, totalWaves);
-                    qv = qu = 0; slot = 0; tile0 = tile;
-                }
+                while (qu - qh + 64 > kQueueCap) walkStep();     /* still full: walk until there is room */
             }
             const bool has = hits != 0;
             const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
             const uint32_t k = b >> 2;
             const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
             const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
-            const uint32_t at = qu + laneRankIn(pending);
+            const uint32_t at = (qu + laneRankIn(pending)) & kMask;
             if (has) {
-                qPos[at] = (uint16_t)((slot << 10) + (k << 8) + (lane << 2) + (b & 3));
+                qPos[at] = (seq << 10) + (k << 8) + (lane << 2) + (b & 3);
                 qBytes[at] = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
                 hits &= hits - 1;
             }
             qu += (uint32_t)__popcll(pending);
             pending = __ballot(hits != 0);
         }
-        slot++;
         if (qu - qv >= 64) verifyPending();
-
-        /* ---- 5. walk when the queue spans the maximum number of tiles */
-        if (slot == kMaxSlots) drainAll();
 
 #pragma unroll
         for (int k = 0; k < 4; k++) d[k] = nd[k];
         halo = nhalo;
         tile = nextTile;
+        seq++;
     }
-    drainAll();
+    /* drain: no more tiles to hide behind */
+    if (qu != qv) verifyPending();
+    while (busy()) walkStep();
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -596,7 +635,7 @@ size_t filterLdsBytes(const PFAC_context *c)
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * kQueueCap * (sizeof(uint16_t) + sizeof(uint32_t));
+    bytes += (size_t)kWavesPerBlock * kQueueCap * 2 * sizeof(uint32_t);
     return bytes;
 }
 

@@ -71,6 +71,7 @@ constexpr int kTileBytes = 1024;              /* input bytes per wave per iterat
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 enum TableMode { DENSE_GLOBAL = 0, DENSE_BUFFER = 1, HASH_GLOBAL = 2, HASH_BUFFER = 3 };
 
@@ -184,16 +185,26 @@ struct Lds {
 };
 
 /* 16 input bytes from the 4-byte aligned address at or below byte `pos` (the input base is 4-byte
- * aligned on this path); dwords at or beyond numDwords read as 0. */
-__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, size_t pos, size_t numDwords)
+ * aligned on this path); dwords at or beyond numDwords read as 0 (pos < 4*numDwords + 16). */
+__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, size_t pos, size_t numDwords, uint32_t &pulledBack)
 {
+    /* exactly one load instruction on every path (keeps the compiler's vmcnt bookkeeping exact) and no
+     * use of the loaded value here (the load must stay in flight); numDwords >= 4 on this path.  Near
+     * the end of the input the load is pulled back by `pulledBack` dwords; fixWindow16() undoes it. */
     const size_t w = pos >> 2;
-    if (w + 4 <= numDwords) return *reinterpret_cast<const u32x4_a4 *>(in32 + w);
+    const size_t wc = w + 4 <= numDwords ? w : numDwords - 4;
+    pulledBack = (uint32_t)(w - wc);
+    return *reinterpret_cast<const u32x4_a4 *>(in32 + wc);
+}
+
+__device__ __forceinline__ u32x4 fixWindow16(u32x4 t, uint32_t sh)
+{
+    if (sh == 0) return t;
     u32x4 r;
-    r.x = w < numDwords ? in32[w] : 0u;
-    r.y = w + 1 < numDwords ? in32[w + 1] : 0u;
-    r.z = w + 2 < numDwords ? in32[w + 2] : 0u;
-    r.w = w + 3 < numDwords ? in32[w + 3] : 0u;
+    r.x = sh == 1 ? t.y : sh == 2 ? t.z : sh == 3 ? t.w : 0u;
+    r.y = sh == 1 ? t.z : sh == 2 ? t.w : 0u;
+    r.z = sh == 1 ? t.w : 0u;
+    r.w = 0u;
     return r;
 }
 
@@ -230,13 +241,14 @@ template <int MODE> struct Walker {
     /* in flight */
     int loadedState;
     u32x4 loadedWindow;
+    uint32_t pulledBack;
     bool refilling;
     bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
 
     __device__ Walker(const ScanArgs &a, const Lds &lds, size_t numDw)
         : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
           numFinal(a.numFinal), sInit(lds.init), pos(0), state(kTrap), match(0), depth(0), have(0), win(0),
-          loadedState(kTrap), loadedWindow{0, 0, 0, 0}, refilling(false), sawLoad(false) {}
+          loadedState(kTrap), loadedWindow{0, 0, 0, 0}, pulledBack(0), refilling(false), sawLoad(false) {}
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
@@ -252,7 +264,7 @@ template <int MODE> struct Walker {
     {
         if (pos + depth >= n) return false;
         if (have == 0) {                                       /* window exhausted: fetch 8 more bytes */
-            loadedWindow = loadWindow16(in32, pos + depth, numDwords);
+            loadedWindow = loadWindow16(in32, pos + depth, numDwords, pulledBack);
             refilling = true;
             return true;
         }
@@ -266,7 +278,8 @@ template <int MODE> struct Walker {
         sawLoad = true;
         if (refilling) {
             const uint32_t o = (uint32_t)(pos + depth) & 3u;
-            win = ((uint64_t)windowDword(loadedWindow, o + 4) << 32) | windowDword(loadedWindow, o);
+            const u32x4 lw = fixWindow16(loadedWindow, pulledBack);
+            win = ((uint64_t)windowDword(lw, o + 4) << 32) | windowDword(lw, o);
             have = 8;
             refilling = false;
             return true;
@@ -297,8 +310,11 @@ template <int MODE> struct ChainWalker {
     size_t pos;
     int off, ks, match;
     uint32_t b0, depth;
-    /* in flight */
-    u32x4 s0, s1, w;
+    /* in flight: every loaded register is consumed later (a dead destination register would be
+     * recycled by the compiler and force an early wait), hence the 12-byte load of the chain half */
+    u32x4 s0, w;
+    u32x3 s1;
+    uint32_t pulledBack;
     bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
 
     __device__ ChainWalker(const ScanArgs &a, const Lds &lds, size_t numDw)
@@ -306,71 +322,75 @@ template <int MODE> struct ChainWalker {
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
           sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
           numFinal(a.numFinal), pos(0), off(-1), ks(-1), match(0), b0(0), depth(0),
-          s0{0, 0, 0, 0}, s1{0, 0, 0, 0}, w{0, 0, 0, 0}, sawLoad(false) {}
+          s0{0, 0, 0, 0}, w{0, 0, 0, 0}, s1{0, 0, 0}, pulledBack(0), sawLoad(false) {}
 
-    /* The slots of the initial state live in LDS.  If the root slot's chain fits into the four
-     * bytes that came with the queue entry (chain length <= 2) the first transition is taken right
-     * here without touching memory; otherwise it goes through issue()/consume() like any other.
-     * Returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    /* Take the transition described by slot {t0,t1} on edge byte b0 at position p, given the
+     * 16-byte input window `win` loaded at p & ~3: compares the chain, lands in the slot's end
+     * state and picks the next edge byte out of the same window.  False = trap. */
+    __device__ __forceinline__ bool advance(const u32x4 &t0, const u32x3 &t1, const u32x4 &win, size_t p)
     {
-        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = 0; ks = 0; sawLoad = false;
-        const u32x4 r0 = sRoot[b0 * 2];
-        if ((int)r0.y < 0) return false;                       /* no transition on this byte */
-        const uint32_t k = (r0.y >> 8) & 0xFFu;
-        if (k > 2) return true;                                /* long root chain: generic path */
-        if (p + 1 + k > n) return false;
-        const uint32_t chain = sRoot[b0 * 2 + 1].x;
-        const uint32_t mask = (1u << (8 * k)) - 1u;
-        if (((x >> 8) ^ chain) & mask) return false;
-        const int end = (int)r0.x;
-        if (end <= numFinal) match = end;
-        off = (int)r0.z; ks = (int)r0.w;
-        depth = 1 + k;
-        b0 = (x >> (8 * depth)) & 0xFFu;
-        return true;
-    }
-    __device__ __forceinline__ bool issue()
-    {
-        const size_t p = pos + depth;                          /* position of the edge byte b0 */
-        if (p >= n) return false;
-        if (depth == 0) {                                      /* initial state: its slots live in LDS */
-            s0 = sRoot[b0 * 2];
-            s1 = sRoot[b0 * 2 + 1];
-        } else {
-            if (off < 0) return false;                         /* state without outgoing transitions */
-            const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
-            if (MODE == HASH_BUFFER) {
-                s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u), 0, 0);
-                s1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u + 16u), 0, 0);
-            } else {
-                s0 = slots[(size_t)idx * 2];
-                s1 = slots[(size_t)idx * 2 + 1];
-            }
-        }
-        w = loadWindow16(in32, p, numDwords);
-        return true;
-    }
-    __device__ __forceinline__ bool consume()
-    {
-        const size_t p = pos + depth;
-        sawLoad = true;                                        /* the window load is always a global load */
-        if ((s0.y & 0xFFu) != b0 || (int)s0.y < 0) return false;     /* empty slot or another byte's slot */
-        const uint32_t k = (s0.y >> 8) & 0xFFu;
+        if ((t0.y & 0xFFu) != b0 || (int)t0.y < 0) return false;     /* empty slot or another byte's slot */
+        const uint32_t k = (t0.y >> 8) & 0xFFu;
         if (p + 1 + k > n) return false;                       /* the chain would run past the input */
         const uint32_t o = ((uint32_t)p & 3u) + 1u;             /* window offset of the first chain byte */
         const uint32_t m0 = k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u);
         const uint32_t m1 = k >= 8 ? 0xFFFFFFFFu : (k > 4 ? ((1u << (8 * (k - 4))) - 1u) : 0u);
         const uint32_t m2 = k > 8 ? ((1u << (8 * (k - 8))) - 1u) : 0u;
-        const uint32_t diff = ((windowDword(w, o) ^ s1.x) & m0) | ((windowDword(w, o + 4) ^ s1.y) & m1) |
-                              ((windowDword(w, o + 8) ^ s1.z) & m2);
+        const uint32_t diff = ((windowDword(win, o) ^ t1.x) & m0) | ((windowDword(win, o + 4) ^ t1.y) & m1) |
+                              ((windowDword(win, o + 8) ^ t1.z) & m2);
         if (diff != 0) return false;                           /* mismatch inside the chain = trap */
-        const int end = (int)s0.x;
+        const int end = (int)t0.x;
         if (end <= numFinal) match = end;                      /* skipped chain states are never final */
-        off = (int)s0.z; ks = (int)s0.w;
+        off = (int)t0.z; ks = (int)t0.w;
         depth += 1 + k;
-        b0 = windowDword(w, o + k) & 0xFFu;                    /* edge byte of the next step (o + k <= 15) */
+        b0 = windowDword(win, o + k) & 0xFFu;                  /* edge byte of the next step (o + k <= 15) */
         return true;
+    }
+
+    /* The slots of the initial state live in LDS, so the first transition is taken right here.  If
+     * its chain fits into the four bytes that came with the queue entry (chain length <= 2, the
+     * common case) no memory is touched; a longer root chain fetches its window synchronously.
+     * Returns false if the walk is already over. */
+    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    {
+        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = -1; ks = -1; sawLoad = false;
+        const u32x4 r0 = sRoot[b0 * 2];
+        const u32x4 r1w = sRoot[b0 * 2 + 1];
+        const u32x3 r1 = {r1w.x, r1w.y, r1w.z};
+        if ((int)r0.y < 0) return false;                       /* no transition on this byte */
+        if (((r0.y >> 8) & 0xFFu) <= 2) {
+            /* window = the 4 known bytes placed where advance() expects them */
+            const uint32_t sh = (uint32_t)p & 3u;
+            u32x4 win;
+            win.x = x << (8 * sh);
+            win.y = sh ? x >> (8 * (4 - sh)) : 0u;
+            win.z = 0; win.w = 0;
+            return advance(r0, r1, win, p);
+        }
+        uint32_t back;
+        const u32x4 raw = loadWindow16(in32, p, numDwords, back);
+        sawLoad = true;
+        return advance(r0, r1, fixWindow16(raw, back), p);
+    }
+    __device__ __forceinline__ bool issue()
+    {
+        const size_t p = pos + depth;                          /* position of the edge byte b0 */
+        if (p >= n || off < 0) return false;                   /* end of input, or a state without transitions */
+        const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
+        if (MODE == HASH_BUFFER) {
+            s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u), 0, 0);
+            s1 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(idx * 32u + 16u), 0, 0);
+        } else {
+            s0 = slots[(size_t)idx * 2];
+            s1 = *reinterpret_cast<const u32x3 *>(&slots[(size_t)idx * 2 + 1]);
+        }
+        w = loadWindow16(in32, p, numDwords, pulledBack);
+        return true;
+    }
+    __device__ __forceinline__ bool consume()
+    {
+        sawLoad = true;                                        /* a global load issued after the walk started has landed */
+        return advance(s0, s1, fixWindow16(w, pulledBack), pos + depth);
     }
 };
 
@@ -416,7 +436,6 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: (tile sequence number << 10) | offset    */
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const size_t n = a.n;
-    const size_t numTiles = (n + kTileBytes - 1) / kTileBytes;
     const size_t numDwords = (n + 3) >> 2;          /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
@@ -488,55 +507,54 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     };
     auto busy = [&]() { return __ballot(alive) != 0 || qh != qv; };
 
-    /* one tile = 4 coalesced dword loads per lane + 1 halo dword per wave */
-    auto loadTile = [&](size_t t, uint32_t (&d)[4], uint32_t &halo) {
-        const size_t dwBase = t * (kTileBytes / 4);
-        halo = 0;
-        if ((t + 1) * kTileBytes <= n) {
+    /* The main loop only sees FULL tiles and issues the same vector-memory instructions on every
+     * path (5 loads + 4 stores per tile; the prefetch past the end is clamped, not skipped), so the
+     * compiler's s_waitcnt vmcnt(N) are counted waits and the prefetched tile / walker loads really
+     * stay in flight across the filter work.  The ragged tail (< 1 KiB) is handled after the loop. */
+    const size_t numFullTiles = n / kTileBytes;              /* >= 1: the launcher sends smaller inputs elsewhere */
+    auto loadFullTile = [&](size_t t, uint32_t (&d)[4], uint32_t &halo) {
+        const size_t tc = t < numFullTiles ? t : numFullTiles - 1;
+        const size_t dwBase = tc * (kTileBytes / 4);
 #pragma unroll
-            for (int k = 0; k < 4; k++) d[k] = in32[dwBase + k * 64 + lane];
-            if (dwBase + 256 < numDwords) halo = in32[dwBase + 256];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const size_t idx = dwBase + k * 64 + lane;
-                d[k] = idx < numDwords ? in32[idx] : 0u;
-            }
+        for (int k = 0; k < 4; k++) d[k] = in32[dwBase + k * 64 + lane];
+        const bool haveHalo = dwBase + 256 < numDwords;
+        const uint32_t h = in32[haveHalo ? dwBase + 256 : numDwords - 1];
+        halo = haveHalo ? h : 0u;
+    };
+    auto appendHit = [&](uint32_t seq, uint32_t offset, uint32_t x, bool has) {
+        if (qu - qh + 64 > kQueueCap) {
+            verifyPending();
+            while (qu - qh + 64 > kQueueCap) walkStep();         /* still full: walk until there is room */
+        }
+        const uint64_t m = __ballot(has);
+        if (m) {
+            const uint32_t at = (qu + laneRankIn(m)) & kMask;
+            if (has) { qPos[at] = (seq << 10) + offset; qBytes[at] = x; }
+            qu += (uint32_t)__popcll(m);
         }
     };
 
     size_t tile = firstTile;
     uint32_t seq = 0;                               /* tile = firstTile + seq * totalWaves */
     uint32_t d[4] = {0, 0, 0, 0}, halo = 0;
-    if (tile < numTiles) loadTile(tile, d, halo);
+    if (tile < numFullTiles) loadFullTile(tile, d, halo);
 
-    while (tile < numTiles) {
-        const size_t base = tile * kTileBytes;
-        const bool full = base + kTileBytes <= n;            /* wave-uniform */
+    while (tile < numFullTiles) {
+        /* ---- 1. walkers: finish the transitions issued one tile ago, start the next ones */
+        if (busy()) walkStep();
 
-        /* ---- 1. prefetch the next tile of this wave: its loads stay in flight during 2..5 */
+        /* ---- 2. prefetch the next tile of this wave: its loads stay in flight during 3..5 */
         const size_t nextTile = tile + totalWaves;
-        uint32_t nd[4] = {0, 0, 0, 0}, nhalo = 0;
-        if (nextTile < numTiles) loadTile(nextTile, nd, nhalo);
+        uint32_t nd[4], nhalo;
+        loadFullTile(nextTile, nd, nhalo);
 
-        /* ---- 2. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
-        if (full) {
-            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + base);
+        /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
+        {
+            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + tile * kTileBytes);
             const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const size_t p0 = base + k * 256 + lane * 4;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (p0 + i < n) a.out[p0 + i] = 0;
-            }
         }
-
-        /* ---- 3. walkers: one split-phase step; its loads fly while this tile is filtered */
-        if (busy()) walkStep();
 
         /* ---- 4. filter level 1: one LDS bit test per start position */
         uint32_t hits = 0;
@@ -555,35 +573,17 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 hits |= bit << (k * 4 + i);
             }
         }
-        if (!full) {   /* never queue a position at or beyond n */
-            uint32_t valid = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (base + k * 256 + lane * 4 + i < n) valid |= 1u << (k * 4 + i);
-            hits &= valid;
-        }
 
         /* ---- 5. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
         uint64_t pending = __ballot(hits != 0);
         while (pending) {                                   /* wave-uniform: max hits per lane iterations */
-            if (qu - qh + 64 > kQueueCap) {
-                verifyPending();
-                while (qu - qh + 64 > kQueueCap) walkStep();     /* still full: walk until there is room */
-            }
             const bool has = hits != 0;
             const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
             const uint32_t k = b >> 2;
             const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
             const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
-            const uint32_t at = (qu + laneRankIn(pending)) & kMask;
-            if (has) {
-                qPos[at] = (seq << 10) + (k << 8) + (lane << 2) + (b & 3);
-                qBytes[at] = __builtin_amdgcn_alignbyte(nk, dk, b & 3);
-                hits &= hits - 1;
-            }
-            qu += (uint32_t)__popcll(pending);
+            appendHit(seq, (k << 8) + (lane << 2) + (b & 3), __builtin_amdgcn_alignbyte(nk, dk, b & 3), has);
+            if (has) hits &= hits - 1;
             pending = __ballot(hits != 0);
         }
         if (qu - qv >= 64) verifyPending();
@@ -594,6 +594,25 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         tile = nextTile;
         seq++;
     }
+
+    /* ---- ragged tail: the < 1 KiB behind the last full tile belongs to the wave whose stride lands
+     * on it.  Every position is zeroed, then queued without filtering (the walker is exact). */
+    if (tile == numFullTiles && numFullTiles * kTileBytes < n) {
+        const size_t base = numFullTiles * kTileBytes;
+        const uint32_t rem = (uint32_t)(n - base);
+        for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t o0 = 0; o0 < rem; o0 += 64) {
+            const uint32_t o = o0 + lane;
+            const bool has = o < rem;
+            uint32_t x = 0;
+            for (int j = 0; j < 4; j++)
+                if (has && base + o + j < n) x |= (uint32_t)a.in[base + o + j] << (8 * j);
+            appendHit(seq, o, x, has);
+        }
+        qv = qu;                                     /* tail entries skip filter level 2 */
+    }
+
     /* drain: no more tiles to hide behind */
     if (qu != qv) verifyPending();
     while (busy()) walkStep();
@@ -719,7 +738,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
     const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 3u) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+                          ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kTileBytes;
     hipError_t e;
     if (hashed) e = tex ? launchMode<HASH_BUFFER>(c, a, vectorOk) : launchMode<HASH_GLOBAL>(c, a, vectorOk);
     else        e = tex ? launchMode<DENSE_BUFFER>(c, a, vectorOk) : launchMode<DENSE_GLOBAL>(c, a, vectorOk);

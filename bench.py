@@ -170,13 +170,9 @@ def main():
     handle.readPatternFromFile(pattern_file)
     info = handle.info()
 
-    n = args.size_mib << 20                              # bytes this rank owns
-    overlap = sharding.overlap_bytes(info.maxPatternLen) if rank < world - 1 else 0
-    host_in = np.empty(n + overlap, dtype=np.uint8)
-    host_in[:n] = cfg.input_slice(n, rank)               # slice `rank` of the N x size stream
-    if overlap:
-        host_in[n:] = cfg.input_slice(overlap, rank + 1)  # head of the next slice (generators are prefix-stable)
-    n_read = n + overlap
+    # slice `rank` of the N x size stream plus the head of the next slice (generators are prefix-stable)
+    host_in, n = sharding.rank_input(cfg, args.size_mib << 20, rank, world, info.maxPatternLen)
+    n_read = host_in.size
     d_in = torch.from_numpy(host_in).to(f"cuda:{local_rank}")
     d_out = torch.full((n_read,), -1, dtype=torch.int32, device=f"cuda:{local_rank}")
     torch.cuda.synchronize()
@@ -222,14 +218,8 @@ def main():
     kernel_avg_s = float(np.mean(kernel_ms)) / 1e3
 
     # ---- gather per-rank facts (RCCL: 4 x int64 per rank) ----------------------------------------
-    facts = torch.tensor([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9)], dtype=torch.int64,
-                         device=f"cuda:{local_rank}")
-    if world > 1:
-        allf = [torch.zeros_like(facts) for _ in range(world)]
-        dist.all_gather(allf, facts)
-        allf = torch.stack(allf).cpu().numpy()
-    else:
-        allf = facts.cpu().numpy()[None, :]
+    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9)],
+                                     device=f"cuda:{local_rank}")
     elapsed_max = float(allf[:, 3].max()) / 1e9
     total_matches = int(allf[:, 0].sum())
     all_ok = bool(allf[:, 2].all())

@@ -73,3 +73,31 @@ def position_checksum(positions, ids, base: int = 0) -> int:
         h = p * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
         h ^= h >> np.uint64(29)
         return int((h * v).sum(dtype=np.uint64))
+
+
+def rank_input(cfg, n: int, rank: int, world: int, max_pattern_len: int):
+    """Input one rank scans in the weak-scaling layout used by bench.py (BASELINE config 4): the
+    global stream is `world` slices of n bytes, slice i generated from seed+i; every rank but the
+    last appends the first overlap_bytes() bytes of its successor (generators are prefix-stable).
+    Returns (host_array, owned_bytes)."""
+    import numpy as np
+    overlap = overlap_bytes(max_pattern_len) if rank < world - 1 else 0
+    buf = np.empty(n + overlap, dtype=np.uint8)
+    buf[:n] = cfg.input_slice(n, rank)
+    if overlap:
+        buf[n:] = cfg.input_slice(overlap, rank + 1)
+    return buf, n
+
+
+def all_gather_facts(values, device=None):
+    """All-gather a short list of int64 facts from every rank (RCCL on GPU, gloo on CPU).
+    Returns a [world, len(values)] numpy array; no-op for a single process."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.cpu().numpy()[None, :]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()

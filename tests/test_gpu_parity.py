@@ -207,3 +207,89 @@ def test_two_handles_interleaved(workloads, oracle_results):
     finally:
         a.destroy()
         b.destroy()
+
+
+def test_golden_vectors_of_the_reference_build(golden_dir, workdir):
+    """tests/golden/ref_vectors.json (produced by the reference's own CPU code) through matchFromDevice."""
+    import json, os
+    from pfac_amd import workloads as wl
+    from tests.test_oracle_golden import _golden_input
+    vec = json.load(open(os.path.join(golden_dir, "ref_vectors.json")))
+    for case in vec["cases"]:
+        pats = getattr(wl, case["patterns"]["fn"])(*case["patterns"]["args"])
+        pf = wl.write_pattern_file(os.path.join(workdir, "gpu_golden_" + case["name"] + ".pat"), pats)
+        data = _golden_input(wl, case, pats)
+        for perf, tex, mode_name in MODES:
+            h = make_handle(pf, perf, tex)
+            try:
+                got = device_match(h, data)
+            finally:
+                h.destroy()
+            pos = np.nonzero(got)[0]
+            assert pos.tolist() == case["positions"], f"{case['name']}/{mode_name}"
+            assert got[pos].tolist() == case["ids"], f"{case['name']}/{mode_name}"
+
+
+@pytest.mark.parametrize("workload,perf", [("c3", api.PFAC_SPACE_DRIVEN), ("c2", api.PFAC_TIME_DRIVEN)])
+def test_full_size_properties(workdir, workload, perf):
+    """BASELINE.json sizes (1 GiB): size-independent properties instead of a full oracle pass.
+       (a) two independent kernels (prefilter+walkers vs one-thread-per-byte) agree on every element;
+       (b) scanning the stream in 5 slices with maxPatternLen+1 overlap reproduces the single call
+           (the reference's omp_PFAC.cpp self-check);
+       (c) sampled 256 KiB windows equal the oracle;  (d) every planted pattern is reported."""
+    from oracle import binding as ob
+    from pfac_amd import sharding
+    from pfac_amd import workloads as wl
+    n = 1 << 30
+    cfg = wl.make_config(workload)
+    pf = wl.write_pattern_file(f"{workdir}/full_{workload}.pat", cfg.patterns)
+    host = cfg.input_slice(n, 0)
+    rng = np.random.Generator(np.random.PCG64(17))
+    planted = []
+    for _ in range(64):
+        pid = int(rng.integers(0, len(cfg.patterns)))
+        at = int(rng.integers(0, n - 128))
+        p = np.frombuffer(cfg.patterns[pid], dtype=np.uint8)
+        host[at:at + p.size] = p
+        planted.append((at, pid + 1, p.size))
+    edge = np.frombuffer(cfg.patterns[3], dtype=np.uint8)
+    host[n - edge.size:] = edge                      # a match that ends exactly at the last byte
+    d_in = torch.from_numpy(host).to("cuda:0")
+    d_a = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+    h = make_handle(pf, perf, api.PFAC_AUTOMATIC)
+    try:
+        h.matchFromDevice(d_in.data_ptr(), n, d_a.data_ptr())
+        torch.cuda.synchronize()
+        assert int((d_a < 0).sum()) == 0, "every element must be written"
+        # (a)
+        d_b = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        h.setKernelVariant(api.PFACX_KERNEL_NAIVE)
+        h.matchFromDevice(d_in.data_ptr(), n, d_b.data_ptr())
+        h.setKernelVariant(api.PFACX_KERNEL_FILTER)
+        torch.cuda.synchronize()
+        assert torch.equal(d_a, d_b), "filter kernel and naive kernel disagree"
+        # (b)
+        d_b.fill_(-1)
+        overlap = sharding.overlap_bytes(h.info().maxPatternLen)
+        scratch = torch.empty((n // 5 + overlap + 4096,), dtype=torch.int32, device="cuda:0")
+        for s in sharding.plan_slices(n, 5, overlap):
+            h.matchFromDevice(d_in.data_ptr() + s.start, s.read_end - s.start, scratch.data_ptr())
+            d_b[s.start:s.end] = scratch[: s.end - s.start]
+        torch.cuda.synchronize()
+        assert torch.equal(d_a, d_b), "sliced scan differs from the single call"
+        del d_b, scratch
+        # (d)
+        res_at = d_a[torch.tensor([p[0] for p in planted], device="cuda:0")].cpu().numpy()
+        assert np.all(res_at != 0)
+        lens = np.array([0] + [len(p) for p in cfg.patterns])
+        assert np.all(lens[res_at] >= np.array([p[2] for p in planted])), "longest-match semantics"
+        assert int(d_a[n - edge.size]) != 0
+        # (c)
+        o = ob.Oracle(pf, dense=(perf == api.PFAC_TIME_DRIVEN), hashed=(perf == api.PFAC_SPACE_DRIVEN))
+        win, tail = 1 << 18, o.max_pattern_len + 1
+        for s in [0, n - win] + [int(x) for x in rng.integers(0, n - win, size=6)]:
+            want = o.match(host[s:min(n, s + win + tail)], hashed=(perf == api.PFAC_SPACE_DRIVEN), omp=True)[:win]
+            assert_same(d_a[s:s + win].cpu().numpy(), want, f"window at {s}")
+        o.close()
+    finally:
+        h.destroy()

@@ -1,0 +1,210 @@
+"""Host side of the C ABI, no GPU needed.
+
+Covers (a) the exported surface: every symbol include/*.h declares is present in libpfac.so /
+libpfac_gfx950.so; (b) the reference's status-code behaviour (PFAC/src/PFAC.cpp argument checks);
+(c) the pattern compiler and both table materialisers byte-for-byte against the oracle;
+(d) the CPU platforms (PFAC_PLATFORM_CPU / CPU_OMP) against the oracle; (e) the prefilter bitmaps
+are supersets (a miss proves the result is 0).  Everything goes through a PFACX_createHostOnly
+handle: no compute call touches a device.
+"""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pfac_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = api.load_library()
+    host, module = api.library_paths()
+    declared_host, declared_module = set(), set()
+    for header, bucket in (("PFAC.h", declared_host), ("pfac_ext.h", declared_host), ("pfac_module.h", declared_module)):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for name in re.findall(r"\b(PFACX?_[A-Za-z_]+)\s*\(", text):
+            if not name.endswith("protoType") and not name.endswith("_t") and not name.isupper():
+                bucket.add(name)
+    assert declared_host == set(api.EXPORTED_SYMBOLS), declared_host ^ set(api.EXPORTED_SYMBOLS)
+    assert declared_module == set(api.MODULE_SYMBOLS), declared_module ^ set(api.MODULE_SYMBOLS)
+    for name in declared_host:
+        assert getattr(lib, name)
+    mod = ctypes.CDLL(module)
+    for name in declared_module:
+        assert getattr(mod, name)
+
+
+def test_status_values_and_error_strings():
+    """Enum values of PFAC.h:57-70 and the texts of PFAC.cpp:1131-1183."""
+    S = api.STATUS
+    assert (S.SUCCESS, S.BASE, S.ALLOC_FAILED, S.CUDA_ALLOC_FAILED, S.INVALID_HANDLE, S.INVALID_PARAMETER,
+            S.PATTERNS_NOT_READY, S.FILE_OPEN_ERROR, S.LIB_NOT_EXIST, S.ARCH_MISMATCH, S.MUTEX_ERROR,
+            S.INTERNAL_ERROR) == (0, 10000, 10001, 10002, 10003, 10004, 10005, 10006, 10007, 10008, 10009, 10010)
+    assert api.error_string(S.SUCCESS).startswith("PFAC_STATUS_SUCCESS")
+    assert api.error_string(S.PATTERNS_NOT_READY).startswith("PFAC_STATUS_PATTERNS_NOT_READY")
+    assert api.error_string(S.FILE_OPEN_ERROR) == "PFAC_STATUS_FILE_OPEN_ERROR: pattern file does not exist"
+    assert api.error_string(10999).startswith("PFAC_STATUS_INTERNAL_ERROR")      # default branch
+
+
+def test_null_handle_and_argument_checks(workloads, tmp_path):
+    lib = api.load_library()
+    null = ctypes.c_void_p()
+    assert lib.PFAC_destroy(null) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_setPlatform(null, 0) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_setPerfMode(null, 0) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_setTextureMode(null, 0) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_readPatternFromFile(null, b"x") == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_matchFromHost(null, 1, 1, 1) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_matchFromDevice(null, 1, 1, 1) == api.STATUS.INVALID_HANDLE
+    assert lib.PFAC_dumpTransitionTable(null, None) == api.STATUS.INVALID_HANDLE
+
+    h = api.PFAC.createHostOnly()
+    assert h.setPlatform(7, check=False) == api.STATUS.INVALID_PARAMETER
+    assert h.setPerfMode(2, check=False) == api.STATUS.INVALID_PARAMETER
+    assert h.setTextureMode(3, check=False) == api.STATUS.INVALID_PARAMETER
+    buf = np.zeros(16, dtype=np.int32)
+    # order of checks: ready, input, output, size (ref PFAC.cpp:882-897)
+    assert h.matchFromHost(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.PATTERNS_NOT_READY
+    assert h.readPatternFromFile(None, check=False) == api.STATUS.INVALID_PARAMETER
+    assert h.readPatternFromFile(str(tmp_path / "missing.pat"), check=False) == api.STATUS.FILE_OPEN_ERROR
+    assert h.readPatternFromFile("x" * 300, check=False) == api.STATUS.INTERNAL_ERROR     # FILENAME_LEN, PFAC.cpp:668-672
+    h.readPatternFromFile(workloads["c1"].pattern_file)
+    assert h.matchFromHost(0, 4, buf.ctypes.data, check=False) == api.STATUS.INVALID_PARAMETER
+    assert h.matchFromHost(buf.ctypes.data, 4, 0, check=False) == api.STATUS.INVALID_PARAMETER
+    buf[:] = -3
+    assert h.matchFromHost(buf.ctypes.data, 0, buf.ctypes.data, check=False) == api.STATUS.SUCCESS
+    assert np.all(buf == -3), "size 0 must not write"
+    # a host-only handle has no GPU path and must say so loudly (no silent CPU fallback)
+    assert h.matchFromDevice(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.LIB_NOT_EXIST
+    h.setPlatform(api.PFAC_PLATFORM_GPU)
+    assert h.matchFromHost(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.LIB_NOT_EXIST
+    assert h.destroy() == api.STATUS.SUCCESS
+
+
+def test_create_without_device_forwards_the_runtime_error():
+    """ref PFAC.cpp:148-151: PFAC_create returns the raw runtime error code when no device is usable."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    h = api.PFAC.create(check=False)
+    assert 0 < h.create_status < api.STATUS.BASE
+    assert api.error_string(h.create_status)
+
+
+@pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
+def test_compiled_tables_are_byte_identical_to_the_oracle(workloads, name):
+    w = workloads[name]
+    o = ob.Oracle(w.pattern_file)
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(w.pattern_file)
+    info = h.info()
+    assert (info.numOfPatterns, info.numOfStates, info.initialState, info.maxPatternLen, info.numOfLeaves) == (
+        o.num_patterns, o.num_states, o.initial_state, o.max_pattern_len, o.num_leaves)
+    assert info.numOfTableEntry == o.num_states * 256 and info.sizeOfTableEntry == 4
+    assert np.array_equal(h.table(api.PFACX_TABLE_DENSE), o.dense_table())
+    h.setPerfMode(api.PFAC_SPACE_DRIVEN)
+    info = h.info()
+    assert info.numOfTableEntry == o.hash_total and info.sizeOfTableEntry == 8
+    assert np.array_equal(h.table(api.PFACX_TABLE_HASH_ROWPTR), o.hash_row())
+    assert np.array_equal(h.table(api.PFACX_TABLE_HASH_VALPTR), o.hash_val())
+    assert np.array_equal(h.table(api.PFACX_TABLE_INITIAL_ROW), o.initial_row())
+    h.destroy()
+
+
+def test_dump_transition_table_matches_user_guide_and_oracle(workloads, golden_dir, tmp_path):
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(os.path.join(golden_dir, "example_pattern"))
+    out = tmp_path / "t.txt"
+    h.dumpTransitionTable(str(out))
+    assert out.read_bytes() == open(os.path.join(golden_dir, "userguide_r1.2_p21_table.txt"), "rb").read()
+    for name in ("ex2", "binary", "c2"):
+        h.readPatternFromFile(workloads[name].pattern_file)
+        h.dumpTransitionTable(str(out))
+        ref = tmp_path / "o.txt"
+        ob.Oracle(workloads[name].pattern_file).dump_table(str(ref))
+        assert out.read_bytes() == ref.read_bytes(), name
+    h.destroy()
+
+
+@pytest.mark.parametrize("platform", [api.PFAC_PLATFORM_CPU, api.PFAC_PLATFORM_CPU_OMP])
+@pytest.mark.parametrize("perf", [api.PFAC_TIME_DRIVEN, api.PFAC_SPACE_DRIVEN])
+def test_cpu_platforms_equal_oracle(workloads, oracle_results, platform, perf, monkeypatch):
+    monkeypatch.setenv("OMP_NUM_THREADS", "4")          # CPU_OMP degrades to 1 thread without it (PFAC.cpp:904-908)
+    for name in ("c1", "ex2", "c2", "c3", "dense_hits", "binary"):
+        h = api.PFAC.createHostOnly()
+        h.setPlatform(platform)
+        h.setPerfMode(perf)
+        h.readPatternFromFile(workloads[name].pattern_file)
+        got = h.match_host_array(workloads[name].data)
+        h.destroy()
+        assert np.array_equal(got, oracle_results[name]), name
+
+
+def test_host_reduce_on_cpu_platform(workloads, oracle_results):
+    """ref the CPU branch of PFAC_matchFromHostReduce, PFAC.cpp:1036-1068."""
+    w = workloads["c3"]
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(w.pattern_file)
+    res = np.zeros(w.data.size, dtype=np.int32)
+    pos = np.zeros(w.data.size, dtype=np.int32)
+    st, count = h.matchFromHostReduce(w.data.ctypes.data, w.data.size, res.ctypes.data, pos.ctypes.data)
+    h.destroy()
+    ids, want_pos = ob.reduce(oracle_results["c3"])
+    assert count == ids.size
+    assert np.array_equal(res[:count], ids) and np.array_equal(pos[:count], want_pos)
+
+
+def test_pattern_file_quirks(tmp_path):
+    """last line without newline is dropped; blank line before a pattern and
+    duplicates are rejected with a status (the reference asserts / is undefined); CRLF keeps the CR."""
+    h = api.PFAC.createHostOnly()
+
+    def load(b):
+        p = tmp_path / "q.pat"
+        p.write_bytes(b)
+        return h.readPatternFromFile(str(p), check=False)
+
+    assert load(b"AB\nCD\nEF") == 0 and h.info().numOfPatterns == 2
+    assert load(b"AB\n\nCD\n") == api.STATUS.INVALID_PARAMETER
+    buf = np.zeros(4, dtype=np.int32)
+    assert h.matchFromHost(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.PATTERNS_NOT_READY, \
+        "a failed load leaves no patterns behind (ref PFAC.cpp:678-681)"
+    assert load(b"AB\nCD\nAB\n") == api.STATUS.INTERNAL_ERROR
+    assert load(b"AB\r\nC\r\n") == 0 and h.info().maxPatternLen == 3
+    assert load(b"") == 0 and h.info().numOfPatterns == 0
+    got = h.match_host_array(np.frombuffer(b"anything", dtype=np.uint8))
+    assert not got.any()
+    h.destroy()
+
+
+@pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
+def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
+    """Every position with a non-zero result passes both filter levels as the kernel evaluates them."""
+    w = workloads[name]
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(w.pattern_file)
+    info = h.info()
+    g3, g4 = h.table(api.PFACX_TABLE_FILTER_GRAM3), h.table(api.PFACX_TABLE_FILTER_GRAM4)
+    f3, sb = h.table(api.PFACX_TABLE_FILTER_FINAL3), h.table(api.PFACX_TABLE_FILTER_SHORT)
+    h.destroy()
+    d = np.concatenate([w.data, np.zeros(4, dtype=np.uint8)]).astype(np.uint64)
+    x = d[:-4] | (d[1:-3] << 8) | (d[2:-2] << 16) | (d[3:-1] << 24)
+
+    def bit(bitmap, hv):
+        return (bitmap[(hv >> 5).astype(np.int64)] >> (hv & 31).astype(np.uint32)) & 1
+
+    h3 = (((x & 0xFFFFFF) * 0x797A0B) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits)
+    h4 = ((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
+    hf = (((x & 0xFFFFFF) * 0x85EBCB) & 0xFFFFFFFF) >> (32 - info.filterLog2BitsFinal3)
+    short = bit(sb, x & 0xFFFF)
+    level1 = bit(g3, h3) | short
+    level2 = bit(g4, h4) | bit(f3, hf) | short
+    hit = oracle_results[name] != 0
+    assert np.all(level1[hit] == 1) and np.all(level2[hit] == 1)
+    assert info.filterHasShort == int(any(len(p) < 3 for p in open(w.pattern_file, "rb").read().split(b"\n") if p))

@@ -94,6 +94,26 @@ def verify(handle, api, ob, cfg_pattern_file, host_in, d_in, d_out, n, n_read, p
     return same and windows_ok, pos, ids
 
 
+def committed_traffic(workload, kernel_substr):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
+    profiles/rNN_hbm_traffic_<workload>.json): 2 x FETCH_SIZE (gfx950 reports half of coalesced
+    reads -- calibrated on the stream probe in the same file) + WRITE_SIZE, in bytes.  None if no
+    profile of this workload is committed.  PMC passes cannot run inside the timed bench process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{workload}.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if kernel_substr in k]
+        w = [v for k, v in d["WRITE_SIZE"]["scan"].items() if kernel_substr in k]
+        if not f or not w:
+            return None, None
+        return int((2.0 * f[0] + w[0]) * 1024), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(ob, pattern_file, host_in, perf_mode, target_seconds):
     """Reference OpenMP matcher (oracle/_ref) -- or the C port if _ref is absent -- on a bounded sample."""
     threads = ob.omp_max_threads()
@@ -228,6 +248,9 @@ def main():
         ms_per_step = elapsed_max / args.steps * 1e3
         value = world * n / (elapsed_max / args.steps) / 1e9
         achieved = ALGO_BYTES_PER_INPUT_BYTE * n_read / kernel_avg_s / 1e9
+        kname = "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive"
+        traffic, traffic_src = (committed_traffic(cfg.name, kname) if args.size_mib == 1024 and perf_mode == cfg.perf_mode
+                                else (None, None))
         out = {
             "metric": "input GB/s scanned (PFAC_matchFromDevice, bit-exact)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,8 +266,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kname,
                 "kernel_ms_avg": round(kernel_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_INPUT_BYTE * n_read,
                 "input_only_frac": round(n_read / kernel_avg_s / 1e9 / HBM_PEAK_GBS, 4),

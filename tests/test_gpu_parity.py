@@ -293,3 +293,17 @@ def test_full_size_properties(workdir, workload, perf):
         o.close()
     finally:
         h.destroy()
+
+
+def test_cpp_example_program_prints_the_readme_answer(tmp_path):
+    """examples/simple_example.cpp (re-authored PFAC/test/simple_example.cpp) linked against the
+    drop-in library prints README.md:113-120."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-B"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "examples", "simple_example")], cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("At position")]
+    assert lines == ["At position    0, match pattern 1", "At position    1, match pattern 3",
+                     "At position    2, match pattern 4", "At position    4, match pattern 4",
+                     "At position    6, match pattern 2"]

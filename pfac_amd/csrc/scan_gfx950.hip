@@ -219,61 +219,62 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
 
 /*
  * Walkers are split-phase: issue() starts the loads of the next transition, consume() finishes it.
- * The scan loop calls consume/refill/issue once per tile, so the (long, queueing-dominated) latency
- * of the dependent table loads is hidden behind the streaming and filtering of the next tile
- * instead of stalling the wave.
+ * Each lane runs kWalkSets independent walks; per scan iteration all of them issue, then the tile
+ * prefetch and the zero stores are issued, and only then the (single) wait of the iteration happens,
+ * so one memory round trip covers kWalkSets x 64 table steps plus the streaming traffic.
  *
- * Per-lane walker over the DENSE table (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.
- * Input bytes come 16 at a time; a step that runs out of window only refills the window.
+ * Shared, wave-uniform context of the DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte
+ * gather per byte.  Input bytes come 16 at a time; a step that runs out of window only refills it.
  */
-template <int MODE> struct Walker {
+template <int MODE> struct DenseCtx {
     static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
     const Lookup<MODE> lookup;
     const uint32_t *in32;
     size_t n, numDwords;
     int numFinal;
     const int *sInit;
-    /* lane state */
-    size_t pos;
-    int state, match;
-    uint32_t depth, have;                      /* have = input bytes left in win */
-    uint64_t win;
-    /* in flight */
-    int loadedState;
-    u32x4 loadedWindow;
-    uint32_t pulledBack;
-    bool refilling;
-    bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
-
-    __device__ Walker(const ScanArgs &a, const Lds &lds, size_t numDw)
+    __device__ DenseCtx(const ScanArgs &a, const Lds &lds, size_t numDw)
         : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
-          numFinal(a.numFinal), sInit(lds.init), pos(0), state(kTrap), match(0), depth(0), have(0), win(0),
-          loadedState(kTrap), loadedWindow{0, 0, 0, 0}, pulledBack(0), refilling(false), sawLoad(false) {}
+          numFinal(a.numFinal), sInit(lds.init) {}
+};
+
+template <int MODE> struct DenseLane {
+    using Ctx = DenseCtx<MODE>;
+    size_t pos = 0;
+    int state = kTrap, match = 0;
+    uint32_t depth = 0, have = 0;              /* have = input bytes left in win */
+    uint64_t win = 0;
+    /* in flight */
+    int loadedState = kTrap;
+    u32x4 loadedWindow = {0, 0, 0, 0};
+    uint32_t pulledBack = 0;
+    bool refilling = false;
+    bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    __device__ __forceinline__ bool start(const Ctx &c, size_t p, uint32_t x)
     {
         pos = p; refilling = false; sawLoad = false;
-        state = sInit[x & 0xFF];
-        match = (state != kTrap && state <= numFinal) ? state : 0;
+        state = c.sInit[x & 0xFF];
+        match = (state != kTrap && state <= c.numFinal) ? state : 0;
         win = x >> 8; have = 3; depth = 1;
         return state != kTrap;
     }
-    __device__ __forceinline__ bool issue()
+    __device__ __forceinline__ bool issue(const Ctx &c)
     {
-        if (pos + depth >= n) return false;
+        if (pos + depth >= c.n) return false;
         if (have == 0) {                                       /* window exhausted: fetch 8 more bytes */
-            loadedWindow = loadWindow16(in32, pos + depth, numDwords, pulledBack);
+            loadedWindow = loadWindow16(c.in32, pos + depth, c.numDwords, pulledBack);
             refilling = true;
             return true;
         }
-        int s = lookup(state, (int)(win & 0xFF));
+        int s = c.lookup(state, (int)(win & 0xFF));
         if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
         loadedState = s;
         return true;
     }
-    __device__ __forceinline__ bool consume()
+    __device__ __forceinline__ bool consume(const Ctx &c)
     {
         sawLoad = true;
         if (refilling) {
@@ -286,19 +287,19 @@ template <int MODE> struct Walker {
         }
         if (loadedState == kTrap) return false;
         state = loadedState;
-        if (state <= numFinal) match = state;
+        if (state <= c.numFinal) match = state;
         win >>= 8; have--; depth++;
         return true;
     }
 };
 
 /*
- * Per-lane walker over the CHAINED hashed table (tables.cpp: buildChainedHashTable).  Each step
- * consumes the edge byte plus the slot's single-successor chain (up to 11 bytes) with one
- * dependent memory round trip: the 32-byte slot and the 16-byte input window are independent loads,
- * and the window always contains the edge byte of the NEXT step (1 + 11 + 1 <= 13 usable bytes).
+ * CHAINED hashed table walkers (tables.cpp: buildChainedHashTable).  Each step consumes the edge
+ * byte plus the slot's single-successor chain (up to 11 bytes) with one dependent memory round
+ * trip: the 32-byte slot and the 16-byte input window are independent loads, and the window always
+ * contains the edge byte of the NEXT step (1 + 11 + 1 <= 13 usable bytes).
  */
-template <int MODE> struct ChainWalker {
+template <int MODE> struct ChainCtx {
     static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -306,32 +307,33 @@ template <int MODE> struct ChainWalker {
     const uint32_t *in32;
     size_t n, numDwords;
     int numFinal;
-    /* lane state */
-    size_t pos;
-    int off, ks, match;
-    uint32_t b0, depth;
-    /* in flight: every loaded register is consumed later (a dead destination register would be
-     * recycled by the compiler and force an early wait), hence the 12-byte load of the chain half */
-    u32x4 s0, w;
-    u32x3 s1;
-    uint32_t pulledBack;
-    bool sawLoad;                              /* a global load issued after this position's zero stores has completed */
-
-    __device__ ChainWalker(const ScanArgs &a, const Lds &lds, size_t numDw)
+    __device__ ChainCtx(const ScanArgs &a, const Lds &lds, size_t numDw)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
           sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
-          numFinal(a.numFinal), pos(0), off(-1), ks(-1), match(0), b0(0), depth(0),
-          s0{0, 0, 0, 0}, w{0, 0, 0, 0}, s1{0, 0, 0}, pulledBack(0), sawLoad(false) {}
+          numFinal(a.numFinal) {}
+};
+
+template <int MODE> struct ChainLane {
+    using Ctx = ChainCtx<MODE>;
+    size_t pos = 0;
+    int off = -1, ks = -1, match = 0;
+    uint32_t b0 = 0, depth = 0;
+    /* in flight: every loaded register is consumed later (a dead destination register would be
+     * recycled by the compiler and force an early wait), hence the 12-byte load of the chain half */
+    u32x4 s0 = {0, 0, 0, 0}, w = {0, 0, 0, 0};
+    u32x3 s1 = {0, 0, 0};
+    uint32_t pulledBack = 0;
+    bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
     /* Take the transition described by slot {t0,t1} on edge byte b0 at position p, given the
      * 16-byte input window `win` loaded at p & ~3: compares the chain, lands in the slot's end
      * state and picks the next edge byte out of the same window.  False = trap. */
-    __device__ __forceinline__ bool advance(const u32x4 &t0, const u32x3 &t1, const u32x4 &win, size_t p)
+    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t0, const u32x3 &t1, const u32x4 &win, size_t p)
     {
         if ((t0.y & 0xFFu) != b0 || (int)t0.y < 0) return false;     /* empty slot or another byte's slot */
         const uint32_t k = (t0.y >> 8) & 0xFFu;
-        if (p + 1 + k > n) return false;                       /* the chain would run past the input */
+        if (p + 1 + k > c.n) return false;                     /* the chain would run past the input */
         const uint32_t o = ((uint32_t)p & 3u) + 1u;             /* window offset of the first chain byte */
         const uint32_t m0 = k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u);
         const uint32_t m1 = k >= 8 ? 0xFFFFFFFFu : (k > 4 ? ((1u << (8 * (k - 4))) - 1u) : 0u);
@@ -340,7 +342,7 @@ template <int MODE> struct ChainWalker {
                               ((windowDword(win, o + 8) ^ t1.z) & m2);
         if (diff != 0) return false;                           /* mismatch inside the chain = trap */
         const int end = (int)t0.x;
-        if (end <= numFinal) match = end;                      /* skipped chain states are never final */
+        if (end <= c.numFinal) match = end;                    /* skipped chain states are never final */
         off = (int)t0.z; ks = (int)t0.w;
         depth += 1 + k;
         b0 = windowDword(win, o + k) & 0xFFu;                  /* edge byte of the next step (o + k <= 15) */
@@ -351,11 +353,11 @@ template <int MODE> struct ChainWalker {
      * its chain fits into the four bytes that came with the queue entry (chain length <= 2, the
      * common case) no memory is touched; a longer root chain fetches its window synchronously.
      * Returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(size_t p, uint32_t x)
+    __device__ __forceinline__ bool start(const Ctx &c, size_t p, uint32_t x)
     {
         pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = -1; ks = -1; sawLoad = false;
-        const u32x4 r0 = sRoot[b0 * 2];
-        const u32x4 r1w = sRoot[b0 * 2 + 1];
+        const u32x4 r0 = c.sRoot[b0 * 2];
+        const u32x4 r1w = c.sRoot[b0 * 2 + 1];
         const u32x3 r1 = {r1w.x, r1w.y, r1w.z};
         if ((int)r0.y < 0) return false;                       /* no transition on this byte */
         if (((r0.y >> 8) & 0xFFu) <= 2) {
@@ -365,45 +367,51 @@ template <int MODE> struct ChainWalker {
             win.x = x << (8 * sh);
             win.y = sh ? x >> (8 * (4 - sh)) : 0u;
             win.z = 0; win.w = 0;
-            return advance(r0, r1, win, p);
+            return advance(c, r0, r1, win, p);
         }
         uint32_t back;
-        const u32x4 raw = loadWindow16(in32, p, numDwords, back);
+        const u32x4 raw = loadWindow16(c.in32, p, c.numDwords, back);
         sawLoad = true;
-        return advance(r0, r1, fixWindow16(raw, back), p);
+        return advance(c, r0, r1, fixWindow16(raw, back), p);
     }
-    __device__ __forceinline__ bool issue()
+    __device__ __forceinline__ bool issue(const Ctx &c)
     {
         const size_t p = pos + depth;                          /* position of the edge byte b0 */
-        if (p >= n || off < 0) return false;                   /* end of input, or a state without transitions */
+        if (p >= c.n || off < 0) return false;                 /* end of input, or a state without transitions */
         const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
         if (MODE == HASH_BUFFER) {
-            s0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 32u), 0, 0);
-            s1 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(idx * 32u + 16u), 0, 0);
+            s0 = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 32u), 0, 0);
+            s1 = __builtin_amdgcn_raw_buffer_load_b96(c.rsrc, (int)(idx * 32u + 16u), 0, 0);
         } else {
-            s0 = slots[(size_t)idx * 2];
-            s1 = *reinterpret_cast<const u32x3 *>(&slots[(size_t)idx * 2 + 1]);
+            s0 = c.slots[(size_t)idx * 2];
+            s1 = *reinterpret_cast<const u32x3 *>(&c.slots[(size_t)idx * 2 + 1]);
         }
-        w = loadWindow16(in32, p, numDwords, pulledBack);
+        w = loadWindow16(c.in32, p, c.numDwords, pulledBack);
         return true;
     }
-    __device__ __forceinline__ bool consume()
+    __device__ __forceinline__ bool consume(const Ctx &c)
     {
         sawLoad = true;                                        /* a global load issued after the walk started has landed */
-        return advance(s0, s1, fixWindow16(w, pulledBack), pos + depth);
+        return advance(c, s0, s1, fixWindow16(w, pulledBack), pos + depth);
     }
 };
 
-template <int MODE> struct WalkerFor { using type = Walker<MODE>; };
-template <> struct WalkerFor<HASH_GLOBAL> { using type = ChainWalker<HASH_GLOBAL>; };
-template <> struct WalkerFor<HASH_BUFFER> { using type = ChainWalker<HASH_BUFFER>; };
+template <int MODE> struct WalkTypes { using Ctx = DenseCtx<MODE>; using Lane = DenseLane<MODE>; };
+template <> struct WalkTypes<HASH_GLOBAL> { using Ctx = ChainCtx<HASH_GLOBAL>; using Lane = ChainLane<HASH_GLOBAL>; };
+template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; using Lane = ChainLane<HASH_BUFFER>; };
 
 /* --------------------------------------------------------- filter kernel */
+
+constexpr int kTilesPerIter = 2;              /* 1 KiB tiles a wave handles per loop iteration        */
+constexpr int kWalkSets = 3;                  /* independent walks per lane                           */
+constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
 
 template <int MODE, bool HAS_SHORT>
 __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 {
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
+    using WCtx = typename WalkTypes<MODE>::Ctx;
+    using WLane = typename WalkTypes<MODE>::Lane;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words3 = 1 << (a.log2Bits - 5), words4 = 1 << (a.log2Bits4 - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
@@ -433,23 +441,27 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     uint32_t *qBytes = sQBytesAll + wave * kQueueCap;   /* ring: first four input bytes of the position   */
-    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: (tile sequence number << 10) | offset    */
+    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: (chunk sequence number << 11) | offset   */
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
+    const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const size_t n = a.n;
     const size_t numDwords = (n + 3) >> 2;          /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
                   32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
-    typename WalkerFor<MODE>::type walker(a, lds, numDwords);
+    const WCtx wctx(a, lds, numDwords);
+    WLane walk[kWalkSets];
+    bool alive[kWalkSets];
+#pragma unroll
+    for (int s = 0; s < kWalkSets; s++) alive[s] = false;
     const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
-    const size_t firstTile = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t firstChunk = (size_t)blockIdx.x * kWavesPerBlock + wave;
 
     /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
      *   [qh, qv)  passed both filter levels, waiting for a walker lane
      *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
     uint32_t qh = 0, qv = 0, qu = 0;
     constexpr uint32_t kMask = kQueueCap - 1;
-    bool alive = false;                             /* this lane's walker is in the middle of a walk */
 
     /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
      * the walk survives four transitions, or a pattern of length <= 3 can match here */
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         uint32_t w = qv;
         for (uint32_t r = qv; r != qu; r += (qu - r < 64 ? qu - r : 64)) {
             const uint32_t idx = r + lane;
-            const bool act = idx - r < qu - r && lane < (int)(qu - r);
+            const bool act = (uint32_t)lane < qu - r;
             const uint32_t x = act ? qBytes[idx & kMask] : 0u;
             const uint32_t e = act ? qPos[idx & kMask] : 0u;
             uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
@@ -476,129 +488,153 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     };
 
     /* Zero stores and walker loads of one wave complete in issue order (a single in-order vmcnt
-     * counter), and a position is only walked after the loads issued behind its tile's zero stores
-     * have been consumed, so the patch always lands on top of the zero. */
-    auto finish = [&]() {
-        if (walker.match != 0) {
-            /* walks that ended without consuming a global load (patterns resolved from LDS alone) have
-             * no such ordering: drain this wave's stores first */
-            if (!walker.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            a.out[walker.pos] = walker.match;
+     * counter), and a position is only walked after the loads issued behind its chunk's zero stores
+     * have been consumed, so the patch always lands on top of the zero.  Walks that ended without
+     * consuming a global load (patterns resolved from LDS alone) drain this wave's stores first. */
+    auto finish = [&](const WLane &w) {
+        if (w.match != 0) {
+            if (!w.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.out[w.pos] = w.match;
         }
     };
-    /* one split-phase step of all 64 walker lanes: finish the transition issued last time, hand
-     * queue entries to idle lanes, start the next transition */
-    auto walkStep = [&]() {
-        if (alive && !walker.consume()) { alive = false; finish(); }
-        const uint64_t idle = __ballot(!alive);
-        if (idle && qh != qv) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t rank = laneRankIn(idle);
-            if (!alive && rank < qv - qh) {
-                const uint32_t e = qPos[(qh + rank) & kMask];
-                alive = walker.start((firstTile + (size_t)(e >> 10) * totalWaves) * kTileBytes + (e & 1023u),
-                                     qBytes[(qh + rank) & kMask]);
-                if (!alive) finish();
-            }
-            const uint32_t taken = (uint32_t)__popcll(idle);
-            qh += taken < qv - qh ? taken : qv - qh;
-        }
-        if (alive && !walker.issue()) { alive = false; finish(); }
-    };
-    auto busy = [&]() { return __ballot(alive) != 0 || qh != qv; };
-
-    /* The main loop only sees FULL tiles and issues the same vector-memory instructions on every
-     * path (5 loads + 4 stores per tile; the prefetch past the end is clamped, not skipped), so the
-     * compiler's s_waitcnt vmcnt(N) are counted waits and the prefetched tile / walker loads really
-     * stay in flight across the filter work.  The ragged tail (< 1 KiB) is handled after the loop. */
-    const size_t numFullTiles = n / kTileBytes;              /* >= 1: the launcher sends smaller inputs elsewhere */
-    auto loadFullTile = [&](size_t t, uint32_t (&d)[4], uint32_t &halo) {
-        const size_t tc = t < numFullTiles ? t : numFullTiles - 1;
-        const size_t dwBase = tc * (kTileBytes / 4);
+    auto walkIssue = [&]() {
 #pragma unroll
-        for (int k = 0; k < 4; k++) d[k] = in32[dwBase + k * 64 + lane];
-        const bool haveHalo = dwBase + 256 < numDwords;
-        const uint32_t h = in32[haveHalo ? dwBase + 256 : numDwords - 1];
-        halo = haveHalo ? h : 0u;
+        for (int s = 0; s < kWalkSets; s++)
+            if (alive[s] && !walk[s].issue(wctx)) { alive[s] = false; finish(walk[s]); }
+    };
+    auto walkConsume = [&]() {
+#pragma unroll
+        for (int s = 0; s < kWalkSets; s++)
+            if (alive[s] && !walk[s].consume(wctx)) { alive[s] = false; finish(walk[s]); }
+    };
+    /* hand verified queue entries to idle walker lanes; the first transition happens here (LDS) */
+    auto walkRefill = [&]() {
+#pragma unroll
+        for (int s = 0; s < kWalkSets; s++) {
+            const uint64_t idle = __ballot(!alive[s]);
+            if (idle && qh != qv) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t rank = laneRankIn(idle);
+                if (!alive[s] && rank < qv - qh) {
+                    const uint32_t e = qPos[(qh + rank) & kMask];
+                    alive[s] = walk[s].start(wctx, (firstChunk + (size_t)(e >> 11) * totalWaves) * kChunkBytes + (e & 2047u),
+                                             qBytes[(qh + rank) & kMask]);
+                    if (!alive[s]) finish(walk[s]);
+                }
+                const uint32_t taken = (uint32_t)__popcll(idle);
+                qh += taken < qv - qh ? taken : qv - qh;
+            }
+        }
+    };
+    auto anyAlive = [&]() {
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < kWalkSets; s++) any |= alive[s];
+        return __ballot(any) != 0;
     };
     auto appendHit = [&](uint32_t seq, uint32_t offset, uint32_t x, bool has) {
         if (qu - qh + 64 > kQueueCap) {
             verifyPending();
-            while (qu - qh + 64 > kQueueCap) walkStep();         /* still full: walk until there is room */
+            while (qu - qh + 64 > kQueueCap) { walkRefill(); walkIssue(); walkConsume(); }   /* full: walk until there is room */
         }
         const uint64_t m = __ballot(has);
         if (m) {
             const uint32_t at = (qu + laneRankIn(m)) & kMask;
-            if (has) { qPos[at] = (seq << 10) + offset; qBytes[at] = x; }
+            if (has) { qPos[at] = (seq << 11) + offset; qBytes[at] = x; }
             qu += (uint32_t)__popcll(m);
         }
     };
 
-    size_t tile = firstTile;
-    uint32_t seq = 0;                               /* tile = firstTile + seq * totalWaves */
-    uint32_t d[4] = {0, 0, 0, 0}, halo = 0;
-    if (tile < numFullTiles) loadFullTile(tile, d, halo);
+    /* The main loop only sees FULL chunks and issues the same vector-memory instructions on every
+     * path (the prefetch past the end is clamped, not skipped).  The ragged tail is handled after. */
+    const size_t numFullChunks = n / kChunkBytes;            /* >= 1: the launcher sends smaller inputs elsewhere */
+    auto loadChunk = [&](size_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
+        const size_t cc = c < numFullChunks ? c : numFullChunks - 1;
+        const size_t q = cc * (kChunkBytes / 16);
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
+        const size_t hd = (cc + 1) * (kChunkBytes / 4);
+        const bool haveHalo = hd < numDwords;
+        const uint32_t h = in32[haveHalo ? hd : numDwords - 1];
+        halo = haveHalo ? h : 0u;
+    };
 
-    while (tile < numFullTiles) {
-        /* ---- 1. walkers: finish the transitions issued one tile ago, start the next ones */
-        if (busy()) walkStep();
+    size_t chunk = firstChunk;
+    uint32_t seq = 0;                               /* chunk = firstChunk + seq * totalWaves */
+    u32x4 d[kTilesPerIter];
+    uint32_t halo = 0;
+    if (chunk < numFullChunks) loadChunk(chunk, d, halo);
 
-        /* ---- 2. prefetch the next tile of this wave: its loads stay in flight during 3..5 */
-        const size_t nextTile = tile + totalWaves;
-        uint32_t nd[4], nhalo;
-        loadFullTile(nextTile, nd, nhalo);
+    while (chunk < numFullChunks) {
+        /* ---- 1. start the next transition of every live walk (kWalkSets x 64 table steps) */
+        walkIssue();
+
+        /* ---- 2. prefetch the next chunk of this wave */
+        const size_t nextChunk = chunk + totalWaves;
+        u32x4 nd[kTilesPerIter];
+        uint32_t nhalo;
+        loadChunk(nextChunk, nd, nhalo);
 
         /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
         {
-            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + tile * kTileBytes);
+            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + chunk * kChunkBytes);
             const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
+            for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
         }
 
-        /* ---- 4. filter level 1: one LDS bit test per start position */
-        uint32_t hits = 0;
-        uint32_t nxt[4];
+        /* ---- 4. finish the transitions issued in 1 (the one exposed wait of the iteration) */
+        walkConsume();
+
+        /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test each */
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            nxt[k] = (uint32_t)__shfl_down((int)d[k], 1);
-            const uint32_t wrap = (k < 3) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d[(k + 1) & 3]) : halo;
-            if (lane == 63) nxt[k] = wrap;
+        for (int t = 0; t < kTilesPerIter; t++) {
+            const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
+            uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
+            const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d[(t + 1) % kTilesPerIter].x) : halo;
+            if (lane == 63) nxtLane = wrap;
+            uint32_t hits = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t x = __builtin_amdgcn_alignbyte(nxt[k], d[k], i);   /* bytes pos..pos+3 */
-                /* __umul24 returns int: the shift must be logical */
-                uint32_t bit = testBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul) >> lds.shift3);
-                if (HAS_SHORT) bit |= testBit(sShort, x & 0xFFFFu);
-                hits |= bit << (k * 4 + i);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t x = __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
+                    /* __umul24 returns int: the shift must be logical */
+                    uint32_t bit = testBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul) >> lds.shift3);
+                    if (HAS_SHORT) bit |= testBit(sShort, x & 0xFFFFu);
+                    hits |= bit << (j * 4 + i);
+                }
             }
-        }
-
-        /* ---- 5. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
-        uint64_t pending = __ballot(hits != 0);
-        while (pending) {                                   /* wave-uniform: max hits per lane iterations */
-            const bool has = hits != 0;
-            const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
-            const uint32_t k = b >> 2;
-            const uint32_t dk = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
-            const uint32_t nk = k == 0 ? nxt[0] : k == 1 ? nxt[1] : k == 2 ? nxt[2] : nxt[3];
-            appendHit(seq, (k << 8) + (lane << 2) + (b & 3), __builtin_amdgcn_alignbyte(nk, dk, b & 3), has);
-            if (has) hits &= hits - 1;
-            pending = __ballot(hits != 0);
+            /* ---- 6. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
+            uint64_t pending = __ballot(hits != 0);
+            while (pending) {                               /* wave-uniform: max hits per lane iterations */
+                const bool has = hits != 0;
+                const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
+                const uint32_t j = b >> 2;
+                const uint32_t lo = j == 0 ? dw[0] : j == 1 ? dw[1] : j == 2 ? dw[2] : dw[3];
+                const uint32_t hi = j == 0 ? dw[1] : j == 1 ? dw[2] : j == 2 ? dw[3] : nxtLane;
+                appendHit(seq, (uint32_t)(t * kTileBytes + (lane << 4)) + b, __builtin_amdgcn_alignbyte(hi, lo, b & 3), has);
+                if (has) hits &= hits - 1;
+                pending = __ballot(hits != 0);
+            }
         }
         if (qu - qv >= 64) verifyPending();
 
+        /* ---- 7. give idle walker lanes new positions (first transition from LDS) */
+        walkRefill();
+
 #pragma unroll
-        for (int k = 0; k < 4; k++) d[k] = nd[k];
+        for (int t = 0; t < kTilesPerIter; t++) d[t] = nd[t];
         halo = nhalo;
-        tile = nextTile;
+        chunk = nextChunk;
         seq++;
     }
 
-    /* ---- ragged tail: the < 1 KiB behind the last full tile belongs to the wave whose stride lands
-     * on it.  Every position is zeroed, then queued without filtering (the walker is exact). */
-    if (tile == numFullTiles && numFullTiles * kTileBytes < n) {
-        const size_t base = numFullTiles * kTileBytes;
+    /* ---- ragged tail: the < kChunkBytes behind the last full chunk belong to the wave whose stride
+     * lands on it.  Every position is zeroed, then queued without filtering (the walker is exact). */
+    if (chunk == numFullChunks && numFullChunks * kChunkBytes < n) {
+        const size_t base = numFullChunks * kChunkBytes;
         const uint32_t rem = (uint32_t)(n - base);
         for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -613,9 +649,10 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         qv = qu;                                     /* tail entries skip filter level 2 */
     }
 
-    /* drain: no more tiles to hide behind */
+    /* drain: no more chunks to hide behind */
     if (qu != qv) verifyPending();
-    while (busy()) walkStep();
+    walkRefill();
+    while (anyAlive() || qh != qv) { walkIssue(); walkConsume(); walkRefill(); }
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -670,8 +707,8 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlockThreads, lds);
     if (e != hipSuccess) return e;
     if (perCU < 1) perCU = 1;
-    const size_t numTiles = (a.n + kTileBytes - 1) / kTileBytes;
-    size_t blocks = (numTiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t numChunks = (a.n + kChunkBytes - 1) / kChunkBytes;
+    size_t blocks = (numChunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
@@ -737,8 +774,8 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         const size_t biggest = hashed ? c->numChainSlots * sizeof(pfac::ChainSlot) : c->h_dense.size() * sizeof(int);
         if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
-    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 3u) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kTileBytes;
+    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kChunkBytes;
     hipError_t e;
     if (hashed) e = tex ? launchMode<HASH_BUFFER>(c, a, vectorOk) : launchMode<HASH_GLOBAL>(c, a, vectorOk);
     else        e = tex ? launchMode<DENSE_BUFFER>(c, a, vectorOk) : launchMode<DENSE_GLOBAL>(c, a, vectorOk);

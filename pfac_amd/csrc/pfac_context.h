@@ -29,13 +29,14 @@ constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX,
 constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
-constexpr int kChainMax = 11;                 /* bytes of single-successor chain folded into one slot */
+constexpr int kChainMax = 8;                  /* bytes of single-successor chain folded into one slot */
 struct ChainSlot {                            /* 32-byte device slot of the chained hashed table        */
     int end;                                  /* state after the edge byte and the whole chain          */
     int meta;                                 /* edge byte | chain length << 8; -1 = empty slot         */
     int endOff, endKS;                        /* hashRowPtr[end] = {offset, (k<<16)|(S-1)}              */
-    unsigned char chain[12];                  /* chain bytes (kChainMax used)                           */
-    int pad;
+    unsigned char chain[8];                   /* chain bytes, zero padded                               */
+    unsigned char mask[8];                    /* 0xFF for each chain byte in use (saves the kernel from
+                                                 building the compare mask out of the length)          */
 };
 static_assert(sizeof(ChainSlot) == 32, "ChainSlot is read as two 16-byte loads");
 

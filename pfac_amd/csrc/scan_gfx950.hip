@@ -185,15 +185,16 @@ struct Lds {
 };
 
 /* 16 input bytes from the 4-byte aligned address at or below byte `pos` (the input base is 4-byte
- * aligned on this path); dwords at or beyond numDwords read as 0 (pos < 4*numDwords + 16). */
-__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, size_t pos, size_t numDwords, uint32_t &pulledBack)
+ * aligned on this path); dwords at or beyond numDwords read as 0.  Positions are 32-bit: the
+ * launcher splits inputs of 4 GiB and more into several launches. */
+__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos, uint32_t numDwords, uint32_t &pulledBack)
 {
     /* exactly one load instruction on every path (keeps the compiler's vmcnt bookkeeping exact) and no
      * use of the loaded value here (the load must stay in flight); numDwords >= 4 on this path.  Near
      * the end of the input the load is pulled back by `pulledBack` dwords; fixWindow16() undoes it. */
-    const size_t w = pos >> 2;
-    const size_t wc = w + 4 <= numDwords ? w : numDwords - 4;
-    pulledBack = (uint32_t)(w - wc);
+    const uint32_t w = pos >> 2;
+    const uint32_t wc = w + 4 <= numDwords ? w : numDwords - 4;
+    pulledBack = w - wc;
     return *reinterpret_cast<const u32x4_a4 *>(in32 + wc);
 }
 
@@ -222,6 +223,8 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
  * Each lane runs kWalkSets independent walks; per scan iteration all of them issue, then the tile
  * prefetch and the zero stores are issued, and only then the (single) wait of the iteration happens,
  * so one memory round trip covers kWalkSets x 64 table steps plus the streaming traffic.
+ * The walker code is the largest consumer of VALU issue slots on pattern-dense input (profiles/),
+ * hence 32-bit positions and host-precomputed compare masks.
  *
  * Shared, wave-uniform context of the DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte
  * gather per byte.  Input bytes come 16 at a time; a step that runs out of window only refills it.
@@ -230,17 +233,17 @@ template <int MODE> struct DenseCtx {
     static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
     const Lookup<MODE> lookup;
     const uint32_t *in32;
-    size_t n, numDwords;
+    uint32_t n, numDwords;
     int numFinal;
     const int *sInit;
-    __device__ DenseCtx(const ScanArgs &a, const Lds &lds, size_t numDw)
-        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
+    __device__ DenseCtx(const ScanArgs &a, const Lds &lds, uint32_t numDw)
+        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw),
           numFinal(a.numFinal), sInit(lds.init) {}
 };
 
 template <int MODE> struct DenseLane {
     using Ctx = DenseCtx<MODE>;
-    size_t pos = 0;
+    uint32_t pos = 0;
     int state = kTrap, match = 0;
     uint32_t depth = 0, have = 0;              /* have = input bytes left in win */
     uint64_t win = 0;
@@ -253,7 +256,7 @@ template <int MODE> struct DenseLane {
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, size_t p, uint32_t x)
+    __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
         pos = p; refilling = false; sawLoad = false;
         state = c.sInit[x & 0xFF];
@@ -278,7 +281,7 @@ template <int MODE> struct DenseLane {
     {
         sawLoad = true;
         if (refilling) {
-            const uint32_t o = (uint32_t)(pos + depth) & 3u;
+            const uint32_t o = (pos + depth) & 3u;
             const u32x4 lw = fixWindow16(loadedWindow, pulledBack);
             win = ((uint64_t)windowDword(lw, o + 4) << 32) | windowDword(lw, o);
             have = 8;
@@ -295,9 +298,9 @@ template <int MODE> struct DenseLane {
 
 /*
  * CHAINED hashed table walkers (tables.cpp: buildChainedHashTable).  Each step consumes the edge
- * byte plus the slot's single-successor chain (up to 11 bytes) with one dependent memory round
- * trip: the 32-byte slot and the 16-byte input window are independent loads, and the window always
- * contains the edge byte of the NEXT step (1 + 11 + 1 <= 13 usable bytes).
+ * byte plus the slot's single-successor chain (up to 8 bytes) with one dependent memory round trip:
+ * the 32-byte slot and the 16-byte input window are independent loads, and the window always
+ * contains the edge byte of the NEXT step (1 + 8 + 1 <= 13 usable bytes).
  */
 template <int MODE> struct ChainCtx {
     static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
@@ -305,47 +308,50 @@ template <int MODE> struct ChainCtx {
     __amdgpu_buffer_rsrc_t rsrc;
     const u32x4 *sRoot;
     const uint32_t *in32;
-    size_t n, numDwords;
+    uint32_t n, numDwords;
     int numFinal;
-    __device__ ChainCtx(const ScanArgs &a, const Lds &lds, size_t numDw)
+    __device__ ChainCtx(const ScanArgs &a, const Lds &lds, uint32_t numDw)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n(a.n), numDwords(numDw),
+          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw),
           numFinal(a.numFinal) {}
 };
 
 template <int MODE> struct ChainLane {
     using Ctx = ChainCtx<MODE>;
-    size_t pos = 0;
+    uint32_t pos = 0;
     int off = -1, ks = -1, match = 0;
     uint32_t b0 = 0, depth = 0;
-    /* in flight: every loaded register is consumed later (a dead destination register would be
-     * recycled by the compiler and force an early wait), hence the 12-byte load of the chain half */
-    u32x4 s0 = {0, 0, 0, 0}, w = {0, 0, 0, 0};
-    u32x3 s1 = {0, 0, 0};
+    /* in flight: all eight slot dwords and all four window dwords are consumed later (a dead
+     * destination register would be recycled by the compiler and force an early wait) */
+    u32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, w = {0, 0, 0, 0};
     uint32_t pulledBack = 0;
     bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
-    /* Take the transition described by slot {t0,t1} on edge byte b0 at position p, given the
-     * 16-byte input window `win` loaded at p & ~3: compares the chain, lands in the slot's end
-     * state and picks the next edge byte out of the same window.  False = trap. */
-    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t0, const u32x3 &t1, const u32x4 &win, size_t p)
+    /* Take the transition described by slot {t0 = end, meta, end.off, end.ks; t1 = chain[8], mask[8]}
+     * on edge byte b0 at position p, given the 16-byte input window `win` loaded at p & ~3: compares
+     * the chain, lands in the slot's end state and picks the next edge byte out of the same window.
+     * False = trap. */
+    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t0, const u32x4 &t1, const u32x4 &win, uint32_t p)
     {
         if ((t0.y & 0xFFu) != b0 || (int)t0.y < 0) return false;     /* empty slot or another byte's slot */
         const uint32_t k = (t0.y >> 8) & 0xFFu;
         if (p + 1 + k > c.n) return false;                     /* the chain would run past the input */
-        const uint32_t o = ((uint32_t)p & 3u) + 1u;             /* window offset of the first chain byte */
-        const uint32_t m0 = k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u);
-        const uint32_t m1 = k >= 8 ? 0xFFFFFFFFu : (k > 4 ? ((1u << (8 * (k - 4))) - 1u) : 0u);
-        const uint32_t m2 = k > 8 ? ((1u << (8 * (k - 8))) - 1u) : 0u;
-        const uint32_t diff = ((windowDword(win, o) ^ t1.x) & m0) | ((windowDword(win, o + 4) ^ t1.y) & m1) |
-                              ((windowDword(win, o + 8) ^ t1.z) & m2);
-        if (diff != 0) return false;                           /* mismatch inside the chain = trap */
+        /* bytes p+1.. of the input: shift the window by o = (p & 3) + 1 bytes (1..4) */
+        const uint32_t o = (p & 3u) + 1u;
+        const bool whole = o == 4;
+        const uint32_t a0 = whole ? win.y : win.x, a1 = whole ? win.z : win.y, a2 = whole ? win.w : win.z,
+                       a3 = whole ? 0u : win.w;
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, o & 3u);
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, o & 3u);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, o & 3u);
+        if ((((x0 ^ t1.x) & t1.z) | ((x1 ^ t1.y) & t1.w)) != 0) return false;   /* mismatch inside the chain = trap */
         const int end = (int)t0.x;
         if (end <= c.numFinal) match = end;                    /* skipped chain states are never final */
         off = (int)t0.z; ks = (int)t0.w;
         depth += 1 + k;
-        b0 = windowDword(win, o + k) & 0xFFu;                  /* edge byte of the next step (o + k <= 15) */
+        const uint32_t sel = k < 4 ? x0 : k < 8 ? x1 : x2;     /* byte k after the edge byte = next edge byte */
+        b0 = (sel >> (8 * (k & 3u))) & 0xFFu;
         return true;
     }
 
@@ -353,21 +359,22 @@ template <int MODE> struct ChainLane {
      * its chain fits into the four bytes that came with the queue entry (chain length <= 2, the
      * common case) no memory is touched; a longer root chain fetches its window synchronously.
      * Returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, size_t p, uint32_t x)
+    __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
         pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = -1; ks = -1; sawLoad = false;
         const u32x4 r0 = c.sRoot[b0 * 2];
-        const u32x4 r1w = c.sRoot[b0 * 2 + 1];
-        const u32x3 r1 = {r1w.x, r1w.y, r1w.z};
         if ((int)r0.y < 0) return false;                       /* no transition on this byte */
-        if (((r0.y >> 8) & 0xFFu) <= 2) {
-            /* window = the 4 known bytes placed where advance() expects them */
-            const uint32_t sh = (uint32_t)p & 3u;
-            u32x4 win;
-            win.x = x << (8 * sh);
-            win.y = sh ? x >> (8 * (4 - sh)) : 0u;
-            win.z = 0; win.w = 0;
-            return advance(c, r0, r1, win, p);
+        const uint32_t k = (r0.y >> 8) & 0xFFu;
+        const u32x4 r1 = c.sRoot[b0 * 2 + 1];
+        if (k <= 2) {
+            if (p + 1 + k > c.n) return false;
+            if ((((x >> 8) ^ r1.x) & r1.z) != 0) return false;
+            const int end = (int)r0.x;
+            if (end <= c.numFinal) match = end;
+            off = (int)r0.z; ks = (int)r0.w;
+            depth = 1 + k;
+            b0 = (x >> (8 * depth)) & 0xFFu;
+            return true;
         }
         uint32_t back;
         const u32x4 raw = loadWindow16(c.in32, p, c.numDwords, back);
@@ -376,15 +383,15 @@ template <int MODE> struct ChainLane {
     }
     __device__ __forceinline__ bool issue(const Ctx &c)
     {
-        const size_t p = pos + depth;                          /* position of the edge byte b0 */
+        const uint32_t p = pos + depth;                        /* position of the edge byte b0 */
         if (p >= c.n || off < 0) return false;                 /* end of input, or a state without transitions */
         const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
         if (MODE == HASH_BUFFER) {
             s0 = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 32u), 0, 0);
-            s1 = __builtin_amdgcn_raw_buffer_load_b96(c.rsrc, (int)(idx * 32u + 16u), 0, 0);
+            s1 = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 32u + 16u), 0, 0);
         } else {
-            s0 = c.slots[(size_t)idx * 2];
-            s1 = *reinterpret_cast<const u32x3 *>(&c.slots[(size_t)idx * 2 + 1]);
+            s0 = c.slots[idx * 2u];
+            s1 = c.slots[idx * 2u + 1u];
         }
         w = loadWindow16(c.in32, p, c.numDwords, pulledBack);
         return true;
@@ -441,11 +448,11 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     uint32_t *qBytes = sQBytesAll + wave * kQueueCap;   /* ring: first four input bytes of the position   */
-    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: (chunk sequence number << 11) | offset   */
+    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: byte position in the input (32-bit)      */
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
-    const size_t n = a.n;
-    const size_t numDwords = (n + 3) >> 2;          /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
+    const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
+    const uint32_t numDwords = (n + 3u) >> 2;       /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
                   32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
@@ -454,8 +461,8 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     bool alive[kWalkSets];
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) alive[s] = false;
-    const size_t totalWaves = (size_t)gridDim.x * kWavesPerBlock;
-    const size_t firstChunk = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t totalWaves = gridDim.x * kWavesPerBlock;
+    const uint32_t firstChunk = blockIdx.x * kWavesPerBlock + wave;
 
     /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
      *   [qh, qv)  passed both filter levels, waiting for a walker lane
@@ -516,9 +523,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
                 if (!alive[s] && rank < qv - qh) {
-                    const uint32_t e = qPos[(qh + rank) & kMask];
-                    alive[s] = walk[s].start(wctx, (firstChunk + (size_t)(e >> 11) * totalWaves) * kChunkBytes + (e & 2047u),
-                                             qBytes[(qh + rank) & kMask]);
+                    alive[s] = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
                     if (!alive[s]) finish(walk[s]);
                 }
                 const uint32_t taken = (uint32_t)__popcll(idle);
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         for (int s = 0; s < kWalkSets; s++) any |= alive[s];
         return __ballot(any) != 0;
     };
-    auto appendHit = [&](uint32_t seq, uint32_t offset, uint32_t x, bool has) {
+    auto appendHit = [&](uint32_t position, uint32_t x, bool has) {
         if (qu - qh + 64 > kQueueCap) {
             verifyPending();
             while (qu - qh + 64 > kQueueCap) { walkRefill(); walkIssue(); walkConsume(); }   /* full: walk until there is room */
@@ -540,27 +545,26 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         const uint64_t m = __ballot(has);
         if (m) {
             const uint32_t at = (qu + laneRankIn(m)) & kMask;
-            if (has) { qPos[at] = (seq << 11) + offset; qBytes[at] = x; }
+            if (has) { qPos[at] = position; qBytes[at] = x; }
             qu += (uint32_t)__popcll(m);
         }
     };
 
     /* The main loop only sees FULL chunks and issues the same vector-memory instructions on every
      * path (the prefetch past the end is clamped, not skipped).  The ragged tail is handled after. */
-    const size_t numFullChunks = n / kChunkBytes;            /* >= 1: the launcher sends smaller inputs elsewhere */
-    auto loadChunk = [&](size_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
-        const size_t cc = c < numFullChunks ? c : numFullChunks - 1;
-        const size_t q = cc * (kChunkBytes / 16);
+    const uint32_t numFullChunks = n / kChunkBytes;          /* >= 1: the launcher sends smaller inputs elsewhere */
+    auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
+        const uint32_t cc = c < numFullChunks ? c : numFullChunks - 1;
+        const uint32_t q = cc * (kChunkBytes / 16);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
-        const size_t hd = (cc + 1) * (kChunkBytes / 4);
+        const uint32_t hd = (cc + 1) * (kChunkBytes / 4);
         const bool haveHalo = hd < numDwords;
         const uint32_t h = in32[haveHalo ? hd : numDwords - 1];
         halo = haveHalo ? h : 0u;
     };
 
-    size_t chunk = firstChunk;
-    uint32_t seq = 0;                               /* chunk = firstChunk + seq * totalWaves */
+    uint32_t chunk = firstChunk;
     u32x4 d[kTilesPerIter];
     uint32_t halo = 0;
     if (chunk < numFullChunks) loadChunk(chunk, d, halo);
@@ -570,14 +574,14 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         walkIssue();
 
         /* ---- 2. prefetch the next chunk of this wave */
-        const size_t nextChunk = chunk + totalWaves;
+        const uint32_t nextChunk = chunk + totalWaves;
         u32x4 nd[kTilesPerIter];
         uint32_t nhalo;
         loadChunk(nextChunk, nd, nhalo);
 
         /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
         {
-            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + chunk * kChunkBytes);
+            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
             const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 const uint32_t j = b >> 2;
                 const uint32_t lo = j == 0 ? dw[0] : j == 1 ? dw[1] : j == 2 ? dw[2] : dw[3];
                 const uint32_t hi = j == 0 ? dw[1] : j == 1 ? dw[2] : j == 2 ? dw[3] : nxtLane;
-                appendHit(seq, (uint32_t)(t * kTileBytes + (lane << 4)) + b, __builtin_amdgcn_alignbyte(hi, lo, b & 3), has);
+                appendHit(chunk * kChunkBytes + (uint32_t)(t * kTileBytes + (lane << 4)) + b, __builtin_amdgcn_alignbyte(hi, lo, b & 3), has);
                 if (has) hits &= hits - 1;
                 pending = __ballot(hits != 0);
             }
@@ -628,14 +632,13 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         for (int t = 0; t < kTilesPerIter; t++) d[t] = nd[t];
         halo = nhalo;
         chunk = nextChunk;
-        seq++;
     }
 
     /* ---- ragged tail: the < kChunkBytes behind the last full chunk belong to the wave whose stride
      * lands on it.  Every position is zeroed, then queued without filtering (the walker is exact). */
     if (chunk == numFullChunks && numFullChunks * kChunkBytes < n) {
-        const size_t base = numFullChunks * kChunkBytes;
-        const uint32_t rem = (uint32_t)(n - base);
+        const uint32_t base = numFullChunks * kChunkBytes;
+        const uint32_t rem = n - base;
         for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (uint32_t o0 = 0; o0 < rem; o0 += 64) {
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             uint32_t x = 0;
             for (int j = 0; j < 4; j++)
                 if (has && base + o + j < n) x |= (uint32_t)a.in[base + o + j] << (8 * j);
-            appendHit(seq, o, x, has);
+            appendHit(base + o, x, has);
         }
         qv = qu;                                     /* tail entries skip filter level 2 */
     }
@@ -776,9 +779,29 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     }
     const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) &&
                           ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kChunkBytes;
-    hipError_t e;
-    if (hashed) e = tex ? launchMode<HASH_BUFFER>(c, a, vectorOk) : launchMode<HASH_GLOBAL>(c, a, vectorOk);
-    else        e = tex ? launchMode<DENSE_BUFFER>(c, a, vectorOk) : launchMode<DENSE_GLOBAL>(c, a, vectorOk);
+    auto launch = [&](const ScanArgs &args) {
+        if (hashed) return tex ? launchMode<HASH_BUFFER>(c, args, vectorOk) : launchMode<HASH_GLOBAL>(c, args, vectorOk);
+        return tex ? launchMode<DENSE_BUFFER>(c, args, vectorOk) : launchMode<DENSE_GLOBAL>(c, args, vectorOk);
+    };
+    /* The vector kernel keeps byte positions in 32 bits.  Larger inputs are scanned as consecutive
+     * windows of kMaxLaunchBytes owned positions; each window also scans maxPatternLen bytes of its
+     * successor, whose (possibly cut short) results are overwritten by the next launch -- launches on
+     * one stream run in order, so the final value of every element is the complete one. */
+    constexpr size_t kMaxLaunchBytes = (size_t(1) << 32) - (size_t(1) << 24);
+    hipError_t e = hipSuccess;
+    if (input_size <= kMaxLaunchBytes || !vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) {
+        e = launch(a);
+    } else {
+        const size_t overlap = (size_t)c->fa.maxPatternLen;
+        for (size_t off = 0; off < input_size && e == hipSuccess; off += kMaxLaunchBytes) {
+            ScanArgs part = a;
+            part.in = a.in + off;
+            part.out = a.out + off;
+            const size_t owned = input_size - off < kMaxLaunchBytes ? input_size - off : kMaxLaunchBytes;
+            part.n = owned + overlap < input_size - off ? owned + overlap : input_size - off;
+            e = launch(part);
+        }
+    }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
 }
 

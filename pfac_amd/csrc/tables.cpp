@@ -136,8 +136,9 @@ static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &row
     s.endOff = rowPtr[cur].x;
     s.endKS = rowPtr[cur].y;
     std::memset(s.chain, 0, sizeof(s.chain));
+    std::memset(s.mask, 0, sizeof(s.mask));
     std::memcpy(s.chain, bytes, (size_t)k);
-    s.pad = 0;
+    std::memset(s.mask, 0xFF, (size_t)k);
     return s;
 }
 

@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) is the real path; gloo lets several ranks share one GPU for a dry run")
     return ap.parse_args()
 
 
@@ -161,9 +163,14 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU: the match path has no CPU fallback"
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()      # dry run: ranks may share a device
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -239,7 +246,7 @@ def main():
 
     # ---- gather per-rank facts (RCCL: 4 x int64 per rank) ----------------------------------------
     allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9)],
-                                     device=f"cuda:{local_rank}")
+                                     device=f"cuda:{local_rank}" if args.dist_backend == "nccl" else None)
     elapsed_max = float(allf[:, 3].max()) / 1e9
     total_matches = int(allf[:, 0].sum())
     all_ok = bool(allf[:, 2].all())

@@ -409,8 +409,14 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 
 /* --------------------------------------------------------- filter kernel */
 
-constexpr int kTilesPerIter = 2;              /* 1 KiB tiles a wave handles per loop iteration        */
-constexpr int kWalkSets = 3;                  /* independent walks per lane                           */
+#ifndef PFAC_TILES_PER_ITER
+#define PFAC_TILES_PER_ITER 2
+#endif
+#ifndef PFAC_WALK_SETS
+#define PFAC_WALK_SETS 3
+#endif
+constexpr int kTilesPerIter = PFAC_TILES_PER_ITER;   /* 1 KiB tiles a wave handles per loop iteration (tuned on MI355X) */
+constexpr int kWalkSets = PFAC_WALK_SETS;            /* independent walks per lane                                      */
 constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
 
 template <int MODE, bool HAS_SHORT>

@@ -307,3 +307,44 @@ def test_cpp_example_program_prints_the_readme_answer(tmp_path):
     assert lines == ["At position    0, match pattern 1", "At position    1, match pattern 3",
                      "At position    2, match pattern 4", "At position    4, match pattern 4",
                      "At position    6, match pattern 2"]
+
+
+def test_input_larger_than_4_gib(workdir):
+    """The vector kernel keeps positions in 32 bits; inputs of 4 GiB and more are scanned as
+    consecutive windows (scan_gfx950.hip: kMaxLaunchBytes) whose overlap is rewritten by the next
+    window.  Patterns planted across the window boundary, across 2^32 and at the very end must be
+    reported exactly like the one-thread-per-byte kernel (size_t positions) reports them."""
+    from pfac_amd import workloads as wl
+    cfg = wl.make_config("c2")
+    pf = wl.write_pattern_file(f"{workdir}/big.pat", cfg.patterns)
+    n = (1 << 32) + (3 << 20) + 5
+    window = (1 << 32) - (1 << 24)
+    d_in = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    chunk = cfg.input_slice(1 << 28, 0)
+    t = torch.from_numpy(chunk).to("cuda:0")
+    for off in range(0, n, 1 << 28):
+        m = min(1 << 28, n - off)
+        d_in[off:off + m] = t[:m]
+    del t
+    planted = []
+    lens = [len(p) for p in cfg.patterns]
+    longest = int(np.argmax(lens))
+    for at, pid in [(window - 16, longest), (window - 100, 3), (window + 64, 4), ((1 << 32) - 7, longest),
+                    ((1 << 32) + 200, 9), (n - lens[11], 11), (12345, 12), (window - 200 - lens[5], 5)]:
+        p = torch.tensor(list(cfg.patterns[pid]), dtype=torch.uint8, device="cuda:0")
+        d_in[at:at + p.numel()] = p
+        planted.append((at, pid + 1))
+    h = make_handle(pf, api.PFAC_TIME_DRIVEN, api.PFAC_AUTOMATIC)
+    try:
+        d_a = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        h.matchFromDevice(d_in.data_ptr(), n, d_a.data_ptr())
+        torch.cuda.synchronize()
+        for at, pid in planted:
+            assert int(d_a[at]) == pid, f"planted pattern {pid} at {at}: got {int(d_a[at])}"
+        d_b = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        h.setKernelVariant(api.PFACX_KERNEL_NAIVE)
+        h.matchFromDevice(d_in.data_ptr(), n, d_b.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(d_a, d_b)
+    finally:
+        h.destroy()

@@ -53,6 +53,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_gram3);
     devFree(c->d_shortBits);
     devFree(c->d_gram4);
+    devFree(c->d_reduceCount);
     devFree(c->d_final3);
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();
@@ -133,6 +134,8 @@ PFAC_status_t bindCommon(PFAC_context *c)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram4, c->filter.gram4.data(), c->filter.gram4.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
+    const unsigned int zero = 0;
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_reduceCount, &zero, 1);
     return st;
 }
 

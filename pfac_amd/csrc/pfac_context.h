@@ -117,6 +117,7 @@ struct PFAC_context {
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_gram4 = nullptr;
+    unsigned int *d_reduceCount = nullptr;    /* device counter of the compacted-output path */
     uint32_t *d_final3 = nullptr;
 
     /* ref numOfTableEntry / sizeOfTableEntry / sizeOfTableInBytes, PFAC_P.h:131-133 */

@@ -56,7 +56,12 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <cstdint>
+#include <vector>
 
 #include "pfac_context.h"
 
@@ -93,6 +98,10 @@ struct ScanArgs {
     int log2Bits, log2Bits4, log2BitsF3;
     int numFinal;
     int initialState;
+    /* compacted output (PFAC_matchFromDeviceReduce): unordered append, sorted by position afterwards */
+    int *reducePos;
+    unsigned int *reduceCount;
+    unsigned int reduceBase;                           /* position of a.in[0] inside the caller's stream */
 };
 
 /* ---------------------------------------------------------------- lookups */
@@ -419,7 +428,7 @@ constexpr int kTilesPerIter = PFAC_TILES_PER_ITER;   /* 1 KiB tiles a wave handl
 constexpr int kWalkSets = PFAC_WALK_SETS;            /* independent walks per lane                                      */
 constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
 
-template <int MODE, bool HAS_SHORT>
+template <int MODE, bool HAS_SHORT, bool REDUCE>
 __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 {
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
@@ -506,8 +515,14 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
      * consuming a global load (patterns resolved from LDS alone) drain this wave's stores first. */
     auto finish = [&](const WLane &w) {
         if (w.match != 0) {
-            if (!w.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            a.out[w.pos] = w.match;
+            if (REDUCE) {                                  /* compacted output: no zero stores to order against */
+                const unsigned int at = atomicAdd(a.reduceCount, 1u);
+                a.out[at] = w.match;
+                a.reducePos[at] = (int)(a.reduceBase + w.pos);
+            } else {
+                if (!w.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                a.out[w.pos] = w.match;
+            }
         }
     };
     auto walkIssue = [&]() {
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         loadChunk(nextChunk, nd, nhalo);
 
         /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
-        {
+        if (!REDUCE) {
             i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
             const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -645,8 +660,10 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     if (chunk == numFullChunks && numFullChunks * kChunkBytes < n) {
         const uint32_t base = numFullChunks * kChunkBytes;
         const uint32_t rem = n - base;
-        for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!REDUCE) {
+            for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         for (uint32_t o0 = 0; o0 < rem; o0 += 64) {
             const uint32_t o = o0 + lane;
             const bool has = o < rem;
@@ -704,10 +721,10 @@ size_t filterLdsBytes(const PFAC_context *c)
     return bytes;
 }
 
-template <int MODE, bool HAS_SHORT>
+template <int MODE, bool HAS_SHORT, bool REDUCE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 {
-    auto kernel = pfac_scan_filter<MODE, HAS_SHORT>;
+    auto kernel = pfac_scan_filter<MODE, HAS_SHORT, REDUCE>;
     const size_t lds = filterLdsBytes(c);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -738,20 +755,25 @@ template <int MODE>
 hipError_t launchMode(const PFAC_context *c, const ScanArgs &a, bool vectorOk)
 {
     if (c->kernelVariant == PFACX_KERNEL_NAIVE || !vectorOk) return launchNaive<MODE>(c, a);
-    return c->filter.hasShort ? launchFilter<MODE, true>(c, a) : launchFilter<MODE, false>(c, a);
+    return c->filter.hasShort ? launchFilter<MODE, true, false>(c, a) : launchFilter<MODE, false, false>(c, a);
+}
+
+template <int MODE>
+hipError_t launchReduceMode(const PFAC_context *c, const ScanArgs &a)
+{
+    return c->filter.hasShort ? launchFilter<MODE, true, true>(c, a) : launchFilter<MODE, false, true>(c, a);
 }
 
 uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes; }
 
-PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size, int *d_matched_result, bool hashed)
+/* kernel arguments shared by the full-result and the compacted-result paths */
+PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_string, size_t input_size,
+                       int *d_matched_result, ScanArgs &a)
 {
-    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    const PFAC_context *c = handle;
     if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
     if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_chainSlots || !c->d_rootSlots) : !c->d_dense)
         return PFAC_STATUS_INTERNAL_ERROR;
-
-    ScanArgs a{};
+    a = ScanArgs{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
     a.out = d_matched_result;
     a.n = input_size;
@@ -774,15 +796,23 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.initialState = c->fa.initialState;
-
-    /* the buffer-resource ("texture") path addresses the table with 32-bit byte
-     * offsets; the reference fails the texture bind for an oversized table the
-     * same way (PFAC_kernel.cu:139-142) */
-    const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
-    if (tex) {
+    /* the buffer-resource ("texture") path addresses the table with 32-bit byte offsets; the
+     * reference fails the texture bind for an oversized table the same way (PFAC_kernel.cu:139-142) */
+    if (c->textureMode == PFAC_TEXTURE_ON) {
         const size_t biggest = hashed ? c->numChainSlots * sizeof(pfac::ChainSlot) : c->h_dense.size() * sizeof(int);
         if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
+    return PFAC_STATUS_SUCCESS;
+}
+
+PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size, int *d_matched_result, bool hashed)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    const PFAC_context *c = handle;
+    ScanArgs a;
+    const PFAC_status_t st = fillArgs(c, hashed, d_input_string, input_size, d_matched_result, a);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
     const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) &&
                           ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kChunkBytes;
     auto launch = [&](const ScanArgs &args) {
@@ -811,6 +841,93 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
 }
 
+/*
+ * Compacted output (ref PFAC_reduce_kernel / PFAC_reduce_inplace_kernel, PFAC_reduce_kernel.cu:172-295,
+ * PFAC_reduce_inplace_kernel.cu:155-323): the first *h_num_matched entries of d_match_result / d_pos
+ * receive the non-zero results and their positions in ascending position order.
+ *
+ * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
+ * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
+ * device counter, and the (usually short) list is then sorted by position with rocPRIM's radix sort.
+ * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
+ * (PFAC_reduce_kernel.cu:417-457) because it has no prefilter: every thread owns a result.
+ * Synchronous, like the reference (the count goes back to the host).
+ */
+PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_size, int *d_match_result, int *d_pos,
+                         int *h_num_matched, int *h_match_result, int *h_pos, bool hashed)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!d_input_string || !d_match_result || !d_pos || !h_num_matched || input_size <= 0) return PFAC_STATUS_INVALID_PARAMETER;
+    const PFAC_context *c = handle;
+    if (!c->d_reduceCount) return PFAC_STATUS_INTERNAL_ERROR;
+    const size_t n = (size_t)input_size;
+    ScanArgs a;
+    PFAC_status_t st = fillArgs(c, hashed, reinterpret_cast<const char *>(d_input_string), n, d_match_result, a);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    unsigned int count = 0;
+
+    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) && n >= (size_t)kChunkBytes &&
+                          c->kernelVariant != PFACX_KERNEL_NAIVE;
+    if (vectorOk) {
+        a.reducePos = d_pos;
+        a.reduceCount = c->d_reduceCount;
+        a.reduceBase = 0;
+        if (hipMemsetAsync(c->d_reduceCount, 0, sizeof(unsigned int), 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
+        hipError_t e;
+        if (hashed) e = tex ? launchReduceMode<HASH_BUFFER>(c, a) : launchReduceMode<HASH_GLOBAL>(c, a);
+        else        e = tex ? launchReduceMode<DENSE_BUFFER>(c, a) : launchReduceMode<DENSE_GLOBAL>(c, a);
+        if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        if (count > 1) {                                   /* order by position */
+            unsigned int *keysOut = nullptr;
+            int *valuesOut = nullptr;
+            void *temp = nullptr;
+            size_t tempBytes = 0;
+            unsigned int *keysIn = reinterpret_cast<unsigned int *>(d_pos);
+            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0) != hipSuccess)
+                return PFAC_STATUS_INTERNAL_ERROR;
+            const bool ok = hipMalloc(reinterpret_cast<void **>(&keysOut), count * sizeof(unsigned int)) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void **>(&valuesOut), count * sizeof(int)) == hipSuccess &&
+                            hipMalloc(&temp, tempBytes ? tempBytes : 4) == hipSuccess;
+            hipError_t se = hipErrorOutOfMemory;
+            if (ok) {
+                se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0);
+                if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
+                if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
+                if (se == hipSuccess) se = hipStreamSynchronize(0);
+            }
+            if (keysOut) (void)hipFree(keysOut);
+            if (valuesOut) (void)hipFree(valuesOut);
+            if (temp) (void)hipFree(temp);
+            if (!ok) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+            if (se != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        }
+    } else {
+        /* odd pointers / tiny inputs: full-result scan into a scratch vector, compacted on the host */
+        int *d_full = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d_full), n * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+        st = scan(handle, reinterpret_cast<char *>(d_input_string), n, d_full, hashed);
+        std::vector<int> full(n), ids, pos;
+        if (st == PFAC_STATUS_SUCCESS && hipMemcpy(full.data(), d_full, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            st = PFAC_STATUS_INTERNAL_ERROR;
+        (void)hipFree(d_full);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+        for (size_t i = 0; i < n; i++)
+            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)i); }
+        count = (unsigned int)ids.size();
+        if (count && (hipMemcpy(d_match_result, ids.data(), count * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                      hipMemcpy(d_pos, pos.data(), count * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+            return PFAC_STATUS_INTERNAL_ERROR;
+    }
+    *h_num_matched = (int)count;
+    if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return PFAC_STATUS_INTERNAL_ERROR;
+    if (count && h_pos && hipMemcpy(h_pos, d_pos, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return PFAC_STATUS_INTERNAL_ERROR;
+    return PFAC_STATUS_SUCCESS;
+}
+
 } // namespace
 
 extern "C" {
@@ -827,15 +944,16 @@ PFAC_status_t PFAC_kernel_spaceDriven_warpper(PFAC_handle_t handle, char *d_inpu
     return scan(handle, d_input_string, input_size, d_matched_result, true);
 }
 
-/* Compacted output is SURVEY.md section 8(f) rank 1 ("next"); not built yet. */
-PFAC_status_t PFAC_reduce_kernel(PFAC_handle_t, int *, int, int *, int *, int *, int *, int *)
+PFAC_status_t PFAC_reduce_kernel(PFAC_handle_t handle, int *d_input_string, int input_size, int *d_match_result,
+                                 int *d_pos, int *h_num_matched, int *h_match_result, int *h_pos)
 {
-    return PFAC_STATUS_INTERNAL_ERROR;
+    return reduceScan(handle, d_input_string, input_size, d_match_result, d_pos, h_num_matched, h_match_result, h_pos, false);
 }
 
-PFAC_status_t PFAC_reduce_inplace_kernel(PFAC_handle_t, int *, int, int *, int *, int *, int *, int *)
+PFAC_status_t PFAC_reduce_inplace_kernel(PFAC_handle_t handle, int *d_input_string, int input_size, int *d_match_result,
+                                         int *d_pos, int *h_num_matched, int *h_match_result, int *h_pos)
 {
-    return PFAC_STATUS_INTERNAL_ERROR;
+    return reduceScan(handle, d_input_string, input_size, d_match_result, d_pos, h_num_matched, h_match_result, h_pos, true);
 }
 
 } /* extern "C" */

@@ -348,3 +348,68 @@ def test_input_larger_than_4_gib(workdir):
         assert torch.equal(d_a, d_b)
     finally:
         h.destroy()
+
+
+@pytest.mark.parametrize("perf,tex,mode_name", MODES)
+@pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
+def test_match_from_device_reduce_equals_oracle(workloads, oracle_results, name, perf, tex, mode_name):
+    """PFAC_matchFromDeviceReduce: compacted (id, position) pairs in ascending position order
+    (ref PFAC.cpp:964-1008; known answer user guide r1.2 p.29 is the c1 case)."""
+    from oracle import binding as ob
+    w = workloads[name]
+    ids, pos = ob.reduce(oracle_results[name])
+    n = int(w.data.size)
+    h = make_handle(w.pattern_file, perf, tex)
+    try:
+        d_in = torch.from_numpy(w.data.copy()).to("cuda:0")
+        d_res = torch.full((n + 8,), -5, dtype=torch.int32, device="cuda:0")
+        d_pos = torch.full((n + 8,), -5, dtype=torch.int32, device="cuda:0")
+        st, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+        torch.cuda.synchronize()
+        assert count == ids.size, f"{name}/{mode_name}: count {count} != {ids.size}"
+        assert np.array_equal(d_pos[:count].cpu().numpy(), pos), f"{name}/{mode_name} positions"
+        assert np.array_equal(d_res[:count].cpu().numpy(), ids), f"{name}/{mode_name} ids"
+        assert int(d_res[n:].min()) == -5 and int(d_pos[n:].min()) == -5, "wrote past the caller's arrays"
+    finally:
+        h.destroy()
+
+
+def test_match_from_host_reduce_on_gpu_platform(workloads, oracle_results, golden_dir):
+    """PFAC_matchFromHostReduce on PFAC_PLATFORM_GPU (ref PFAC.cpp:1010-1128, simple_example_reduce.cpp)."""
+    import json, os
+    from oracle import binding as ob
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))["example1"]
+    for name in ("c1", "c3"):
+        w = workloads[name]
+        ids, pos = ob.reduce(oracle_results[name])
+        h = make_handle(w.pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC)
+        try:
+            res = np.full(w.data.size, -5, dtype=np.int32)
+            hp = np.full(w.data.size, -5, dtype=np.int32)
+            st, count = h.matchFromHostReduce(w.data.ctypes.data, w.data.size, res.ctypes.data, hp.ctypes.data)
+            assert count == ids.size and np.array_equal(res[:count], ids) and np.array_equal(hp[:count], pos)
+            if name == "c1":
+                assert hp[:count].tolist() == ka["reduce_pos"] and res[:count].tolist() == ka["reduce_id"]
+        finally:
+            h.destroy()
+
+
+def test_reduce_misaligned_and_tiny_inputs(workloads, oracle_results):
+    from oracle import binding as ob
+    w = workloads["dense_hits"]
+    for n, off in [(5, 0), (1000, 0), (2049, 1), (30000, 3)]:
+        data = np.tile(w.data, n // w.data.size + 2)[7:7 + n].copy()
+        o = ob.Oracle(w.pattern_file, hashed=False)
+        ids, pos = ob.reduce(o.match(data))
+        o.close()
+        h = make_handle(w.pattern_file, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_OFF)
+        try:
+            d_in = torch.zeros(n + 64, dtype=torch.uint8, device="cuda:0")
+            d_in[off:off + n] = torch.from_numpy(data).to("cuda:0")
+            d_res = torch.zeros(n + 8, dtype=torch.int32, device="cuda:0")
+            d_pos = torch.zeros(n + 8, dtype=torch.int32, device="cuda:0")
+            st, count = h.matchFromDeviceReduce(d_in.data_ptr() + off, n, d_res.data_ptr(), d_pos.data_ptr())
+            assert count == ids.size
+            assert np.array_equal(d_pos[:count].cpu().numpy(), pos) and np.array_equal(d_res[:count].cpu().numpy(), ids)
+        finally:
+            h.destroy()

@@ -280,6 +280,22 @@ def main():
                 "input_only_frac": round(n_read / kernel_avg_s / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
+        if world == 1:
+            # not the headline metric: the compacted-output API on the same buffers.
+            # Synchronous (the match count returns to the host), so wall clock per call.
+            d_pos = torch.empty_like(d_out)
+            handle.matchFromDeviceReduce(d_in.data_ptr(), n_read, d_out.data_ptr(), d_pos.data_ptr())
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            for _ in range(5):
+                _, rcount = handle.matchFromDeviceReduce(d_in.data_ptr(), n_read, d_out.data_ptr(), d_pos.data_ptr())
+            torch.cuda.synchronize()
+            tr = (time.perf_counter() - t0r) / 5
+            out["reduce_api"] = {"value": round(n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
+                                 "matches": int(rcount), "same_matches_as_full_result": bool(rcount == count),
+                                 "algorithmic_bytes_per_call": int(n_read + 8 * rcount),
+                                 "note": "PFAC_matchFromDeviceReduce incl. count readback and position sort; ~1 B/input byte of HBM traffic"}
+            del d_pos
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg
             out["cpu_baseline"] = cpu_baseline(ob, pattern_file, host_in[:n], perf_mode, args.cpu_seconds)

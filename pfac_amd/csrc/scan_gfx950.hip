@@ -427,6 +427,7 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 constexpr int kTilesPerIter = PFAC_TILES_PER_ITER;   /* 1 KiB tiles a wave handles per loop iteration (tuned on MI355X) */
 constexpr int kWalkSets = PFAC_WALK_SETS;            /* independent walks per lane                                      */
 constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
+constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
 
 template <int MODE, bool HAS_SHORT, bool REDUCE>
 __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 8 : pfac::kCharSet);
     uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
+    uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
@@ -513,27 +515,67 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
      * counter), and a position is only walked after the loads issued behind its chunk's zero stores
      * have been consumed, so the patch always lands on top of the zero.  Walks that ended without
      * consuming a global load (patterns resolved from LDS alone) drain this wave's stores first. */
-    auto finish = [&](const WLane &w) {
+    /* REDUCE: results are staged per wave in LDS and flushed with one atomic per kReduceCap pairs
+     * (a single device counter saturates at ~90 increments/us; pattern-dense input has 10^5..10^6 matches) */
+    uint32_t *rPos = sReduceAll + wave * (2 * kReduceCap);
+    uint32_t *rId = rPos + kReduceCap;
+    uint32_t rn = 0;                                /* staged pairs (wave-uniform) */
+    int pendMatch[kWalkSets];
+    uint32_t pendPos[kWalkSets];
+#pragma unroll
+    for (int s = 0; s < kWalkSets; s++) { pendMatch[s] = 0; pendPos[s] = 0; }
+
+    auto finish = [&](const WLane &w, int s) {
         if (w.match != 0) {
-            if (REDUCE) {                                  /* compacted output: no zero stores to order against */
-                const unsigned int at = atomicAdd(a.reduceCount, 1u);
-                a.out[at] = w.match;
-                a.reducePos[at] = (int)(a.reduceBase + w.pos);
+            if (REDUCE) {                                  /* parked; stagePending() picks it up in uniform control flow */
+                pendMatch[s] = w.match;
+                pendPos[s] = w.pos;
             } else {
                 if (!w.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 a.out[w.pos] = w.match;
             }
         }
     };
+    auto flushStaged = [&]() {                             /* all 64 lanes, uniform control flow */
+        if (rn == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(a.reduceCount, rn);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < rn; i += 64) {
+            a.out[base + i] = (int)rId[i];
+            a.reducePos[base + i] = (int)(a.reduceBase + rPos[i]);
+        }
+        rn = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    auto stagePending = [&]() {
+        if (!REDUCE) return;
+#pragma unroll
+        for (int s = 0; s < kWalkSets; s++) {
+            const bool has = pendMatch[s] != 0;
+            const uint64_t m = __ballot(has);
+            if (m) {
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (rn + cnt > kReduceCap) flushStaged();
+                const uint32_t at = rn + laneRankIn(m);
+                if (has) { rPos[at] = pendPos[s]; rId[at] = (uint32_t)pendMatch[s]; pendMatch[s] = 0; }
+                rn += cnt;
+            }
+        }
+    };
     auto walkIssue = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++)
-            if (alive[s] && !walk[s].issue(wctx)) { alive[s] = false; finish(walk[s]); }
+            if (alive[s] && !walk[s].issue(wctx)) { alive[s] = false; finish(walk[s], s); }
+        stagePending();
     };
     auto walkConsume = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++)
-            if (alive[s] && !walk[s].consume(wctx)) { alive[s] = false; finish(walk[s]); }
+            if (alive[s] && !walk[s].consume(wctx)) { alive[s] = false; finish(walk[s], s); }
+        stagePending();
     };
     /* hand verified queue entries to idle walker lanes; the first transition happens here (LDS) */
     auto walkRefill = [&]() {
@@ -545,12 +587,13 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 const uint32_t rank = laneRankIn(idle);
                 if (!alive[s] && rank < qv - qh) {
                     alive[s] = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
-                    if (!alive[s]) finish(walk[s]);
+                    if (!alive[s]) finish(walk[s], s);
                 }
                 const uint32_t taken = (uint32_t)__popcll(idle);
                 qh += taken < qv - qh ? taken : qv - qh;
             }
         }
+        stagePending();
     };
     auto anyAlive = [&]() {
         bool any = false;
@@ -679,6 +722,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     if (qu != qv) verifyPending();
     walkRefill();
     while (anyAlive() || qh != qv) { walkIssue(); walkConsume(); walkRefill(); }
+    if (REDUCE) flushStaged();
 }
 
 /* ---------------------------------------------------------- naive kernel */
@@ -711,13 +755,14 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 
 /* ------------------------------------------------------------- launching */
 
-size_t filterLdsBytes(const PFAC_context *c)
+size_t filterLdsBytes(const PFAC_context *c, bool reduce)
 {
     size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
     bytes += (size_t)kWavesPerBlock * kQueueCap * 2 * sizeof(uint32_t);
+    if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }
 
@@ -725,7 +770,7 @@ template <int MODE, bool HAS_SHORT, bool REDUCE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 {
     auto kernel = pfac_scan_filter<MODE, HAS_SHORT, REDUCE>;
-    const size_t lds = filterLdsBytes(c);
+    const size_t lds = filterLdsBytes(c, REDUCE);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -185,6 +185,15 @@ __device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
 
 __device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) { return (bitmap[h >> 5] >> (h & 31)) & 1u; }
 
+/* Bit (product >> shift) of a little-endian bitmap, read as a byte: one shift for the LDS address, one
+ * bit-field extract for the bit number, one for the bit -- the level-1 filter runs this 1024 times
+ * per KiB, and VALU issue slots are what bounds the kernel on pattern-dense input. */
+__device__ __forceinline__ uint32_t testHashedBit(const uint32_t *bitmap, uint32_t product, uint32_t shift)
+{
+    const uint32_t byte = reinterpret_cast<const unsigned char *>(bitmap)[product >> (shift + 3u)];
+    return __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(product, shift, 3u), 1u);
+}
+
 /* LDS view of one block */
 struct Lds {
     const uint32_t *gram3, *gram4, *final3, *shortBits;
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 for (int i = 0; i < 4; i++) {
                     const uint32_t x = __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
                     /* __umul24 returns int: the shift must be logical */
-                    uint32_t bit = testBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul) >> lds.shift3);
+                    uint32_t bit = testHashedBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul), lds.shift3);
                     if (HAS_SHORT) bit |= testBit(sShort, x & 0xFFFFu);
                     hits |= bit << (j * 4 + i);
                 }

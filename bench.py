@@ -62,18 +62,19 @@ def sparse_result(d_out, n):
     return pos.cpu().numpy().astype(np.int64), ids.cpu().numpy().astype(np.int64)
 
 
-def verify(handle, api, ob, cfg_pattern_file, host_in, d_in, d_out, n, n_read, perf_mode):
+def verify(handle, api, ob, cfg_pattern_file, host_in, d_in, d_out, n, n_read, perf_mode, variant):
     """Bit-exactness outside the timed region:
-       (1) full size: the filter kernel's result == the independent naive kernel's result;
+       (1) full size: the timed kernel's result == the other, independent kernel's result;
        (2) sampled 1 MiB windows of the stream re-scanned by the oracle == the same windows of (1)."""
     import torch
     torch.cuda.synchronize()
     pos, ids = sparse_result(d_out, n)
     # (1) second, independent kernel on the same device buffers
     d_chk = torch.full_like(d_out, -1)
-    handle.setKernelVariant(api.PFACX_KERNEL_NAIVE)
+    other = api.PFACX_KERNEL_NAIVE if variant == api.PFACX_KERNEL_FILTER else api.PFACX_KERNEL_FILTER
+    handle.setKernelVariant(other)
     handle.matchFromDevice(d_in.data_ptr(), n_read, d_chk.data_ptr())
-    handle.setKernelVariant(api.PFACX_KERNEL_FILTER)
+    handle.setKernelVariant(variant)
     torch.cuda.synchronize()
     same = bool(torch.equal(d_out[:n_read], d_chk[:n_read]))
     del d_chk
@@ -216,7 +217,8 @@ def main():
     pos = ids = None
     if not args.no_verify:
         from oracle import binding as ob   # checker only
-        ok, pos, ids = verify(handle, api, ob, pattern_file, host_in, d_in, d_out, n, n_read, perf_mode)
+        ok, pos, ids = verify(handle, api, ob, pattern_file, host_in, d_in, d_out, n, n_read, perf_mode,
+                              api.PFACX_KERNEL_FILTER if args.variant == "filter" else api.PFACX_KERNEL_NAIVE)
     else:
         pos, ids = sparse_result(d_out, n)
     count = int(pos.size)

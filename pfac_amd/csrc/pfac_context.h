@@ -29,16 +29,21 @@ constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX,
 constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
-constexpr int kChainMax = 8;                  /* bytes of single-successor chain folded into one slot */
-struct ChainSlot {                            /* 32-byte device slot of the chained hashed table        */
-    int end;                                  /* state after the edge byte and the whole chain          */
-    int meta;                                 /* edge byte | chain length << 8; -1 = empty slot         */
-    int endOff, endKS;                        /* hashRowPtr[end] = {offset, (k<<16)|(S-1)}              */
-    unsigned char chain[8];                   /* chain bytes, zero padded                               */
-    unsigned char mask[8];                    /* 0xFF for each chain byte in use (saves the kernel from
-                                                 building the compare mask out of the length)          */
+constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
+/* 16-byte device slot of the chained hashed table: one gathered 16-byte load per transition.
+ * meta = edge byte | chain length << 8 | flags | k << 15 | (S-1) << 24, where {k, S} are the hash
+ * parameters of the END state's bucket (hashRowPtr[end].y = (k << 16) | (S-1), k <= 256, S <= 256). */
+struct ChainSlot {
+    uint32_t meta;
+    int endRow;                               /* hashRowPtr[end].x (first slot of the end state's bucket);
+                                                 if the end state is a final LEAF: its pattern ID        */
+    unsigned char chain[8];                   /* chain bytes, zero padded; if the end state is final and
+                                                 has successors: <= 3 chain bytes, pattern ID in [4..7]  */
 };
-static_assert(sizeof(ChainSlot) == 32, "ChainSlot is read as two 16-byte loads");
+constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state                         */
+constexpr uint32_t kSlotLeaf = 1u << 13;      /* the end state has no outgoing transition               */
+constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */
+static_assert(sizeof(ChainSlot) == 16, "ChainSlot is read as one 16-byte load");
 
 /* One compiled pattern set: patterns + trie.  Independent of perfMode. */
 struct Automaton {

@@ -70,7 +70,16 @@ namespace {
 using pfac::Int2;
 
 constexpr int kTrap = pfac::kTrapState;
-constexpr int kBlockThreads = 1024;
+#ifndef PFAC_BLOCK_THREADS
+#define PFAC_BLOCK_THREADS 1024
+#endif
+#ifndef PFAC_MIN_BLOCKS
+#define PFAC_MIN_BLOCKS 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
+#endif
+#ifndef PFAC_QUEUE_CAP
+#define PFAC_QUEUE_CAP 512
+#endif
+constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kTileBytes = 1024;              /* input bytes per wave per iteration   */
 
@@ -87,7 +96,7 @@ struct ScanArgs {
     const int *dense;
     const Int2 *hashRow;
     const Int2 *hashVal;
-    const u32x4 *chainSlots;                           /* pfac::ChainSlot[], two 16-byte halves per slot */
+    const u32x4 *chainSlots;                           /* pfac::ChainSlot[], 16 bytes each               */
     const u32x4 *rootSlots;                            /* pfac::ChainSlot[256] of the initial state      */
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
     const int *initialRow;
@@ -174,7 +183,7 @@ template <> struct Lookup<HASH_BUFFER> {
 
 /* ------------------------------------------------------------------ walkers */
 
-constexpr uint32_t kQueueCap = 512;           /* ring entries per wave (power of two)                 */
+constexpr uint32_t kQueueCap = PFAC_QUEUE_CAP;           /* ring entries per wave (power of two)                 */
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -185,13 +194,16 @@ __device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
 
 __device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) { return (bitmap[h >> 5] >> (h & 31)) & 1u; }
 
-/* Bit (product >> shift) of a little-endian bitmap, read as a byte: one shift for the LDS address, one
- * bit-field extract for the bit number, one for the bit -- the level-1 filter runs this 1024 times
- * per KiB, and VALU issue slots are what bounds the kernel on pattern-dense input. */
-__device__ __forceinline__ uint32_t testHashedBit(const uint32_t *bitmap, uint32_t product, uint32_t shift)
+/* Bit (product >> shift) of the little-endian bitmap that starts at LDS address 0 (the level-1 bitmap
+ * is the first thing in the block's dynamic LDS, and the kernel has no static LDS: checked at kernel
+ * entry).  Read as a byte: one shift for the LDS address, one bit-field extract for the bit number, one
+ * for the bit.  Addressing LDS by number instead of through the `smem` symbol saves the add of a
+ * link-time constant (0) per test -- the level-1 filter runs this 1024 times per KiB, and VALU issue
+ * slots are what bounds the kernel on pattern-dense input. */
+typedef const __attribute__((address_space(3))) unsigned char LdsByte;
+__device__ __forceinline__ uint32_t loadHashedByteLds0(uint32_t product, uint32_t shift)
 {
-    const uint32_t byte = reinterpret_cast<const unsigned char *>(bitmap)[product >> (shift + 3u)];
-    return __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(product, shift, 3u), 1u);
+    return *reinterpret_cast<LdsByte *>(product >> (shift + 3u));
 }
 
 /* LDS view of one block */
@@ -300,7 +312,7 @@ template <int MODE> struct DenseLane {
         sawLoad = true;
         if (refilling) {
             const uint32_t o = (pos + depth) & 3u;
-            const u32x4 lw = fixWindow16(loadedWindow, pulledBack);
+            const u32x4 lw = __builtin_expect(__ballot(pulledBack != 0) != 0, 0) ? fixWindow16(loadedWindow, pulledBack) : loadedWindow;   /* wave-uniform: end of the input only */
             win = ((uint64_t)windowDword(lw, o + 4) << 32) | windowDword(lw, o);
             have = 8;
             refilling = false;
@@ -315,10 +327,12 @@ template <int MODE> struct DenseLane {
 };
 
 /*
- * CHAINED hashed table walkers (tables.cpp: buildChainedHashTable).  Each step consumes the edge
- * byte plus the slot's single-successor chain (up to 8 bytes) with one dependent memory round trip:
- * the 32-byte slot and the 16-byte input window are independent loads, and the window always
- * contains the edge byte of the NEXT step (1 + 8 + 1 <= 13 usable bytes).
+ * CHAINED hashed table walkers (tables.cpp: buildChainedHashTable).  A step consumes the edge byte
+ * plus the slot's single-successor chain (up to 7 bytes) with one dependent memory round trip and two
+ * gathered 16-byte loads: the slot and the aligned input window behind the edge byte, which always
+ * contains the chain and the edge byte of the NEXT step (3 + 7 + 1 <= 16 bytes).  Gathered loads that
+ * miss the L1 cost ~2.3 cycles per lane on a CU whatever their size (tools/gather_probe.hip), and on
+ * pattern-dense input they are what bounds the kernel, hence the packed slot.
  */
 template <int MODE> struct ChainCtx {
     static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
@@ -327,50 +341,58 @@ template <int MODE> struct ChainCtx {
     const u32x4 *sRoot;
     const uint32_t *in32;
     uint32_t n, numDwords;
-    int numFinal;
     __device__ ChainCtx(const ScanArgs &a, const Lds &lds, uint32_t numDw)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw),
-          numFinal(a.numFinal) {}
+          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw) {}
 };
+
+/* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
+ * ((k*ch) mod 257) & (S-1), ref PFAC_kernel_spaceDriven.cu:76-124.  256 == -1 (mod 257), k*ch <= 65280. */
+__device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
+{
+    const uint32_t x = __umul24(ks & 0x1FFu, ch);
+    const uint32_t r = (x & 0xFFu) - (x >> 8);                 /* in (-256, 256) */
+    return min(r, r + (uint32_t)pfac::kHashP) & (ks >> 9);      /* a negative r is huge as unsigned: picks r + 257 */
+}
 
 template <int MODE> struct ChainLane {
     using Ctx = ChainCtx<MODE>;
     uint32_t pos = 0;
-    int off = -1, ks = -1, match = 0;
-    uint32_t b0 = 0, depth = 0;
-    /* in flight: all eight slot dwords and all four window dwords are consumed later (a dead
+    int row = -1, match = 0;                   /* row: first slot of the current state's bucket, < 0 = no transitions */
+    uint32_t ks = 0, b0 = 0, depth = 0;
+    /* in flight: all four slot dwords and all four window dwords are consumed later (a dead
      * destination register would be recycled by the compiler and force an early wait) */
-    u32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, w = {0, 0, 0, 0};
+    u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
     uint32_t pulledBack = 0;
     bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
-    /* Take the transition described by slot {t0 = end, meta, end.off, end.ks; t1 = chain[8], mask[8]}
-     * on edge byte b0 at position p, given the 16-byte input window `win` loaded at p & ~3: compares
+    /* Take the transition described by slot `t` (pfac::ChainSlot) on edge byte b0 at position p, given the aligned 16-byte input window `win` that starts at (p + 1) & ~3: compares
      * the chain, lands in the slot's end state and picks the next edge byte out of the same window.
      * False = trap. */
-    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t0, const u32x4 &t1, const u32x4 &win, uint32_t p)
+    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t, const u32x4 &win, uint32_t p)
     {
-        if ((t0.y & 0xFFu) != b0 || (int)t0.y < 0) return false;     /* empty slot or another byte's slot */
-        const uint32_t k = (t0.y >> 8) & 0xFFu;
-        if (p + 1 + k > c.n) return false;                     /* the chain would run past the input */
-        /* bytes p+1.. of the input: shift the window by o = (p & 3) + 1 bytes (1..4) */
-        const uint32_t o = (p & 3u) + 1u;
-        const bool whole = o == 4;
-        const uint32_t a0 = whole ? win.y : win.x, a1 = whole ? win.z : win.y, a2 = whole ? win.w : win.z,
-                       a3 = whole ? 0u : win.w;
-        const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, o & 3u);
-        const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, o & 3u);
-        const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, o & 3u);
-        if ((((x0 ^ t1.x) & t1.z) | ((x1 ^ t1.y) & t1.w)) != 0) return false;   /* mismatch inside the chain = trap */
-        const int end = (int)t0.x;
-        if (end <= c.numFinal) match = end;                    /* skipped chain states are never final */
-        off = (int)t0.z; ks = (int)t0.w;
-        depth += 1 + k;
-        const uint32_t sel = k < 4 ? x0 : k < 8 ? x1 : x2;     /* byte k after the edge byte = next edge byte */
-        b0 = (sel >> (8 * (k & 3u))) & 0xFFu;
+        const uint32_t meta = t.x;
+        if ((meta & (pfac::kSlotEmpty | 0xFFu)) != b0) return false;    /* empty slot or another byte's slot */
+        const uint32_t len = (meta >> 8) & 0xFu;
+        if (p + 1 + len > c.n) return false;                   /* the chain would run past the input */
+        const uint32_t o = (p + 1) & 3u;
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(win.y, win.x, o);     /* input bytes p+1 .. p+4 */
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(win.z, win.y, o);     /*             p+5 .. p+8 */
+        const uint64_t diff = ((uint64_t)(x1 ^ t.w) << 32) | (x0 ^ t.z);
+        if (len != 0 && (diff << (64u - 8u * len)) != 0) return false;      /* mismatch inside the chain = trap */
+        const bool leaf = (meta & pfac::kSlotLeaf) != 0;
+        if (meta & pfac::kSlotFinal) match = (int)(leaf ? t.y : t.w);   /* skipped chain states are never final */
+        row = leaf ? -1 : (int)t.y;
+        ks = meta >> 15;
+        depth += 1 + len;
+        b0 = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * len)) & 0xFFu;   /* byte len (<= 7) behind the edge byte */
         return true;
+    }
+    __device__ __forceinline__ u32x4 window(const u32x4 &raw, uint32_t back) const
+    {
+        if (__builtin_expect(__ballot(back != 0) != 0, 0)) return fixWindow16(raw, back);   /* wave-uniform: end of the input only */
+        return raw;
     }
 
     /* The slots of the initial state live in LDS, so the first transition is taken right here.  If
@@ -379,45 +401,40 @@ template <int MODE> struct ChainLane {
      * Returns false if the walk is already over. */
     __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
-        pos = p; match = 0; depth = 0; b0 = x & 0xFF; off = -1; ks = -1; sawLoad = false;
-        const u32x4 r0 = c.sRoot[b0 * 2];
-        if ((int)r0.y < 0) return false;                       /* no transition on this byte */
-        const uint32_t k = (r0.y >> 8) & 0xFFu;
-        const u32x4 r1 = c.sRoot[b0 * 2 + 1];
-        if (k <= 2) {
-            if (p + 1 + k > c.n) return false;
-            if ((((x >> 8) ^ r1.x) & r1.z) != 0) return false;
-            const int end = (int)r0.x;
-            if (end <= c.numFinal) match = end;
-            off = (int)r0.z; ks = (int)r0.w;
-            depth = 1 + k;
+        pos = p; match = 0; depth = 0; b0 = x & 0xFF; row = -1; ks = 0; sawLoad = false;
+        const u32x4 r = c.sRoot[b0];
+        if (r.x & pfac::kSlotEmpty) return false;              /* no transition on this byte */
+        const uint32_t len = (r.x >> 8) & 0xFu;
+        if (len <= 2) {
+            if (p + 1 + len > c.n) return false;
+            if (len != 0 && (((x >> 8) ^ r.z) << (32u - 8u * len)) != 0) return false;
+            const bool leaf = (r.x & pfac::kSlotLeaf) != 0;
+            if (r.x & pfac::kSlotFinal) match = (int)(leaf ? r.y : r.w);
+            row = leaf ? -1 : (int)r.y;
+            ks = r.x >> 15;
+            depth = 1 + len;
             b0 = (x >> (8 * depth)) & 0xFFu;
             return true;
         }
         uint32_t back;
-        const u32x4 raw = loadWindow16(c.in32, p, c.numDwords, back);
+        const u32x4 raw = loadWindow16(c.in32, p + 1, c.numDwords, back);
         sawLoad = true;
-        return advance(c, r0, r1, fixWindow16(raw, back), p);
+        return advance(c, r, window(raw, back), p);
     }
     __device__ __forceinline__ bool issue(const Ctx &c)
     {
         const uint32_t p = pos + depth;                        /* position of the edge byte b0 */
-        if (p >= c.n || off < 0) return false;                 /* end of input, or a state without transitions */
-        const uint32_t idx = (uint32_t)off + (uint32_t)hashSlot(ks, (int)b0);
-        if (MODE == HASH_BUFFER) {
-            s0 = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 32u), 0, 0);
-            s1 = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 32u + 16u), 0, 0);
-        } else {
-            s0 = c.slots[idx * 2u];
-            s1 = c.slots[idx * 2u + 1u];
-        }
-        w = loadWindow16(c.in32, p, c.numDwords, pulledBack);
+        if (p >= c.n || row < 0) return false;                 /* end of input, or a state without transitions */
+        const uint32_t idx = (uint32_t)row + chainHashSlot(ks, b0);
+        if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+        else t = c.slots[idx];
+        w = loadWindow16(c.in32, p + 1, c.numDwords, pulledBack);
         return true;
     }
     __device__ __forceinline__ bool consume(const Ctx &c)
     {
         sawLoad = true;                                        /* a global load issued after the walk started has landed */
-        return advance(c, s0, s1, fixWindow16(w, pulledBack), pos + depth);
+        return advance(c, t, window(w, pulledBack), pos + depth);
     }
 };
 
@@ -427,6 +444,12 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 
 /* --------------------------------------------------------- filter kernel */
 
+#ifndef PFAC_ABLATE
+#define PFAC_ABLATE 0                         /* timing experiments only (tools/ab.sh): 1 = stream + level 1, 2 = no walks */
+#endif
+#ifndef PFAC_STATS
+#define PFAC_STATS 0
+#endif
 #ifndef PFAC_TILES_PER_ITER
 #define PFAC_TILES_PER_ITER 2
 #endif
@@ -439,7 +462,7 @@ constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
 
 template <int MODE, bool HAS_SHORT, bool REDUCE>
-__global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
+__global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filter(ScanArgs a)
 {
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     using WCtx = typename WalkTypes<MODE>::Ctx;
@@ -451,11 +474,12 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     uint32_t *sFinal3 = sGram4 + words4;
     uint32_t *sShort = sFinal3 + wordsF3;
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
-    uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 8 : pfac::kCharSet);
+    uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);
     uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
     uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* testHashedBitLds0: sGram3 must sit at LDS address 0 */
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
         auto copy16 = [&](uint32_t *dst, const void *src, int words) {
             const u32x4 *g = reinterpret_cast<const u32x4 *>(src);
@@ -466,13 +490,13 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         copy16(sGram4, a.gram4, words4);
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
-        if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 8);
+        if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
         else copy16(sFirst, a.initialRow, pfac::kCharSet);
     }
     __syncthreads();
 
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform by construction: keep it (and what derives from it) scalar */
     uint32_t *qBytes = sQBytesAll + wave * kQueueCap;   /* ring: first four input bytes of the position   */
     uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: byte position in the input (32-bit)      */
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
@@ -495,6 +519,11 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
      *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
     uint32_t qh = 0, qv = 0, qu = 0;
     constexpr uint32_t kMask = kQueueCap - 1;
+#if PFAC_STATS
+    uint32_t stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0;
+#endif
+    /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
     /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
      * the walk survives four transitions, or a pattern of length <= 3 can match here */
@@ -514,9 +543,12 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             const uint64_t keepMask = __ballot(keep);
             const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
             if (keep) { qPos[at & kMask] = e; qBytes[at & kMask] = x; }
-            w += (uint32_t)__popcll(keepMask);
+            w = uni(w + (uint32_t)__popcll(keepMask));
         }
-        qv = qu = w;
+#if PFAC_STATS
+        stVerified += w - qv;
+#endif
+        qv = qu = uni(w);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
 
@@ -570,7 +602,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                 if (rn + cnt > kReduceCap) flushStaged();
                 const uint32_t at = rn + laneRankIn(m);
                 if (has) { rPos[at] = pendPos[s]; rId[at] = (uint32_t)pendMatch[s]; pendMatch[s] = 0; }
-                rn += cnt;
+                rn = uni(rn + cnt);
             }
         }
     };
@@ -578,6 +610,11 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++)
             if (alive[s] && !walk[s].issue(wctx)) { alive[s] = false; finish(walk[s], s); }
+#if PFAC_STATS
+        stRounds++;
+#pragma unroll
+        for (int s = 0; s < kWalkSets; s++) stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
+#endif
         stagePending();
     };
     auto walkConsume = [&]() {
@@ -598,8 +635,13 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
                     alive[s] = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
                     if (!alive[s]) finish(walk[s], s);
                 }
+#if PFAC_STATS
+                { const uint32_t took = (uint32_t)__popcll(idle) < qv - qh ? (uint32_t)__popcll(idle) : qv - qh;
+                  stStarts += took;
+                  stStartDead += (uint32_t)__popcll(__ballot(!alive[s] && rank < qv - qh)); }
+#endif
                 const uint32_t taken = (uint32_t)__popcll(idle);
-                qh += taken < qv - qh ? taken : qv - qh;
+                qh = uni(qh + (taken < qv - qh ? taken : qv - qh));
             }
         }
         stagePending();
@@ -613,13 +655,21 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     auto appendHit = [&](uint32_t position, uint32_t x, bool has) {
         if (qu - qh + 64 > kQueueCap) {
             verifyPending();
-            while (qu - qh + 64 > kQueueCap) { walkRefill(); walkIssue(); walkConsume(); }   /* full: walk until there is room */
+            while (qu - qh + 64 > kQueueCap) {   /* full: walk until there is room */
+                walkRefill(); walkIssue(); walkConsume();
+#if PFAC_STATS
+                stFullRounds++;
+#endif
+            }
         }
         const uint64_t m = __ballot(has);
         if (m) {
             const uint32_t at = (qu + laneRankIn(m)) & kMask;
             if (has) { qPos[at] = position; qBytes[at] = x; }
-            qu += (uint32_t)__popcll(m);
+            qu = uni(qu + (uint32_t)__popcll(m));
+#if PFAC_STATS
+            stHits += (uint32_t)__popcll(m);
+#endif
         }
     };
 
@@ -637,6 +687,12 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         halo = haveHalo ? h : 0u;
     };
 
+#if PFAC_ABLATE == 1
+    uint32_t ablateSink = 0;
+#endif
+#if PFAC_STATS
+    uint32_t stIters = 0;
+#endif
     uint32_t chunk = firstChunk;
     u32x4 d[kTilesPerIter];
     uint32_t halo = 0;
@@ -645,6 +701,9 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
     while (chunk < numFullChunks) {
         /* ---- 1. start the next transition of every live walk (kWalkSets x 64 table steps) */
         walkIssue();
+#if PFAC_STATS
+        stIters++;
+#endif
 
         /* ---- 2. prefetch the next chunk of this wave */
         const uint32_t nextChunk = chunk + totalWaves;
@@ -663,7 +722,7 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         /* ---- 4. finish the transitions issued in 1 (the one exposed wait of the iteration) */
         walkConsume();
 
-        /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test each */
+        /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position */
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) {
             const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
@@ -672,17 +731,25 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             if (lane == 63) nxtLane = wrap;
             uint32_t hits = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+            for (int half = 0; half < 2; half++) {          /* 8 positions at a time: 8 LDS reads in flight */
+                uint32_t product[8], byte[8];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t x = __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
-                    /* __umul24 returns int: the shift must be logical */
-                    uint32_t bit = testHashedBit(sGram3, (uint32_t)__umul24(x, pfac::kGram3Mul), lds.shift3);
-                    if (HAS_SHORT) bit |= testBit(sShort, x & 0xFFFFu);
-                    hits |= bit << (j * 4 + i);
+                for (int q = 0; q < 8; q++) {
+                    const int j = half * 2 + (q >> 2), i = q & 3;
+                    const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+                    const uint32_t x = i == 0 ? dw[j] : __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
+                    product[q] = (uint32_t)__umul24(x, pfac::kGram3Mul);       /* __umul24 returns int: shifts must be logical */
+                    byte[q] = loadHashedByteLds0(product[q], lds.shift3);
+                    if (HAS_SHORT) hits |= testBit(sShort, x & 0xFFFFu) << (half * 8 + q);
                 }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    hits |= __builtin_amdgcn_ubfe(byte[q], __builtin_amdgcn_ubfe(product[q], lds.shift3, 3u), 1u) << (half * 8 + q);
             }
+#if PFAC_ABLATE == 1
+            ablateSink |= hits;
+            hits = 0;
+#endif
             /* ---- 6. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
             uint64_t pending = __ballot(hits != 0);
             while (pending) {                               /* wave-uniform: max hits per lane iterations */
@@ -697,6 +764,9 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
             }
         }
         if (qu - qv >= 64) verifyPending();
+#if PFAC_ABLATE == 2
+        qh = qv;                                        /* timing experiment: drop the verified entries unwalked */
+#endif
 
         /* ---- 7. give idle walker lanes new positions (first transition from LDS) */
         walkRefill();
@@ -727,11 +797,28 @@ __global__ __launch_bounds__(kBlockThreads) void pfac_scan_filter(ScanArgs a)
         qv = qu;                                     /* tail entries skip filter level 2 */
     }
 
+#if PFAC_ABLATE == 1
+    if (ablateSink == 0x12345u) a.out[0] = 1;
+#endif
     /* drain: no more chunks to hide behind */
     if (qu != qv) verifyPending();
     walkRefill();
     while (anyAlive() || qh != qv) { walkIssue(); walkConsume(); walkRefill(); }
     if (REDUCE) flushStaged();
+#if PFAC_STATS
+    __syncthreads();
+    if (tid < 16) sGram3[tid] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        atomicAdd(&sGram3[0], stIters); atomicAdd(&sGram3[1], stRounds); atomicAdd(&sGram3[2], stFullRounds);
+        atomicAdd(&sGram3[3], stLaneSteps); atomicAdd(&sGram3[4], stStarts); atomicAdd(&sGram3[5], stHits);
+        atomicAdd(&sGram3[6], stVerified); atomicAdd(&sGram3[7], stStartDead);
+    }
+    __syncthreads();
+    if (tid == 0 && (blockIdx.x % 32) == 0)
+        printf("STATS block %d iters %u rounds %u fullRounds %u laneSteps %u starts %u hits %u verified %u startDead %u\n", (int)blockIdx.x,
+               sGram3[0], sGram3[1], sGram3[2], sGram3[3], sGram3[4], sGram3[5], sGram3[6], sGram3[7]);
+#endif
 }
 
 /* ---------------------------------------------------------- naive kernel */

@@ -108,37 +108,52 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
 /*
  * Device-only "chained" form of the hashed table for the gfx950 walker (scan_gfx950.hip).
  *
- * Slot i corresponds 1:1 to slot i of the reference's hashValPtr.  Besides {next, ch} it carries
+ * Slot i corresponds 1:1 to slot i of the reference's hashValPtr.  Instead of {next, ch} it carries
  *   - the hashRowPtr entry of the state the walker will be in next, so a transition needs ONE
- *     dependent load instead of the reference's two (rowPtr[state], then valPtr[...],
+ *     dependent 16-byte load instead of the reference's two (rowPtr[state], then valPtr[...],
  *     PFAC_kernel_spaceDriven.cu:76-124);
  *   - the single-successor chain that follows `next`: while the current state is not final and has
  *     exactly one outgoing transition, the byte of that transition is appended (up to
  *     kChainMax bytes) and the state advances.  The walker compares the chain against the input
- *     with masked dword compares and lands directly in `end`.  Skipping is exact: the skipped
- *     states are not final, so they could not have changed the reported match, and a mismatch
- *     anywhere in the chain is the trap state (PFAC_CPU.cpp:76-96).
+ *     and lands directly in the end state.  Skipping is exact: the skipped states are not final, so
+ *     they could not have changed the reported match, and a mismatch anywhere in the chain is the
+ *     trap state (PFAC_CPU.cpp:76-96).
+ * The end state's number is only needed when it is final (it is the pattern ID).  A final leaf
+ * keeps it in endRow (a leaf has no bucket); a final state with successors (a pattern that is a
+ * prefix of another) keeps it in chain[4..7], and such a slot's chain is cut to <= 3 bytes (the cut
+ * lands on a non-final chain state; the next slot carries on from there).
  * rootSlots is the same encoding for the 256 transitions of the initial state (kept in LDS).
  */
 static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next)
 {
     ChainSlot s;
-    std::memset(&s, 0xFF, sizeof(s));               /* empty: meta = -1 never equals a byte */
+    std::memset(&s, 0, sizeof(s));
+    s.meta = kSlotEmpty;
+    s.endRow = -1;
     if (next < 0) return s;
-    int k = 0, cur = next;
-    unsigned char bytes[kChainMax];
-    while (k < kChainMax && cur > fa.numPatterns && fa.edgeBegin[cur + 1] - fa.edgeBegin[cur] == 1) {
-        bytes[k++] = fa.edgeCh[fa.edgeBegin[cur]];
-        cur = fa.edgeNext[fa.edgeBegin[cur]];
+    auto follow = [&](int limit, int &end) {
+        int k = 0;
+        end = next;
+        while (k < limit && end > fa.numPatterns && fa.edgeBegin[end + 1] - fa.edgeBegin[end] == 1) {
+            s.chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
+            end = fa.edgeNext[fa.edgeBegin[end]];
+        }
+        return k;
+    };
+    int cur;
+    int k = follow(kChainMax, cur);
+    if (cur <= fa.numPatterns && rowPtr[cur].x >= 0 && k > 3) {      /* final with successors: the ID needs chain[4..7] */
+        std::memset(s.chain, 0, sizeof(s.chain));
+        k = follow(3, cur);
     }
-    s.end = cur;
-    s.meta = ch | (k << 8);
-    s.endOff = rowPtr[cur].x;
-    s.endKS = rowPtr[cur].y;
-    std::memset(s.chain, 0, sizeof(s.chain));
-    std::memset(s.mask, 0, sizeof(s.mask));
-    std::memcpy(s.chain, bytes, (size_t)k);
-    std::memset(s.mask, 0xFF, (size_t)k);
+    const bool leaf = rowPtr[cur].x < 0;
+    const bool fin = cur <= fa.numPatterns;
+    const uint32_t hashK = leaf ? 0u : (uint32_t)rowPtr[cur].y >> 16;           /* 1..256 */
+    const uint32_t sizeMask = leaf ? 0u : (uint32_t)rowPtr[cur].y & 0xFFFFu;    /* S-1 <= 255 */
+    s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 15) |
+             (sizeMask << 24);
+    s.endRow = leaf ? (fin ? cur : -1) : rowPtr[cur].x;
+    if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));
     return s;
 }
 
@@ -150,6 +165,8 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2>
         slots.resize(valPtr.size());
         rootSlots.resize(kCharSet);
     } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+    for (const Int2 &r : rowPtr)
+        if (r.x >= 0 && (((uint32_t)r.y >> 16) > 256u || ((uint32_t)r.y & 0xFFFFu) > 255u)) return PFAC_STATUS_INTERNAL_ERROR;
     for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
     for (int c = 0; c < kCharSet; c++) rootSlots[c] = makeChainSlot(fa, rowPtr, c, kTrapState);
     const int init = fa.initialState;

@@ -73,8 +73,8 @@ constexpr int kTrap = pfac::kTrapState;
 #ifndef PFAC_BLOCK_THREADS
 #define PFAC_BLOCK_THREADS 1024
 #endif
-#ifndef PFAC_MIN_BLOCKS
-#define PFAC_MIN_BLOCKS 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
+#ifndef PFAC_MIN_WAVES_PER_SIMD
+#define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
 #ifndef PFAC_QUEUE_CAP
 #define PFAC_QUEUE_CAP 512
@@ -92,7 +92,8 @@ enum TableMode { DENSE_GLOBAL = 0, DENSE_BUFFER = 1, HASH_GLOBAL = 2, HASH_BUFFE
 struct ScanArgs {
     const unsigned char *in;
     int *out;
-    size_t n;
+    size_t n;                                          /* filter kernel: owned = readable bytes handled here (whole chunks); naive: readable bytes */
+    size_t owned;                                      /* naive kernel: positions [0, owned) get a result */
     const int *dense;
     const Int2 *hashRow;
     const Int2 *hashVal;
@@ -214,29 +215,11 @@ struct Lds {
     uint32_t shift3, shift4, shiftF3;
 };
 
-/* 16 input bytes from the 4-byte aligned address at or below byte `pos` (the input base is 4-byte
- * aligned on this path); dwords at or beyond numDwords read as 0.  Positions are 32-bit: the
- * launcher splits inputs of 4 GiB and more into several launches. */
-__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos, uint32_t numDwords, uint32_t &pulledBack)
+/* 16 input bytes from the 4-byte aligned address at or below byte `pos`.  No bound: the launcher only
+ * gives this kernel positions whose walks end at least 32 bytes before the end of the input. */
+__device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos)
 {
-    /* exactly one load instruction on every path (keeps the compiler's vmcnt bookkeeping exact) and no
-     * use of the loaded value here (the load must stay in flight); numDwords >= 4 on this path.  Near
-     * the end of the input the load is pulled back by `pulledBack` dwords; fixWindow16() undoes it. */
-    const uint32_t w = pos >> 2;
-    const uint32_t wc = w + 4 <= numDwords ? w : numDwords - 4;
-    pulledBack = w - wc;
-    return *reinterpret_cast<const u32x4_a4 *>(in32 + wc);
-}
-
-__device__ __forceinline__ u32x4 fixWindow16(u32x4 t, uint32_t sh)
-{
-    if (sh == 0) return t;
-    u32x4 r;
-    r.x = sh == 1 ? t.y : sh == 2 ? t.z : sh == 3 ? t.w : 0u;
-    r.y = sh == 1 ? t.z : sh == 2 ? t.w : 0u;
-    r.z = sh == 1 ? t.w : 0u;
-    r.w = 0u;
-    return r;
+    return *reinterpret_cast<const u32x4_a4 *>(in32 + (pos >> 2));
 }
 
 /* 4 bytes of a 16-byte window starting at byte offset o (0..12) */
@@ -253,22 +236,24 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
  * Each lane runs kWalkSets independent walks; per scan iteration all of them issue, then the tile
  * prefetch and the zero stores are issued, and only then the (single) wait of the iteration happens,
  * so one memory round trip covers kWalkSets x 64 table steps plus the streaming traffic.
- * The walker code is the largest consumer of VALU issue slots on pattern-dense input (profiles/),
- * hence 32-bit positions and host-precomputed compare masks.
  *
- * Shared, wave-uniform context of the DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte
- * gather per byte.  Input bytes come 16 at a time; a step that runs out of window only refills it.
+ * On pattern-dense input the kernel is bound by instruction issue, and the walkers are the largest
+ * consumer (profiles/): a step is written as straight-line selects (every early `return` costs
+ * exec-mask bookkeeping for the whole wave), positions are 32-bit, and nothing checks a bound -- the
+ * launcher hands the last maxPatternLen + 32 bytes of the input to the simple kernel, so a walk that
+ * starts in this kernel's range can neither run past the input nor load past it.
+ *
+ * DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.  Input bytes come 16 at a
+ * time; a step that runs out of window only refills it.
  */
 template <int MODE> struct DenseCtx {
     static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
     const Lookup<MODE> lookup;
     const uint32_t *in32;
-    uint32_t n, numDwords;
-    int numFinal;
+    uint32_t numFinal;
     const int *sInit;
-    __device__ DenseCtx(const ScanArgs &a, const Lds &lds, uint32_t numDw)
-        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw),
-          numFinal(a.numFinal), sInit(lds.init) {}
+    __device__ DenseCtx(const ScanArgs &a, const Lds &lds)
+        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), numFinal((uint32_t)a.numFinal), sInit(lds.init) {}
 };
 
 template <int MODE> struct DenseLane {
@@ -280,49 +265,42 @@ template <int MODE> struct DenseLane {
     /* in flight */
     int loadedState = kTrap;
     u32x4 loadedWindow = {0, 0, 0, 0};
-    uint32_t pulledBack = 0;
     bool refilling = false;
-    bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
     __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
-        pos = p; refilling = false; sawLoad = false;
+        pos = p; refilling = false;
         state = c.sInit[x & 0xFF];
-        match = (state != kTrap && state <= c.numFinal) ? state : 0;
+        match = (uint32_t)(state - 1) < c.numFinal ? state : 0;       /* final states are 1..F; trap is -1 */
         win = x >> 8; have = 3; depth = 1;
         return state != kTrap;
     }
-    __device__ __forceinline__ bool issue(const Ctx &c)
+    __device__ __forceinline__ void issue(const Ctx &c)
     {
-        if (pos + depth >= c.n) return false;
-        if (have == 0) {                                       /* window exhausted: fetch 8 more bytes */
-            loadedWindow = loadWindow16(c.in32, pos + depth, c.numDwords, pulledBack);
-            refilling = true;
-            return true;
+        refilling = have == 0;
+        if (refilling) {                                       /* window exhausted: fetch 8 more bytes */
+            loadedWindow = loadWindow16(c.in32, pos + depth);
+        } else {
+            int s = c.lookup(state, (int)(win & 0xFF));
+            if (MODE == DENSE_BUFFER && s == 0) s = kTrap;     /* out-of-range clamp of the descriptor */
+            loadedState = s;
         }
-        int s = c.lookup(state, (int)(win & 0xFF));
-        if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
-        loadedState = s;
-        return true;
     }
+    /* false = the walk is over (trap) */
     __device__ __forceinline__ bool consume(const Ctx &c)
     {
-        sawLoad = true;
         if (refilling) {
             const uint32_t o = (pos + depth) & 3u;
-            const u32x4 lw = __builtin_expect(__ballot(pulledBack != 0) != 0, 0) ? fixWindow16(loadedWindow, pulledBack) : loadedWindow;   /* wave-uniform: end of the input only */
-            win = ((uint64_t)windowDword(lw, o + 4) << 32) | windowDword(lw, o);
+            win = ((uint64_t)windowDword(loadedWindow, o + 4) << 32) | windowDword(loadedWindow, o);
             have = 8;
-            refilling = false;
             return true;
         }
-        if (loadedState == kTrap) return false;
         state = loadedState;
-        if (state <= c.numFinal) match = state;
+        match = (uint32_t)(state - 1) < c.numFinal ? state : match;
         win >>= 8; have--; depth++;
-        return true;
+        return state != kTrap;
     }
 };
 
@@ -331,8 +309,8 @@ template <int MODE> struct DenseLane {
  * plus the slot's single-successor chain (up to 7 bytes) with one dependent memory round trip and two
  * gathered 16-byte loads: the slot and the aligned input window behind the edge byte, which always
  * contains the chain and the edge byte of the NEXT step (3 + 7 + 1 <= 16 bytes).  Gathered loads that
- * miss the L1 cost ~2.3 cycles per lane on a CU whatever their size (tools/gather_probe.hip), and on
- * pattern-dense input they are what bounds the kernel, hence the packed slot.
+ * miss the L1 cost ~2.3 cycles per lane on a CU whatever their size (tools/gather_probe.hip), hence
+ * the packed slot.
  */
 template <int MODE> struct ChainCtx {
     static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
@@ -340,11 +318,10 @@ template <int MODE> struct ChainCtx {
     __amdgpu_buffer_rsrc_t rsrc;
     const u32x4 *sRoot;
     const uint32_t *in32;
-    uint32_t n, numDwords;
-    __device__ ChainCtx(const ScanArgs &a, const Lds &lds, uint32_t numDw)
+    __device__ ChainCtx(const ScanArgs &a, const Lds &lds)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)), n((uint32_t)a.n), numDwords(numDw) {}
+          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
 };
 
 /* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
@@ -359,40 +336,35 @@ __device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
 template <int MODE> struct ChainLane {
     using Ctx = ChainCtx<MODE>;
     uint32_t pos = 0;
-    int row = -1, match = 0;                   /* row: first slot of the current state's bucket, < 0 = no transitions */
+    uint32_t row = 0;                          /* first slot of the current state's bucket */
+    int match = 0;
     uint32_t ks = 0, b0 = 0, depth = 0;
-    /* in flight: all four slot dwords and all four window dwords are consumed later (a dead
-     * destination register would be recycled by the compiler and force an early wait) */
+    /* in flight: all four slot dwords and the first three window dwords are consumed later */
     u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
-    uint32_t pulledBack = 0;
-    bool sawLoad = false;                      /* a global load issued after this position's zero stores has completed */
 
-    /* Take the transition described by slot `t` (pfac::ChainSlot) on edge byte b0 at position p, given the aligned 16-byte input window `win` that starts at (p + 1) & ~3: compares
-     * the chain, lands in the slot's end state and picks the next edge byte out of the same window.
-     * False = trap. */
-    __device__ __forceinline__ bool advance(const Ctx &c, const u32x4 &t, const u32x4 &win, uint32_t p)
+    /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0 at position p, given
+     * the aligned 16-byte input window `win` that starts at (p + 1) & ~3: compares the chain, lands in
+     * the slot's end state and picks the next edge byte out of the same window.  Straight-line: the
+     * walker's fields are garbage afterwards unless the result is true; `match` is always valid.
+     * False = the walk is over (trap, or the end state has no successor). */
+    __device__ __forceinline__ bool advance(const u32x4 &s, const u32x4 &win, uint32_t p)
     {
-        const uint32_t meta = t.x;
-        if ((meta & (pfac::kSlotEmpty | 0xFFu)) != b0) return false;    /* empty slot or another byte's slot */
+        const uint32_t meta = s.x;
         const uint32_t len = (meta >> 8) & 0xFu;
-        if (p + 1 + len > c.n) return false;                   /* the chain would run past the input */
         const uint32_t o = (p + 1) & 3u;
         const uint32_t x0 = __builtin_amdgcn_alignbyte(win.y, win.x, o);     /* input bytes p+1 .. p+4 */
         const uint32_t x1 = __builtin_amdgcn_alignbyte(win.z, win.y, o);     /*             p+5 .. p+8 */
-        const uint64_t diff = ((uint64_t)(x1 ^ t.w) << 32) | (x0 ^ t.z);
-        if (len != 0 && (diff << (64u - 8u * len)) != 0) return false;      /* mismatch inside the chain = trap */
+        const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
+        /* the slot is this byte's (not empty, not another byte's), and the chain matches the input */
+        const bool ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & ((len == 0) | ((diff << (64u - 8u * len)) == 0));
         const bool leaf = (meta & pfac::kSlotLeaf) != 0;
-        if (meta & pfac::kSlotFinal) match = (int)(leaf ? t.y : t.w);   /* skipped chain states are never final */
-        row = leaf ? -1 : (int)t.y;
+        const int id = (int)(leaf ? s.y : s.w);                /* kSlotFinal: see pfac::ChainSlot */
+        match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
+        row = s.y;
         ks = meta >> 15;
         depth += 1 + len;
         b0 = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * len)) & 0xFFu;   /* byte len (<= 7) behind the edge byte */
-        return true;
-    }
-    __device__ __forceinline__ u32x4 window(const u32x4 &raw, uint32_t back) const
-    {
-        if (__builtin_expect(__ballot(back != 0) != 0, 0)) return fixWindow16(raw, back);   /* wave-uniform: end of the input only */
-        return raw;
+        return ok & !leaf;
     }
 
     /* The slots of the initial state live in LDS, so the first transition is taken right here.  If
@@ -401,41 +373,34 @@ template <int MODE> struct ChainLane {
      * Returns false if the walk is already over. */
     __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
-        pos = p; match = 0; depth = 0; b0 = x & 0xFF; row = -1; ks = 0; sawLoad = false;
+        pos = p; match = 0; depth = 0; b0 = x & 0xFF;
         const u32x4 r = c.sRoot[b0];
-        if (r.x & pfac::kSlotEmpty) return false;              /* no transition on this byte */
         const uint32_t len = (r.x >> 8) & 0xFu;
-        if (len <= 2) {
-            if (p + 1 + len > c.n) return false;
-            if (len != 0 && (((x >> 8) ^ r.z) << (32u - 8u * len)) != 0) return false;
+        const bool present = (r.x & pfac::kSlotEmpty) == 0;
+        bool cont;
+        if (__builtin_expect(__ballot(present & (len > 2)) != 0, 0)) {        /* wave-uniform; rare with real pattern sets */
+            cont = false;
+            if (present) cont = advance(r, loadWindow16(c.in32, p + 1), p);
+        } else {
+            const bool ok = present & ((len == 0) | ((((x >> 8) ^ r.z) << (32u - 8u * len)) == 0));
             const bool leaf = (r.x & pfac::kSlotLeaf) != 0;
-            if (r.x & pfac::kSlotFinal) match = (int)(leaf ? r.y : r.w);
-            row = leaf ? -1 : (int)r.y;
+            match = (ok & ((r.x & pfac::kSlotFinal) != 0)) ? (int)(leaf ? r.y : r.w) : 0;
+            row = r.y;
             ks = r.x >> 15;
             depth = 1 + len;
             b0 = (x >> (8 * depth)) & 0xFFu;
-            return true;
+            cont = ok & !leaf;
         }
-        uint32_t back;
-        const u32x4 raw = loadWindow16(c.in32, p + 1, c.numDwords, back);
-        sawLoad = true;
-        return advance(c, r, window(raw, back), p);
+        return cont;
     }
-    __device__ __forceinline__ bool issue(const Ctx &c)
+    __device__ __forceinline__ void issue(const Ctx &c)
     {
-        const uint32_t p = pos + depth;                        /* position of the edge byte b0 */
-        if (p >= c.n || row < 0) return false;                 /* end of input, or a state without transitions */
-        const uint32_t idx = (uint32_t)row + chainHashSlot(ks, b0);
+        const uint32_t idx = row + chainHashSlot(ks, b0);
         if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
         else t = c.slots[idx];
-        w = loadWindow16(c.in32, p + 1, c.numDwords, pulledBack);
-        return true;
+        w = loadWindow16(c.in32, pos + depth + 1);             /* pos + depth = position of the edge byte b0 */
     }
-    __device__ __forceinline__ bool consume(const Ctx &c)
-    {
-        sawLoad = true;                                        /* a global load issued after the walk started has landed */
-        return advance(c, t, window(w, pulledBack), pos + depth);
-    }
+    __device__ __forceinline__ bool consume(const Ctx &) { return advance(t, w, pos + depth); }
 };
 
 template <int MODE> struct WalkTypes { using Ctx = DenseCtx<MODE>; using Lane = DenseLane<MODE>; };
@@ -448,7 +413,7 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 #define PFAC_ABLATE 0                         /* timing experiments only (tools/ab.sh): 1 = stream + level 1, 2 = no walks */
 #endif
 #ifndef PFAC_STATS
-#define PFAC_STATS 0
+#define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
 #endif
 #ifndef PFAC_TILES_PER_ITER
 #define PFAC_TILES_PER_ITER 2
@@ -461,8 +426,9 @@ constexpr int kWalkSets = PFAC_WALK_SETS;            /* independent walks per la
 constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
 
+/* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
 template <int MODE, bool HAS_SHORT, bool REDUCE>
-__global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filter(ScanArgs a)
+__global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_scan_filter(ScanArgs a)
 {
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     using WCtx = typename WalkTypes<MODE>::Ctx;
@@ -479,7 +445,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
     uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
-    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* testHashedBitLds0: sGram3 must sit at LDS address 0 */
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
         auto copy16 = [&](uint32_t *dst, const void *src, int words) {
             const u32x4 *g = reinterpret_cast<const u32x4 *>(src);
@@ -502,11 +468,10 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
     const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
-    const uint32_t numDwords = (n + 3u) >> 2;       /* dwords that may be read (reference pads the same way, PFAC.cpp:838-842) */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
                   32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
-    const WCtx wctx(a, lds, numDwords);
+    const WCtx wctx(a, lds);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
 #pragma unroll
@@ -519,11 +484,11 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
      *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
     uint32_t qh = 0, qv = 0, qu = 0;
     constexpr uint32_t kMask = kQueueCap - 1;
-#if PFAC_STATS
-    uint32_t stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0;
-#endif
     /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+#if PFAC_STATS
+    uint32_t stIters = 0, stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0;
+#endif
 
     /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
      * the walk survives four transitions, or a pattern of length <= 3 can match here */
@@ -531,7 +496,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t w = qv;
-        for (uint32_t r = qv; r != qu; r += (qu - r < 64 ? qu - r : 64)) {
+        for (uint32_t r = qv; r != qu; r = uni(r + (qu - r < 64 ? qu - r : 64))) {
             const uint32_t idx = r + lane;
             const bool act = (uint32_t)lane < qu - r;
             const uint32_t x = act ? qBytes[idx & kMask] : 0u;
@@ -552,11 +517,11 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
 
-    /* Zero stores and walker loads of one wave complete in issue order (a single in-order vmcnt
-     * counter), and a position is only walked after the loads issued behind its chunk's zero stores
-     * have been consumed, so the patch always lands on top of the zero.  Walks that ended without
-     * consuming a global load (patterns resolved from LDS alone) drain this wave's stores first. */
-    /* REDUCE: results are staged per wave in LDS and flushed with one atomic per kReduceCap pairs
+    /* Reporting a finished walk.  Zero stores and walker loads of one wave complete in issue order (a
+     * single in-order vmcnt counter), and a walk that ends in consume() has just consumed loads issued
+     * behind its chunk's zero stores, so its patch lands on top of the zero.  A walk that ends in
+     * start() (resolved from LDS alone) drains this wave's stores first.
+     * REDUCE: results are staged per wave in LDS and flushed with one atomic per kReduceCap pairs
      * (a single device counter saturates at ~90 increments/us; pattern-dense input has 10^5..10^6 matches) */
     uint32_t *rPos = sReduceAll + wave * (2 * kReduceCap);
     uint32_t *rId = rPos + kReduceCap;
@@ -566,13 +531,13 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) { pendMatch[s] = 0; pendPos[s] = 0; }
 
-    auto finish = [&](const WLane &w, int s) {
-        if (w.match != 0) {
+    auto report = [&](bool ended, const WLane &w, int s, bool afterLoad) {
+        if (ended & (w.match != 0)) {
             if (REDUCE) {                                  /* parked; stagePending() picks it up in uniform control flow */
                 pendMatch[s] = w.match;
                 pendPos[s] = w.pos;
             } else {
-                if (!w.sawLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!afterLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 a.out[w.pos] = w.match;
             }
         }
@@ -609,18 +574,21 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
     auto walkIssue = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++)
-            if (alive[s] && !walk[s].issue(wctx)) { alive[s] = false; finish(walk[s], s); }
+            if (alive[s]) walk[s].issue(wctx);
 #if PFAC_STATS
         stRounds++;
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
 #endif
-        stagePending();
     };
     auto walkConsume = [&]() {
 #pragma unroll
-        for (int s = 0; s < kWalkSets; s++)
-            if (alive[s] && !walk[s].consume(wctx)) { alive[s] = false; finish(walk[s], s); }
+        for (int s = 0; s < kWalkSets; s++) {
+            bool cont = false;
+            if (alive[s]) cont = walk[s].consume(wctx);
+            report(alive[s] & !cont, walk[s], s, true);
+            alive[s] = cont;
+        }
         stagePending();
     };
     /* hand verified queue entries to idle walker lanes; the first transition happens here (LDS) */
@@ -631,16 +599,16 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
             if (idle && qh != qv) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
-                if (!alive[s] && rank < qv - qh) {
-                    alive[s] = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
-                    if (!alive[s]) finish(walk[s], s);
-                }
-#if PFAC_STATS
-                { const uint32_t took = (uint32_t)__popcll(idle) < qv - qh ? (uint32_t)__popcll(idle) : qv - qh;
-                  stStarts += took;
-                  stStartDead += (uint32_t)__popcll(__ballot(!alive[s] && rank < qv - qh)); }
-#endif
+                const bool take = !alive[s] & (rank < qv - qh);
+                bool cont = false;
+                if (take) cont = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
+                report(take & !cont, walk[s], s, false);
+                alive[s] = alive[s] | cont;
                 const uint32_t taken = (uint32_t)__popcll(idle);
+#if PFAC_STATS
+                stStarts += taken < qv - qh ? taken : qv - qh;
+                stStartDead += (uint32_t)__popcll(__ballot(take & !cont));
+#endif
                 qh = uni(qh + (taken < qv - qh ? taken : qv - qh));
             }
         }
@@ -673,32 +641,26 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
         }
     };
 
-    /* The main loop only sees FULL chunks and issues the same vector-memory instructions on every
-     * path (the prefetch past the end is clamped, not skipped).  The ragged tail is handled after. */
-    const uint32_t numFullChunks = n / kChunkBytes;          /* >= 1: the launcher sends smaller inputs elsewhere */
+    /* Every path of the loop issues the same vector-memory instructions (the prefetch past the last
+     * chunk is clamped, not skipped), which keeps the compiler's wait counts exact. */
+    const uint32_t numChunks = n / kChunkBytes;
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
-        const uint32_t cc = c < numFullChunks ? c : numFullChunks - 1;
+        const uint32_t cc = c < numChunks ? c : numChunks - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
-        const uint32_t hd = (cc + 1) * (kChunkBytes / 4);
-        const bool haveHalo = hd < numDwords;
-        const uint32_t h = in32[haveHalo ? hd : numDwords - 1];
-        halo = haveHalo ? h : 0u;
+        halo = in32[(cc + 1) * (kChunkBytes / 4)];                                    /* first dword behind the chunk */
     };
 
 #if PFAC_ABLATE == 1
     uint32_t ablateSink = 0;
 #endif
-#if PFAC_STATS
-    uint32_t stIters = 0;
-#endif
     uint32_t chunk = firstChunk;
     u32x4 d[kTilesPerIter];
     uint32_t halo = 0;
-    if (chunk < numFullChunks) loadChunk(chunk, d, halo);
+    if (chunk < numChunks) loadChunk(chunk, d, halo);
 
-    while (chunk < numFullChunks) {
+    while (chunk < numChunks) {
         /* ---- 1. start the next transition of every live walk (kWalkSets x 64 table steps) */
         walkIssue();
 #if PFAC_STATS
@@ -776,30 +738,10 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
         halo = nhalo;
         chunk = nextChunk;
     }
-
-    /* ---- ragged tail: the < kChunkBytes behind the last full chunk belong to the wave whose stride
-     * lands on it.  Every position is zeroed, then queued without filtering (the walker is exact). */
-    if (chunk == numFullChunks && numFullChunks * kChunkBytes < n) {
-        const uint32_t base = numFullChunks * kChunkBytes;
-        const uint32_t rem = n - base;
-        if (!REDUCE) {
-            for (uint32_t o = lane; o < rem; o += 64) a.out[base + o] = 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        for (uint32_t o0 = 0; o0 < rem; o0 += 64) {
-            const uint32_t o = o0 + lane;
-            const bool has = o < rem;
-            uint32_t x = 0;
-            for (int j = 0; j < 4; j++)
-                if (has && base + o + j < n) x |= (uint32_t)a.in[base + o + j] << (8 * j);
-            appendHit(base + o, x, has);
-        }
-        qv = qu;                                     /* tail entries skip filter level 2 */
-    }
-
 #if PFAC_ABLATE == 1
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
+
     /* drain: no more chunks to hide behind */
     if (qu != qv) verifyPending();
     walkRefill();
@@ -823,8 +765,9 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_BLOCKS) void pfac_scan_filt
 
 /* ---------------------------------------------------------- naive kernel */
 
-/* One thread per input byte, no prefilter: the reference's algorithm with
- * only the initial-state row staged in LDS.  Alignment-agnostic. */
+/* One thread per input byte, no prefilter: the reference's algorithm with only the initial-state row
+ * staged in LDS.  Alignment-agnostic, 64-bit positions.  Produces results for positions [0, owned);
+ * walks may read up to a.n (owned <= n). */
 template <int MODE>
 __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 {
@@ -834,7 +777,7 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
     const Lookup<MODE> lookup(a);
     const size_t n = a.n;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < a.owned; j += stride) {
         int state = sInit[a.in[j]];
         int match = 0;
         if (state != kTrap) {
@@ -885,7 +828,7 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 template <int MODE>
 hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
 {
-    size_t blocks = (a.n + 255) / 256;
+    size_t blocks = (a.owned + 255) / 256;
     const size_t cap = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * 8;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(pfac_scan_naive<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
@@ -893,9 +836,8 @@ hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
 }
 
 template <int MODE>
-hipError_t launchMode(const PFAC_context *c, const ScanArgs &a, bool vectorOk)
+hipError_t launchMode(const PFAC_context *c, const ScanArgs &a)
 {
-    if (c->kernelVariant == PFACX_KERNEL_NAIVE || !vectorOk) return launchNaive<MODE>(c, a);
     return c->filter.hasShort ? launchFilter<MODE, true, false>(c, a) : launchFilter<MODE, false, false>(c, a);
 }
 
@@ -917,7 +859,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a = ScanArgs{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
     a.out = d_matched_result;
-    a.n = input_size;
+    a.n = a.owned = input_size;
     a.dense = c->d_dense;
     a.hashRow = c->d_hashRow;
     a.hashVal = c->d_hashVal;
@@ -946,6 +888,23 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     return PFAC_STATUS_SUCCESS;
 }
 
+/* Launch plan for positions [first, ownEnd) of an input of inputSize readable bytes:
+ *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 32 bytes inside the input
+ *                              (a walk is at most maxPatternLen deep, a window load reads <= 19 bytes on)
+ *   [first + mainLen, ownEnd)  simple kernel (bounds-checked byte loads): the end of the input, and
+ *                              everything when the pointers are not 16-byte aligned                    */
+size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
+{
+    if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
+    const size_t margin = (size_t)c->fa.maxPatternLen + 32;
+    const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
+    const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;
+    return end > first ? (end - first) / kChunkBytes * kChunkBytes : 0;
+}
+
+/* The vector kernel keeps byte positions in 32 bits: larger inputs are scanned as consecutive windows */
+constexpr size_t kMaxLaunchBytes = (size_t(1) << 32) - (size_t(1) << 24);
+
 PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size, int *d_matched_result, bool hashed)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
@@ -954,29 +913,26 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     const PFAC_status_t st = fillArgs(c, hashed, d_input_string, input_size, d_matched_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
-    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) && a.n >= (size_t)kChunkBytes;
-    auto launch = [&](const ScanArgs &args) {
-        if (hashed) return tex ? launchMode<HASH_BUFFER>(c, args, vectorOk) : launchMode<HASH_GLOBAL>(c, args, vectorOk);
-        return tex ? launchMode<DENSE_BUFFER>(c, args, vectorOk) : launchMode<DENSE_GLOBAL>(c, args, vectorOk);
-    };
-    /* The vector kernel keeps byte positions in 32 bits.  Larger inputs are scanned as consecutive
-     * windows of kMaxLaunchBytes owned positions; each window also scans maxPatternLen bytes of its
-     * successor, whose (possibly cut short) results are overwritten by the next launch -- launches on
-     * one stream run in order, so the final value of every element is the complete one. */
-    constexpr size_t kMaxLaunchBytes = (size_t(1) << 32) - (size_t(1) << 24);
+    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
     hipError_t e = hipSuccess;
-    if (input_size <= kMaxLaunchBytes || !vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) {
-        e = launch(a);
-    } else {
-        const size_t overlap = (size_t)c->fa.maxPatternLen;
-        for (size_t off = 0; off < input_size && e == hipSuccess; off += kMaxLaunchBytes) {
-            ScanArgs part = a;
-            part.in = a.in + off;
-            part.out = a.out + off;
-            const size_t owned = input_size - off < kMaxLaunchBytes ? input_size - off : kMaxLaunchBytes;
-            part.n = owned + overlap < input_size - off ? owned + overlap : input_size - off;
-            e = launch(part);
+    for (size_t first = 0; first < input_size && e == hipSuccess; first += kMaxLaunchBytes) {
+        const size_t ownEnd = input_size - first < kMaxLaunchBytes ? input_size : first + kMaxLaunchBytes;
+        const size_t mainLen = filterLength(c, first, ownEnd, input_size, vectorOk);
+        ScanArgs part = a;
+        part.in = a.in + first;
+        part.out = a.out + first;
+        if (mainLen) {
+            part.n = part.owned = mainLen;
+            if (hashed) e = tex ? launchMode<HASH_BUFFER>(c, part) : launchMode<HASH_GLOBAL>(c, part);
+            else        e = tex ? launchMode<DENSE_BUFFER>(c, part) : launchMode<DENSE_GLOBAL>(c, part);
+        }
+        if (e == hipSuccess && first + mainLen < ownEnd) {
+            part.in += mainLen;
+            part.out += mainLen;
+            part.owned = ownEnd - first - mainLen;
+            part.n = input_size - first - mainLen;
+            if (hashed) e = tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
+            else        e = tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
         }
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
@@ -990,6 +946,8 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
  * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
  * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
  * device counter, and the (usually short) list is then sorted by position with rocPRIM's radix sort.
+ * The end of the input (and everything, for odd pointers) goes through the simple kernel into a
+ * scratch vector that is compacted on the host and appended -- its positions follow all others.
  * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
  * (PFAC_reduce_kernel.cu:417-457) because it has no prefilter: every thread owns a result.
  * Synchronous, like the reference (the count goes back to the host).
@@ -1006,18 +964,20 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     PFAC_status_t st = fillArgs(c, hashed, reinterpret_cast<const char *>(d_input_string), n, d_match_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
     unsigned int count = 0;
+    const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
 
-    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) && n >= (size_t)kChunkBytes &&
-                          c->kernelVariant != PFACX_KERNEL_NAIVE;
-    if (vectorOk) {
-        a.reducePos = d_pos;
-        a.reduceCount = c->d_reduceCount;
-        a.reduceBase = 0;
+    const bool vectorOk = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0;
+    const size_t mainLen = filterLength(c, 0, n, n, vectorOk);
+    if (mainLen) {
+        ScanArgs part = a;
+        part.n = part.owned = mainLen;
+        part.reducePos = d_pos;
+        part.reduceCount = c->d_reduceCount;
+        part.reduceBase = 0;
         if (hipMemsetAsync(c->d_reduceCount, 0, sizeof(unsigned int), 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
         hipError_t e;
-        if (hashed) e = tex ? launchReduceMode<HASH_BUFFER>(c, a) : launchReduceMode<HASH_GLOBAL>(c, a);
-        else        e = tex ? launchReduceMode<DENSE_BUFFER>(c, a) : launchReduceMode<DENSE_GLOBAL>(c, a);
+        if (hashed) e = tex ? launchReduceMode<HASH_BUFFER>(c, part) : launchReduceMode<HASH_GLOBAL>(c, part);
+        else        e = tex ? launchReduceMode<DENSE_BUFFER>(c, part) : launchReduceMode<DENSE_GLOBAL>(c, part);
         if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (count > 1) {                                   /* order by position */
@@ -1044,22 +1004,31 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             if (!ok) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
             if (se != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         }
-    } else {
-        /* odd pointers / tiny inputs: full-result scan into a scratch vector, compacted on the host */
+    }
+    if (mainLen < n) {
+        /* the rest: full results into a scratch vector, compacted on the host */
+        const size_t rest = n - mainLen;
         int *d_full = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d_full), n * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
-        st = scan(handle, reinterpret_cast<char *>(d_input_string), n, d_full, hashed);
-        std::vector<int> full(n), ids, pos;
-        if (st == PFAC_STATUS_SUCCESS && hipMemcpy(full.data(), d_full, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipMalloc(reinterpret_cast<void **>(&d_full), rest * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+        ScanArgs part = a;
+        part.in = a.in + mainLen;
+        part.out = d_full;
+        part.n = part.owned = rest;
+        hipError_t e;
+        if (hashed) e = tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
+        else        e = tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
+        std::vector<int> full(rest), ids, pos;
+        st = e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
+        if (st == PFAC_STATUS_SUCCESS && hipMemcpy(full.data(), d_full, rest * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
             st = PFAC_STATUS_INTERNAL_ERROR;
         (void)hipFree(d_full);
         if (st != PFAC_STATUS_SUCCESS) return st;
-        for (size_t i = 0; i < n; i++)
-            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)i); }
-        count = (unsigned int)ids.size();
-        if (count && (hipMemcpy(d_match_result, ids.data(), count * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                      hipMemcpy(d_pos, pos.data(), count * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+        for (size_t i = 0; i < rest; i++)
+            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)(mainLen + i)); }
+        if (!ids.empty() && (hipMemcpy(d_match_result + count, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(d_pos + count, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
             return PFAC_STATUS_INTERNAL_ERROR;
+        count += (unsigned int)ids.size();
     }
     *h_num_matched = (int)count;
     if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)

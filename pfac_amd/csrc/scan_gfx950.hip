@@ -339,21 +339,33 @@ template <int MODE> struct ChainLane {
     uint32_t row = 0;                          /* first slot of the current state's bucket */
     int match = 0;
     uint32_t ks = 0, b0 = 0, depth = 0;
-    /* in flight: all four slot dwords and the first three window dwords are consumed later */
+    /* The 16-byte input window stays in registers across steps (wpos = position of its first byte) and
+     * is only re-fetched when a MATCHING slot needs bytes beyond it: gathered loads are what bounds
+     * the kernel on pattern-dense input (each costs as much as ~60 ALU instructions, tools/ab.sh
+     * sensitivity runs), and the step that ends a walk -- a slot for some other byte -- needs none. */
     u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
+    uint32_t wpos = 0;
+    bool haveWin = false, needWin = true, needSlot = true;
 
-    /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0 at position p, given
-     * the aligned 16-byte input window `win` that starts at (p + 1) & ~3: compares the chain, lands in
-     * the slot's end state and picks the next edge byte out of the same window.  Straight-line: the
-     * walker's fields are garbage afterwards unless the result is true; `match` is always valid.
-     * False = the walk is over (trap, or the end state has no successor). */
-    __device__ __forceinline__ bool advance(const u32x4 &s, const u32x4 &win, uint32_t p)
+    /* input bytes q .. q+7 out of the window (q - wpos in 0..15; bytes beyond the window read as 0) */
+    __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
+    {
+        const uint32_t o = q - wpos, j = o >> 2;
+        const uint32_t lo = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+        const uint32_t mid = j == 0 ? w.y : j == 1 ? w.z : j == 2 ? w.w : 0u;
+        const uint32_t hi = j == 0 ? w.z : j == 1 ? w.w : 0u;
+        x0 = __builtin_amdgcn_alignbyte(mid, lo, o & 3u);
+        x1 = __builtin_amdgcn_alignbyte(hi, mid, o & 3u);
+    }
+
+    /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0, given the input
+     * bytes x0:x1 behind the edge byte: compares the chain, lands in the slot's end state and picks
+     * the next edge byte.  Straight-line: the walker's fields are garbage afterwards unless the result
+     * is true; `match` is always valid.  False = the walk is over (trap, or no successor). */
+    __device__ __forceinline__ bool advance(const u32x4 &s, uint32_t x0, uint32_t x1)
     {
         const uint32_t meta = s.x;
         const uint32_t len = (meta >> 8) & 0xFu;
-        const uint32_t o = (p + 1) & 3u;
-        const uint32_t x0 = __builtin_amdgcn_alignbyte(win.y, win.x, o);     /* input bytes p+1 .. p+4 */
-        const uint32_t x1 = __builtin_amdgcn_alignbyte(win.z, win.y, o);     /*             p+5 .. p+8 */
         const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
         /* the slot is this byte's (not empty, not another byte's), and the chain matches the input */
         const bool ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & ((len == 0) | ((diff << (64u - 8u * len)) == 0));
@@ -374,13 +386,20 @@ template <int MODE> struct ChainLane {
     __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
         pos = p; match = 0; depth = 0; b0 = x & 0xFF;
+        haveWin = false; needWin = true; needSlot = true;
         const u32x4 r = c.sRoot[b0];
         const uint32_t len = (r.x >> 8) & 0xFu;
         const bool present = (r.x & pfac::kSlotEmpty) == 0;
         bool cont;
         if (__builtin_expect(__ballot(present & (len > 2)) != 0, 0)) {        /* wave-uniform; rare with real pattern sets */
             cont = false;
-            if (present) cont = advance(r, loadWindow16(c.in32, p + 1), p);
+            if (present) {
+                w = loadWindow16(c.in32, p + 1);
+                wpos = (p + 1) & ~3u;
+                uint32_t x0, x1;
+                windowBytes(p + 1, x0, x1);
+                cont = advance(r, x0, x1);
+            }
         } else {
             const bool ok = present & ((len == 0) | ((((x >> 8) ^ r.z) << (32u - 8u * len)) == 0));
             const bool leaf = (r.x & pfac::kSlotLeaf) != 0;
@@ -395,12 +414,31 @@ template <int MODE> struct ChainLane {
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
-        const uint32_t idx = row + chainHashSlot(ks, b0);
-        if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
-        else t = c.slots[idx];
-        w = loadWindow16(c.in32, pos + depth + 1);             /* pos + depth = position of the edge byte b0 */
+        if (needSlot) {
+            const uint32_t idx = row + chainHashSlot(ks, b0);
+            if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+            else t = c.slots[idx];
+        }
+        if (needWin) {
+            w = loadWindow16(c.in32, pos + depth + 1);         /* pos + depth = position of the edge byte b0 */
+            wpos = (pos + depth + 1) & ~3u;
+            haveWin = true;
+        }
     }
-    __device__ __forceinline__ bool consume(const Ctx &) { return advance(t, w, pos + depth); }
+    __device__ __forceinline__ bool consume(const Ctx &)
+    {
+        const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
+        const uint32_t len = (t.x >> 8) & 0xFu;
+        const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
+        const bool covered = haveWin & (q - wpos + len + 1u <= 16u);
+        needWin = mine & !covered;                             /* matching slot, bytes missing: fetch them and come back */
+        needSlot = !needWin;
+        uint32_t x0, x1;
+        windowBytes(q, x0, x1);
+        bool cont = true;
+        if (!needWin) cont = advance(t, x0, x1);
+        return cont;
+    }
 };
 
 template <int MODE> struct WalkTypes { using Ctx = DenseCtx<MODE>; using Lane = DenseLane<MODE>; };
@@ -414,6 +452,18 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 #endif
 #ifndef PFAC_STATS
 #define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
+#endif
+#ifndef PFAC_PAD_GATHER
+#define PFAC_PAD_GATHER 0     /* PFAC_PAD_*: sensitivity experiments (tools/ab.sh), results stay exact */
+#endif
+#ifndef PFAC_PAD_VALU
+#define PFAC_PAD_VALU 0
+#endif
+#ifndef PFAC_PAD_LDS
+#define PFAC_PAD_LDS 0
+#endif
+#ifndef PFAC_STREAM_AUX
+#define PFAC_STREAM_AUX (-1)
 #endif
 #ifndef PFAC_TILES_PER_ITER
 #define PFAC_TILES_PER_ITER 2
@@ -504,6 +554,9 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
             pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
             if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
+#if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
+            pass = (((e * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
+#endif
             const bool keep = act && pass != 0;
             const uint64_t keepMask = __ballot(keep);
             const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
@@ -623,8 +676,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     auto appendHit = [&](uint32_t position, uint32_t x, bool has) {
         if (qu - qh + 64 > kQueueCap) {
             verifyPending();
-            while (qu - qh + 64 > kQueueCap) {   /* full: walk until there is room */
-                walkRefill(); walkIssue(); walkConsume();
+            while (qu - qh + 64 > kQueueCap) {   /* full: walk until there is room (walks are in flight here) */
+                walkConsume(); walkRefill(); walkIssue();
 #if PFAC_STATS
                 stFullRounds++;
 #endif
@@ -644,12 +697,22 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     /* Every path of the loop issues the same vector-memory instructions (the prefetch past the last
      * chunk is clamped, not skipped), which keeps the compiler's wait counts exact. */
     const uint32_t numChunks = n / kChunkBytes;
+#if PFAC_STREAM_AUX >= 0
+    const __amdgpu_buffer_rsrc_t streamRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in), 0, (int)(n + 32u), 0x00020000);
+#endif
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
         const uint32_t cc = c < numChunks ? c : numChunks - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
+#if PFAC_STREAM_AUX >= 0      /* experiment: streaming loads through a buffer resource with an explicit cache policy */
+#pragma unroll
+        for (int t = 0; t < kTilesPerIter; t++)
+            d[t] = __builtin_amdgcn_raw_buffer_load_b128(streamRsrc, (int)((q + t * 64 + lane) * 16u), 0, PFAC_STREAM_AUX);
+        halo = __builtin_amdgcn_raw_buffer_load_b32(streamRsrc, (int)((cc + 1) * (uint32_t)kChunkBytes), 0, PFAC_STREAM_AUX);
+#else
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
         halo = in32[(cc + 1) * (kChunkBytes / 4)];                                    /* first dword behind the chunk */
+#endif
     };
 
 #if PFAC_ABLATE == 1
@@ -661,7 +724,10 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     if (chunk < numChunks) loadChunk(chunk, d, halo);
 
     while (chunk < numChunks) {
-        /* ---- 1. start the next transition of every live walk (kWalkSets x 64 table steps) */
+        /* ---- 1. finish the transitions issued one iteration ago, hand idle walker lanes new positions
+         *         (first transition from LDS), start the next transition of every live walk */
+        walkConsume();
+        walkRefill();
         walkIssue();
 #if PFAC_STATS
         stIters++;
@@ -680,9 +746,6 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #pragma unroll
             for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
         }
-
-        /* ---- 4. finish the transitions issued in 1 (the one exposed wait of the iteration) */
-        walkConsume();
 
         /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position */
 #pragma unroll
@@ -730,9 +793,6 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         qh = qv;                                        /* timing experiment: drop the verified entries unwalked */
 #endif
 
-        /* ---- 7. give idle walker lanes new positions (first transition from LDS) */
-        walkRefill();
-
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = nd[t];
         halo = nhalo;
@@ -744,8 +804,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 
     /* drain: no more chunks to hide behind */
     if (qu != qv) verifyPending();
-    walkRefill();
-    while (anyAlive() || qh != qv) { walkIssue(); walkConsume(); walkRefill(); }
+    while (anyAlive() || qh != qv) { walkConsume(); walkRefill(); walkIssue(); }
     if (REDUCE) flushStaged();
 #if PFAC_STATS
     __syncthreads();

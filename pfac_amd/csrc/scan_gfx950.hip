@@ -3,8 +3,9 @@
  * CDNA4 (MI355X).  Hand-written HIP for gfx950 only.
  *
  * Replaces the reference's PFAC_kernel_timeDriven / PFAC_kernel_spaceDriven
- * (PFAC/src/PFAC_kernel.cu:377-458, PFAC/src/PFAC_kernel_spaceDriven.cu:465-558)
- * and their host wrappers (:90-244 / :149-348).  Result contract is identical:
+ * (PFAC/src/PFAC_kernel.cu:377-458, PFAC/src/PFAC_kernel_spaceDriven.cu:465-558),
+ * their host wrappers (:90-244 / :149-348) and the two compaction kernels
+ * (PFAC_reduce_kernel.cu, PFAC_reduce_inplace_kernel.cu).  Result contract is identical:
  * d_matched_result[j] = ID of the longest pattern starting at byte j, else 0,
  * every element written.
  *
@@ -12,47 +13,37 @@
  *
  *   The path is HBM-bound integer work: 1 B read + 4 B written per input byte.
  *   The reference walks the automaton from every byte; on MI355X that makes the
- *   per-CU texture-address pipe (one gathered table line per lane per step),
- *   not HBM, the limit.  Here the walk is split:
+ *   CU's address/L1 pipeline (one gathered table line per lane per step), not
+ *   HBM, the limit.  pfac_scan_filter splits the walk:
  *
- *   1. FILTER  (all lanes, LDS only).  A wave owns a 1 KiB tile.  Lane l loads
- *      dword k*64+l of the tile for k=0..3 (four fully coalesced 256 B loads),
- *      gets the following dword from lane l+1, and tests each of its 16 start
- *      positions against a 3-gram Bloom bitmap held in LDS (plus an exact
- *      2-gram bitmap when patterns shorter than 3 bytes exist).  A position
- *      that misses cannot match anything, so its result is 0.
- *   2. ZERO STORES.  The tile's 4 KiB of results are written as 16 B/lane
- *      non-temporal stores, 1 KiB contiguous per wave instruction, with no
- *      dependence on the input.
- *   3. WALK  (compacted).  Surviving positions (a few %) are compacted into a
- *      per-wave LDS queue with ballot/mbcnt; the queue accumulates over up to
- *      64 tiles and is drained by 64 walker lanes, one position per lane:
- *      first transition from the initial-state row in LDS, the rest from the
- *      dense or hashed table in global memory (plain loads or buffer-resource
- *      loads = the "texture" mode).  A lane whose walk hits the trap state
- *      immediately takes the next queue entry (ballot + mbcnt hand out the
- *      entries), so lanes stay busy although walk depths differ; one wave
- *      ballot ends the drain when every lane is dead and the queue is empty.
- *      Before a level-1 survivor is queued its first four bytes are tested
- *      against a 4-gram bitmap in LDS (second filter level, only executed by
- *      the few lanes that hold a hit); the queue keeps those four bytes, so a
- *      walker needs no input load for its first four transitions.
- *      The hashed mode walks a device-side "chained" copy of the reference's
- *      hash table (tables.cpp): every 32-byte slot also carries the row
- *      descriptor of its target state and the run of single-successor,
- *      non-final states behind it, so one dependent memory round trip
- *      consumes up to 12 input bytes (the reference needs two dependent loads
- *      per byte).
- *      Non-zero results are stored after the wave has drained its zero stores
- *      (s_waitcnt vmcnt(0)), so they land on top.
+ *   1. STREAM.  Persistent 1024-thread blocks; a wave owns 2 KiB chunks, grid-
+ *      strided.  16 B per lane per load (1 KiB contiguous per instruction), the
+ *      next chunk is prefetched; the chunk's 8 KiB of results are written as
+ *      non-temporal 16 B/lane zero stores that do not depend on the input.
+ *   2. FILTER, level 1 (every position, LDS only): a 3-gram Bloom bitmap, plus
+ *      an exact 2-gram bitmap when patterns shorter than 3 bytes exist.  A miss
+ *      proves the result is 0.
+ *   3. QUEUE.  Hits (with their first four bytes) are compacted into a per-wave
+ *      LDS ring with ballot/mbcnt; 64 at a time they are re-tested against a
+ *      4-gram bitmap (level 2).
+ *   4. WALK.  Each lane runs kWalkSets split-phase walkers over the survivors:
+ *      the loads of a step are issued at the top of an iteration and consumed at
+ *      the top of the next one, so a table round trip hides behind a whole chunk
+ *      of filter work.  Dense mode: one 4-byte gather per byte.  Hashed mode: a
+ *      device-only "chained" copy of the reference's hash table (tables.cpp),
+ *      16 bytes per slot, one gather per edge byte + up to 7 single-successor
+ *      bytes; slots are looked up in a per-wave LDS cache first and the input
+ *      window stays in registers, because gathered loads are what costs time
+ *      here.  "Texture" mode = buffer-resource loads.
+ *   5. PATCH.  Non-zero results overwrite the zero; the in-order vmcnt counter
+ *      of the wave orders the two stores.
  *
- *   Blocks are persistent (grid = CUs x resident blocks) and stride over tiles,
- *   so the LDS tables are filled once per block.  No MFMA: nothing here is a
- *   contraction.
- *
- * A second, deliberately simple kernel (one thread per byte, byte loads,
- * scalar stores) serves pointers the vector path cannot take (input not
- * 4-byte aligned, output not 16-byte aligned) and is the A/B baseline.
+ *   The kernel never checks a bound: the launcher gives it whole chunks that end
+ *   at least maxPatternLen + 32 bytes before the end of the input.  The rest --
+ *   and everything when a pointer is not 16-byte aligned -- goes to
+ *   pfac_scan_naive (one thread per byte, reference-layout tables), which is
+ *   also the independent second implementation the tests cross-check against.
+ *   No MFMA: nothing here is a contraction.
  */
 #include <hip/hip_runtime.h>
 
@@ -77,7 +68,7 @@ constexpr int kTrap = pfac::kTrapState;
 #define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
 #ifndef PFAC_QUEUE_CAP
-#define PFAC_QUEUE_CAP 512
+#define PFAC_QUEUE_CAP 256
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
@@ -184,6 +175,10 @@ template <> struct Lookup<HASH_BUFFER> {
 
 /* ------------------------------------------------------------------ walkers */
 
+#ifndef PFAC_SLOT_CACHE
+#define PFAC_SLOT_CACHE 128
+#endif
+constexpr uint32_t kSlotCacheEntries = PFAC_SLOT_CACHE;   /* per wave, hashed modes (16 B slot + 4 B tag each)   */
 constexpr uint32_t kQueueCap = PFAC_QUEUE_CAP;           /* ring entries per wave (power of two)                 */
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -213,6 +208,8 @@ struct Lds {
     const int *init;                           /* dense modes: transition row of the initial state   */
     const u32x4 *root;                         /* hashed modes: ChainSlot[256] of the initial state  */
     uint32_t shift3, shift4, shiftF3;
+    uint32_t *cacheTag;                        /* hashed modes: this wave's slot cache               */
+    u32x4 *cacheData;
 };
 
 /* 16 input bytes from the 4-byte aligned address at or below byte `pos`.  No bound: the launcher only
@@ -317,11 +314,13 @@ template <int MODE> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
     const u32x4 *sRoot;
+    uint32_t *cTag;                            /* this wave's slot cache (LDS): kSlotCacheEntries tags ... */
+    u32x4 *cData;                              /* ... and slots */
     const uint32_t *in32;
     __device__ ChainCtx(const ScanArgs &a, const Lds &lds)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
+          sRoot(lds.root), cTag(lds.cacheTag), cData(lds.cacheData), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
 };
 
 /* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
@@ -346,6 +345,10 @@ template <int MODE> struct ChainLane {
     u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
     uint32_t wpos = 0;
     bool haveWin = false, needWin = true, needSlot = true;
+    /* Slots are looked up in a small per-wave, direct-mapped LDS cache first: on text-like input a few
+     * dozen (state, byte) pairs -- including the probes that END a walk -- make up most lookups. */
+    uint32_t slotIdx = 0;
+    bool fill = false;                         /* the slot in flight came from memory: put it into the cache */
 
     /* input bytes q .. q+7 out of the window (q - wpos in 0..15; bytes beyond the window read as 0) */
     __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
@@ -414,10 +417,17 @@ template <int MODE> struct ChainLane {
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
+        fill = false;
         if (needSlot) {
-            const uint32_t idx = row + chainHashSlot(ks, b0);
-            if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
-            else t = c.slots[idx];
+            slotIdx = row + chainHashSlot(ks, b0);
+            const uint32_t ci = slotIdx & (kSlotCacheEntries - 1);
+            const uint32_t tag = c.cTag[ci];
+            t = c.cData[ci];
+            fill = tag != slotIdx;
+            if (fill) {
+                if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(slotIdx * 16u), 0, 0);
+                else t = c.slots[slotIdx];
+            }
         }
         if (needWin) {
             w = loadWindow16(c.in32, pos + depth + 1);         /* pos + depth = position of the edge byte b0 */
@@ -425,8 +435,19 @@ template <int MODE> struct ChainLane {
             haveWin = true;
         }
     }
-    __device__ __forceinline__ bool consume(const Ctx &)
+    __device__ __forceinline__ bool consume(const Ctx &c)
     {
+        if (fill) {
+            /* Lanes of this instruction may map different slots to one cache entry: the tag write
+             * elects one (a dword write is atomic, the last lane wins), and only lanes holding that
+             * slot write the data.  LDS operations of a wave execute in order and no other wave touches
+             * this cache, so a later lookup never sees a tag without its data. */
+            const uint32_t ci = slotIdx & (kSlotCacheEntries - 1);
+            c.cTag[ci] = slotIdx;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (c.cTag[ci] == slotIdx) c.cData[ci] = t;
+        }
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
         const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
@@ -452,18 +473,6 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 #endif
 #ifndef PFAC_STATS
 #define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
-#endif
-#ifndef PFAC_PAD_GATHER
-#define PFAC_PAD_GATHER 0     /* PFAC_PAD_*: sensitivity experiments (tools/ab.sh), results stay exact */
-#endif
-#ifndef PFAC_PAD_VALU
-#define PFAC_PAD_VALU 0
-#endif
-#ifndef PFAC_PAD_LDS
-#define PFAC_PAD_LDS 0
-#endif
-#ifndef PFAC_STREAM_AUX
-#define PFAC_STREAM_AUX (-1)
 #endif
 #ifndef PFAC_TILES_PER_ITER
 #define PFAC_TILES_PER_ITER 2
@@ -492,7 +501,9 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);
     uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
-    uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sCacheData = sQPosAll + kWavesPerBlock * kQueueCap;     /* hashed: per-wave slot cache, 16-byte aligned */
+    uint32_t *sCacheTag = sCacheData + (kHashed ? kWavesPerBlock * kSlotCacheEntries * 4 : 0);
+    uint32_t *sReduceAll = sCacheTag + (kHashed ? kWavesPerBlock * kSlotCacheEntries : 0);   /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -508,6 +519,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
         else copy16(sFirst, a.initialRow, pfac::kCharSet);
+        if (kHashed)
+            for (int i = tid; i < (int)(kWavesPerBlock * kSlotCacheEntries); i += kBlockThreads) sCacheTag[i] = 0xFFFFFFFFu;   /* no slot has this index */
     }
     __syncthreads();
 
@@ -520,7 +533,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
-                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
+                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3,
+                  sCacheTag + wave * kSlotCacheEntries, reinterpret_cast<u32x4 *>(sCacheData) + wave * kSlotCacheEntries};
     const WCtx wctx(a, lds);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 #if PFAC_STATS
-    uint32_t stIters = 0, stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0;
+    uint32_t stIters = 0, stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0, stSlotGathers = 0, stWinLoads = 0;
 #endif
 
     /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
@@ -631,7 +645,13 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #if PFAC_STATS
         stRounds++;
 #pragma unroll
-        for (int s = 0; s < kWalkSets; s++) stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
+        for (int s = 0; s < kWalkSets; s++) {
+            stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
+            if constexpr (kHashed) {
+                stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].fill));
+                stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
+            }
+        }
 #endif
     };
     auto walkConsume = [&]() {
@@ -697,22 +717,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     /* Every path of the loop issues the same vector-memory instructions (the prefetch past the last
      * chunk is clamped, not skipped), which keeps the compiler's wait counts exact. */
     const uint32_t numChunks = n / kChunkBytes;
-#if PFAC_STREAM_AUX >= 0
-    const __amdgpu_buffer_rsrc_t streamRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in), 0, (int)(n + 32u), 0x00020000);
-#endif
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
         const uint32_t cc = c < numChunks ? c : numChunks - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
-#if PFAC_STREAM_AUX >= 0      /* experiment: streaming loads through a buffer resource with an explicit cache policy */
-#pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++)
-            d[t] = __builtin_amdgcn_raw_buffer_load_b128(streamRsrc, (int)((q + t * 64 + lane) * 16u), 0, PFAC_STREAM_AUX);
-        halo = __builtin_amdgcn_raw_buffer_load_b32(streamRsrc, (int)((cc + 1) * (uint32_t)kChunkBytes), 0, PFAC_STREAM_AUX);
-#else
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
         halo = in32[(cc + 1) * (kChunkBytes / 4)];                                    /* first dword behind the chunk */
-#endif
     };
 
 #if PFAC_ABLATE == 1
@@ -814,11 +824,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         atomicAdd(&sGram3[0], stIters); atomicAdd(&sGram3[1], stRounds); atomicAdd(&sGram3[2], stFullRounds);
         atomicAdd(&sGram3[3], stLaneSteps); atomicAdd(&sGram3[4], stStarts); atomicAdd(&sGram3[5], stHits);
         atomicAdd(&sGram3[6], stVerified); atomicAdd(&sGram3[7], stStartDead);
+        atomicAdd(&sGram3[8], stSlotGathers); atomicAdd(&sGram3[9], stWinLoads);
     }
     __syncthreads();
     if (tid == 0 && (blockIdx.x % 32) == 0)
-        printf("STATS block %d iters %u rounds %u fullRounds %u laneSteps %u starts %u hits %u verified %u startDead %u\n", (int)blockIdx.x,
-               sGram3[0], sGram3[1], sGram3[2], sGram3[3], sGram3[4], sGram3[5], sGram3[6], sGram3[7]);
+        printf("STATS block %d iters %u rounds %u fullRounds %u laneSteps %u starts %u hits %u verified %u startDead %u slotGathers %u winLoads %u\n", (int)blockIdx.x,
+               sGram3[0], sGram3[1], sGram3[2], sGram3[3], sGram3[4], sGram3[5], sGram3[6], sGram3[7], sGram3[8], sGram3[9]);
 #endif
 }
 
@@ -860,6 +871,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
     bytes += (size_t)kWavesPerBlock * kQueueCap * 2 * sizeof(uint32_t);
+    if (c->perfMode == PFAC_SPACE_DRIVEN) bytes += (size_t)kWavesPerBlock * kSlotCacheEntries * (sizeof(pfac::ChainSlot) + sizeof(uint32_t));
     if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }

@@ -54,6 +54,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_shortBits);
     devFree(c->d_gram4);
     devFree(c->d_reduceCount);
+    devFree(c->d_workCounters);
     devFree(c->d_final3);
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();
@@ -136,6 +137,10 @@ PFAC_status_t bindCommon(PFAC_context *c)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
     const unsigned int zero = 0;
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_reduceCount, &zero, 1);
+    if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
+        const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
+        st = upload(c->d_workCounters, zeros.data(), zeros.size());
+    }
     return st;
 }
 

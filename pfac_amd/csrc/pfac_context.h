@@ -29,6 +29,11 @@ constexpr size_t kTexMaxEntries = size_t(1) << 27;   /* ref MAXIMUM_WIDTH_1DTEX,
 constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 */
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
+#ifndef PFAC_WORK_PARTS
+#define PFAC_WORK_PARTS 32
+#endif
+constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
+constexpr int kWorkCounterWords = 64 * 32;   /* one counter per 128-byte line */
 constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
 /* 16-byte device slot of the chained hashed table: one gathered 16-byte load per transition.
  * meta = edge byte | chain length << 8 | flags | k << 15 | (S-1) << 24, where {k, S} are the hash
@@ -123,6 +128,7 @@ struct PFAC_context {
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_gram4 = nullptr;
     unsigned int *d_reduceCount = nullptr;    /* device counter of the compacted-output path */
+    unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
     uint32_t *d_final3 = nullptr;
 
     /* ref numOfTableEntry / sizeOfTableEntry / sizeOfTableInBytes, PFAC_P.h:131-133 */

@@ -99,6 +99,7 @@ struct ScanArgs {
     int log2Bits, log2Bits4, log2BitsF3;
     int numFinal;
     int initialState;
+    unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
     /* compacted output (PFAC_matchFromDeviceReduce): unordered append, sorted by position afterwards */
     int *reducePos;
     unsigned int *reduceCount;
@@ -540,9 +541,6 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     bool alive[kWalkSets];
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) alive[s] = false;
-    const uint32_t totalWaves = gridDim.x * kWavesPerBlock;
-    const uint32_t firstChunk = blockIdx.x * kWavesPerBlock + wave;
-
     /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
      *   [qh, qv)  passed both filter levels, waiting for a walker lane
      *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
@@ -714,11 +712,29 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         }
     };
 
-    /* Every path of the loop issues the same vector-memory instructions (the prefetch past the last
-     * chunk is clamped, not skipped), which keeps the compiler's wait counts exact. */
+    /* Chunks are handed out dynamically and IN ORDER: the input is cut into (up to) kWorkParts parts,
+     * block b serves part b % parts, and a wave takes the next chunk of its part from a device counter.
+     * All waves of a part therefore work inside a window of a few hundred KiB that moves linearly
+     * through memory -- what the hardware does for a grid of small blocks, and worth ~10 % of HBM
+     * throughput over a static grid-stride assignment (profiles/r01_stream_probe2_ordering.txt); it
+     * also balances the load.  (Workgroups are dealt round-robin to the 8 XCDs, so the blocks that
+     * share a counter share an L2.)  The counter value for the chunk after next is requested while
+     * the current chunk is processed.
+     * Every path of the loop issues the same vector-memory instructions (the prefetch past the end of
+     * the part is clamped, not skipped), which keeps the compiler's wait counts exact. */
     const uint32_t numChunks = n / kChunkBytes;
+    const uint32_t parts = gridDim.x < (uint32_t)pfac::kWorkParts ? gridDim.x : (uint32_t)pfac::kWorkParts;
+    const uint32_t part = blockIdx.x % parts;
+    const uint32_t partBegin = (uint32_t)((uint64_t)numChunks * part / parts);
+    const uint32_t partEnd = (uint32_t)((uint64_t)numChunks * (part + 1) / parts);
+    unsigned int *const counter = a.work + part * 32;
+    auto grab = [&]() {                                    /* lane 0 holds the answer */
+        unsigned int v = 0;
+        if (lane == 0) v = atomicAdd(counter, 1u);
+        return v;
+    };
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
-        const uint32_t cc = c < numChunks ? c : numChunks - 1;
+        const uint32_t cc = c < partEnd ? c : partEnd - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
@@ -728,12 +744,13 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #if PFAC_ABLATE == 1
     uint32_t ablateSink = 0;
 #endif
-    uint32_t chunk = firstChunk;
+    uint32_t chunk = partBegin + uni(grab());
+    uint32_t next = partBegin + uni(grab());
     u32x4 d[kTilesPerIter];
     uint32_t halo = 0;
-    if (chunk < numChunks) loadChunk(chunk, d, halo);
+    if (chunk < partEnd) loadChunk(chunk, d, halo);
 
-    while (chunk < numChunks) {
+    while (chunk < partEnd) {
         /* ---- 1. finish the transitions issued one iteration ago, hand idle walker lanes new positions
          *         (first transition from LDS), start the next transition of every live walk */
         walkConsume();
@@ -743,11 +760,11 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         stIters++;
 #endif
 
-        /* ---- 2. prefetch the next chunk of this wave */
-        const uint32_t nextChunk = chunk + totalWaves;
+        /* ---- 2. ask for the chunk after next, prefetch the next one */
+        const unsigned int afterNext = grab();
         u32x4 nd[kTilesPerIter];
         uint32_t nhalo;
-        loadChunk(nextChunk, nd, nhalo);
+        loadChunk(next, nd, nhalo);
 
         /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
         if (!REDUCE) {
@@ -806,7 +823,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = nd[t];
         halo = nhalo;
-        chunk = nextChunk;
+        chunk = next;
+        next = partBegin + uni(afterNext);
     }
 #if PFAC_ABLATE == 1
     if (ablateSink == 0x12345u) a.out[0] = 1;
@@ -892,6 +910,8 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     size_t blocks = (numChunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
+    e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     return hipGetLastError();
 }
@@ -924,7 +944,7 @@ uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu 
 PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_string, size_t input_size,
                        int *d_matched_result, ScanArgs &a)
 {
-    if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits) return PFAC_STATUS_INTERNAL_ERROR;
+    if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
     if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_chainSlots || !c->d_rootSlots) : !c->d_dense)
         return PFAC_STATUS_INTERNAL_ERROR;
     a = ScanArgs{};
@@ -949,6 +969,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.log2Bits4 = c->filter.log2Bits4;
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
+    a.work = c->d_workCounters;
     a.initialState = c->fa.initialState;
     /* the buffer-resource ("texture") path addresses the table with 32-bit byte offsets; the
      * reference fails the texture bind for an oversized table the same way (PFAC_kernel.cu:139-142) */

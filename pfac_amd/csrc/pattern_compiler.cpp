@@ -228,7 +228,7 @@ void buildFilter(const Automaton &fa, Filter &f)
         }
     }
     f.log2Bits = sizeLog2(depth3, 13, 18);
-    f.log2Bits4 = sizeLog2(depth4, 13, 17);
+    f.log2Bits4 = sizeLog2(depth4, 13, 18);
     f.log2BitsF3 = sizeLog2(len3, 10, 16);
     f.gram3.assign((size_t(1) << f.log2Bits) / 32, 0);
     f.gram4.assign((size_t(1) << f.log2Bits4) / 32, 0);

@@ -68,7 +68,7 @@ constexpr int kTrap = pfac::kTrapState;
 #define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
 #ifndef PFAC_QUEUE_CAP
-#define PFAC_QUEUE_CAP 256
+#define PFAC_QUEUE_CAP 512
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
@@ -176,10 +176,6 @@ template <> struct Lookup<HASH_BUFFER> {
 
 /* ------------------------------------------------------------------ walkers */
 
-#ifndef PFAC_SLOT_CACHE
-#define PFAC_SLOT_CACHE 128
-#endif
-constexpr uint32_t kSlotCacheEntries = PFAC_SLOT_CACHE;   /* per wave, hashed modes (16 B slot + 4 B tag each)   */
 constexpr uint32_t kQueueCap = PFAC_QUEUE_CAP;           /* ring entries per wave (power of two)                 */
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -209,8 +205,6 @@ struct Lds {
     const int *init;                           /* dense modes: transition row of the initial state   */
     const u32x4 *root;                         /* hashed modes: ChainSlot[256] of the initial state  */
     uint32_t shift3, shift4, shiftF3;
-    uint32_t *cacheTag;                        /* hashed modes: this wave's slot cache               */
-    u32x4 *cacheData;
 };
 
 /* 16 input bytes from the 4-byte aligned address at or below byte `pos`.  No bound: the launcher only
@@ -315,13 +309,11 @@ template <int MODE> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
     const u32x4 *sRoot;
-    uint32_t *cTag;                            /* this wave's slot cache (LDS): kSlotCacheEntries tags ... */
-    u32x4 *cData;                              /* ... and slots */
     const uint32_t *in32;
     __device__ ChainCtx(const ScanArgs &a, const Lds &lds)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), cTag(lds.cacheTag), cData(lds.cacheData), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
+          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
 };
 
 /* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
@@ -346,10 +338,7 @@ template <int MODE> struct ChainLane {
     u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
     uint32_t wpos = 0;
     bool haveWin = false, needWin = true, needSlot = true;
-    /* Slots are looked up in a small per-wave, direct-mapped LDS cache first: on text-like input a few
-     * dozen (state, byte) pairs -- including the probes that END a walk -- make up most lookups. */
-    uint32_t slotIdx = 0;
-    bool fill = false;                         /* the slot in flight came from memory: put it into the cache */
+    bool eager = false;                        /* this walk outran its window once: from now on fetch a window every step */
 
     /* input bytes q .. q+7 out of the window (q - wpos in 0..15; bytes beyond the window read as 0) */
     __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
@@ -390,7 +379,7 @@ template <int MODE> struct ChainLane {
     __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
     {
         pos = p; match = 0; depth = 0; b0 = x & 0xFF;
-        haveWin = false; needWin = true; needSlot = true;
+        haveWin = false; needWin = true; needSlot = true; eager = false;
         const u32x4 r = c.sRoot[b0];
         const uint32_t len = (r.x >> 8) & 0xFu;
         const bool present = (r.x & pfac::kSlotEmpty) == 0;
@@ -418,17 +407,10 @@ template <int MODE> struct ChainLane {
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
-        fill = false;
         if (needSlot) {
-            slotIdx = row + chainHashSlot(ks, b0);
-            const uint32_t ci = slotIdx & (kSlotCacheEntries - 1);
-            const uint32_t tag = c.cTag[ci];
-            t = c.cData[ci];
-            fill = tag != slotIdx;
-            if (fill) {
-                if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(slotIdx * 16u), 0, 0);
-                else t = c.slots[slotIdx];
-            }
+            const uint32_t idx = row + chainHashSlot(ks, b0);
+            if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+            else t = c.slots[idx];
         }
         if (needWin) {
             w = loadWindow16(c.in32, pos + depth + 1);         /* pos + depth = position of the edge byte b0 */
@@ -436,29 +418,20 @@ template <int MODE> struct ChainLane {
             haveWin = true;
         }
     }
-    __device__ __forceinline__ bool consume(const Ctx &c)
+    __device__ __forceinline__ bool consume(const Ctx &)
     {
-        if (fill) {
-            /* Lanes of this instruction may map different slots to one cache entry: the tag write
-             * elects one (a dword write is atomic, the last lane wins), and only lanes holding that
-             * slot write the data.  LDS operations of a wave execute in order and no other wave touches
-             * this cache, so a later lookup never sees a tag without its data. */
-            const uint32_t ci = slotIdx & (kSlotCacheEntries - 1);
-            c.cTag[ci] = slotIdx;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (c.cTag[ci] == slotIdx) c.cData[ci] = t;
-        }
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
         const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
         const bool covered = haveWin & (q - wpos + len + 1u <= 16u);
         needWin = mine & !covered;                             /* matching slot, bytes missing: fetch them and come back */
         needSlot = !needWin;
+        eager |= needWin;
         uint32_t x0, x1;
         windowBytes(q, x0, x1);
         bool cont = true;
         if (!needWin) cont = advance(t, x0, x1);
+        needWin |= eager;                                      /* long walks (adversarial input): no more retry rounds */
         return cont;
     }
 };
@@ -502,9 +475,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);
     uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
-    uint32_t *sCacheData = sQPosAll + kWavesPerBlock * kQueueCap;     /* hashed: per-wave slot cache, 16-byte aligned */
-    uint32_t *sCacheTag = sCacheData + (kHashed ? kWavesPerBlock * kSlotCacheEntries * 4 : 0);
-    uint32_t *sReduceAll = sCacheTag + (kHashed ? kWavesPerBlock * kSlotCacheEntries : 0);   /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -520,8 +491,6 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
         else copy16(sFirst, a.initialRow, pfac::kCharSet);
-        if (kHashed)
-            for (int i = tid; i < (int)(kWavesPerBlock * kSlotCacheEntries); i += kBlockThreads) sCacheTag[i] = 0xFFFFFFFFu;   /* no slot has this index */
     }
     __syncthreads();
 
@@ -534,8 +503,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
                   reinterpret_cast<const u32x4 *>(sFirst),
-                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3,
-                  sCacheTag + wave * kSlotCacheEntries, reinterpret_cast<u32x4 *>(sCacheData) + wave * kSlotCacheEntries};
+                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
     const WCtx wctx(a, lds);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
@@ -646,7 +614,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         for (int s = 0; s < kWalkSets; s++) {
             stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
             if constexpr (kHashed) {
-                stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].fill));
+                stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needSlot));
                 stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
             }
         }
@@ -889,7 +857,6 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
     bytes += (size_t)kWavesPerBlock * kQueueCap * 2 * sizeof(uint32_t);
-    if (c->perfMode == PFAC_SPACE_DRIVEN) bytes += (size_t)kWavesPerBlock * kSlotCacheEntries * (sizeof(pfac::ChainSlot) + sizeof(uint32_t));
     if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }

@@ -108,8 +108,11 @@ def committed_traffic(workload, kernel_substr):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if kernel_substr in k]
-        w = [v for k, v in d["WRITE_SIZE"]["scan"].items() if kernel_substr in k]
+        # pfac_scan_filter<MODE, HAS_SHORT, REDUCE>: the full-result kernel is the REDUCE = false instance
+        def mine(k):
+            return kernel_substr in k and not k.rstrip(">( ").endswith("true")
+        f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if mine(k)]
+        w = [v for k, v in d["WRITE_SIZE"]["scan"].items() if mine(k)]
         if not f or not w:
             return None, None
         return int((2.0 * f[0] + w[0]) * 1024), os.path.relpath(files[-1], ROOT)

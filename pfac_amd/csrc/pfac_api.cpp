@@ -55,6 +55,8 @@ void freeResources(PFAC_context *c)
     devFree(c->d_gram4);
     devFree(c->d_reduceCount);
     devFree(c->d_workCounters);
+    devFree(c->d_reduceScratch);
+    c->reduceScratchBytes = 0;
     devFree(c->d_final3);
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();

@@ -128,6 +128,10 @@ struct PFAC_context {
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_gram4 = nullptr;
     unsigned int *d_reduceCount = nullptr;    /* device counter of the compacted-output path */
+    /* grow-only scratch of the compacted-output path (sort buffers), owned by the handle so that a
+     * call does not pay for hipMalloc/hipFree */
+    void *d_reduceScratch = nullptr;
+    size_t reduceScratchBytes = 0;
     unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
     uint32_t *d_final3 = nullptr;
 

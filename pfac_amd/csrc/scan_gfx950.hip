@@ -1040,27 +1040,32 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (count > 1) {                                   /* order by position */
-            unsigned int *keysOut = nullptr;
-            int *valuesOut = nullptr;
-            void *temp = nullptr;
             size_t tempBytes = 0;
             unsigned int *keysIn = reinterpret_cast<unsigned int *>(d_pos);
-            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0) != hipSuccess)
+            unsigned int *nullKeys = nullptr;
+            int *nullVals = nullptr;
+            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, 32, 0) != hipSuccess)
                 return PFAC_STATUS_INTERNAL_ERROR;
-            const bool ok = hipMalloc(reinterpret_cast<void **>(&keysOut), count * sizeof(unsigned int)) == hipSuccess &&
-                            hipMalloc(reinterpret_cast<void **>(&valuesOut), count * sizeof(int)) == hipSuccess &&
-                            hipMalloc(&temp, tempBytes ? tempBytes : 4) == hipSuccess;
-            hipError_t se = hipErrorOutOfMemory;
-            if (ok) {
-                se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0);
-                if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
-                if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
-                if (se == hipSuccess) se = hipStreamSynchronize(0);
+            /* scratch = sorted keys | sorted values | rocPRIM workspace, each 256-byte aligned */
+            const size_t arrayBytes = ((size_t)count * sizeof(int) + 255) / 256 * 256;
+            const size_t need = 2 * arrayBytes + (tempBytes ? tempBytes : 4);
+            PFAC_context *mc = handle;
+            if (mc->reduceScratchBytes < need) {
+                if (mc->d_reduceScratch) (void)hipFree(mc->d_reduceScratch);
+                mc->d_reduceScratch = nullptr;
+                mc->reduceScratchBytes = 0;
+                const size_t grow = need + need / 2;
+                if (hipMalloc(&mc->d_reduceScratch, grow) != hipSuccess) { (void)hipGetLastError(); mc->d_reduceScratch = nullptr; return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+                mc->reduceScratchBytes = grow;
             }
-            if (keysOut) (void)hipFree(keysOut);
-            if (valuesOut) (void)hipFree(valuesOut);
-            if (temp) (void)hipFree(temp);
-            if (!ok) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+            char *base = static_cast<char *>(mc->d_reduceScratch);
+            unsigned int *keysOut = reinterpret_cast<unsigned int *>(base);
+            int *valuesOut = reinterpret_cast<int *>(base + arrayBytes);
+            void *temp = base + 2 * arrayBytes;
+            hipError_t se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0);
+            if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
+            if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
+            if (se == hipSuccess) se = hipStreamSynchronize(0);
             if (se != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         }
     }

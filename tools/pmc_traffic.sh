@@ -22,7 +22,7 @@ res = {"workload": w, "unit": "counter KB (1 KB = 1024 B) per launch"}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     scan = mean_by_kernel(glob.glob(f"{out}/scan_{c}/*counter_collection.csv")[0])
     probe = mean_by_kernel(glob.glob(f"{out}/probe_{c}/*counter_collection.csv")[0])
-    res[c] = {"scan": {k[:60]: v for k, v in scan.items() if "pfac_scan" in k},
+    res[c] = {"scan": {k.split("(")[0] + ("(" + k.split("(")[1] if k.startswith("void (") else ""): v for k, v in scan.items() if "pfac_scan" in k},
               "probe": {k[:60]: v for k, v in probe.items()}}
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -68,7 +68,7 @@ constexpr int kTrap = pfac::kTrapState;
 #define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
 #ifndef PFAC_QUEUE_CAP
-#define PFAC_QUEUE_CAP 512
+#define PFAC_QUEUE_CAP 256
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
@@ -261,12 +261,13 @@ template <int MODE> struct DenseLane {
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
+    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &entry)
     {
-        pos = p; refilling = false;
-        state = c.sInit[x & 0xFF];
+        pos = entry.x; refilling = false;
+        state = c.sInit[entry.y & 0xFF];
         match = (uint32_t)(state - 1) < c.numFinal ? state : 0;       /* final states are 1..F; trap is -1 */
-        win = x >> 8; have = 3; depth = 1;
+        win = ((uint64_t)__builtin_amdgcn_alignbyte(entry.w, entry.z, 1) << 32) | __builtin_amdgcn_alignbyte(entry.z, entry.y, 1);
+        have = 8; depth = 1;                                           /* bytes pos+1 .. pos+8 came with the queue entry */
         return state != kTrap;
     }
     __device__ __forceinline__ void issue(const Ctx &c)
@@ -336,9 +337,9 @@ template <int MODE> struct ChainLane {
      * the kernel on pattern-dense input (each costs as much as ~60 ALU instructions, tools/ab.sh
      * sensitivity runs), and the step that ends a walk -- a slot for some other byte -- needs none. */
     u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
-    uint32_t wpos = 0;
-    bool haveWin = false, needWin = true, needSlot = true;
-    bool eager = false;                        /* this walk outran its window once: from now on fetch a window every step */
+    uint32_t wpos = 0, wend = 0;               /* the window holds input bytes [wpos, wend) */
+    bool needWin = false, needSlot = true;
+    uint32_t refetches = 0;                    /* a walk that outran its window twice fetches one every step from then on */
 
     /* input bytes q .. q+7 out of the window (q - wpos in 0..15; bytes beyond the window read as 0) */
     __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
@@ -372,38 +373,16 @@ template <int MODE> struct ChainLane {
         return ok & !leaf;
     }
 
-    /* The slots of the initial state live in LDS, so the first transition is taken right here.  If
-     * its chain fits into the four bytes that came with the queue entry (chain length <= 2, the
-     * common case) no memory is touched; a longer root chain fetches its window synchronously.
-     * Returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, uint32_t p, uint32_t x)
+    /* The slots of the initial state live in LDS and the queue entry brings input bytes pos..pos+11,
+     * so the first transition is taken right here without touching memory; those twelve bytes are
+     * also the walk's first window.  Returns false if the walk is already over. */
+    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &entry)
     {
-        pos = p; match = 0; depth = 0; b0 = x & 0xFF;
-        haveWin = false; needWin = true; needSlot = true; eager = false;
-        const u32x4 r = c.sRoot[b0];
-        const uint32_t len = (r.x >> 8) & 0xFu;
-        const bool present = (r.x & pfac::kSlotEmpty) == 0;
-        bool cont;
-        if (__builtin_expect(__ballot(present & (len > 2)) != 0, 0)) {        /* wave-uniform; rare with real pattern sets */
-            cont = false;
-            if (present) {
-                w = loadWindow16(c.in32, p + 1);
-                wpos = (p + 1) & ~3u;
-                uint32_t x0, x1;
-                windowBytes(p + 1, x0, x1);
-                cont = advance(r, x0, x1);
-            }
-        } else {
-            const bool ok = present & ((len == 0) | ((((x >> 8) ^ r.z) << (32u - 8u * len)) == 0));
-            const bool leaf = (r.x & pfac::kSlotLeaf) != 0;
-            match = (ok & ((r.x & pfac::kSlotFinal) != 0)) ? (int)(leaf ? r.y : r.w) : 0;
-            row = r.y;
-            ks = r.x >> 15;
-            depth = 1 + len;
-            b0 = (x >> (8 * depth)) & 0xFFu;
-            cont = ok & !leaf;
-        }
-        return cont;
+        pos = entry.x; match = 0; depth = 0; b0 = entry.y & 0xFF;
+        w = u32x4{entry.y, entry.z, entry.w, 0u};
+        wpos = pos; wend = pos + 12u;
+        needWin = false; needSlot = true; refetches = 0;
+        return advance(c.sRoot[b0], __builtin_amdgcn_alignbyte(entry.z, entry.y, 1), __builtin_amdgcn_alignbyte(entry.w, entry.z, 1));
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
@@ -415,7 +394,7 @@ template <int MODE> struct ChainLane {
         if (needWin) {
             w = loadWindow16(c.in32, pos + depth + 1);         /* pos + depth = position of the edge byte b0 */
             wpos = (pos + depth + 1) & ~3u;
-            haveWin = true;
+            wend = wpos + 16u;
         }
     }
     __device__ __forceinline__ bool consume(const Ctx &)
@@ -423,15 +402,15 @@ template <int MODE> struct ChainLane {
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
         const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
-        const bool covered = haveWin & (q - wpos + len + 1u <= 16u);
+        const bool covered = q + len + 1u <= wend;
         needWin = mine & !covered;                             /* matching slot, bytes missing: fetch them and come back */
         needSlot = !needWin;
-        eager |= needWin;
+        refetches += needWin ? 1u : 0u;
         uint32_t x0, x1;
         windowBytes(q, x0, x1);
         bool cont = true;
         if (!needWin) cont = advance(t, x0, x1);
-        needWin |= eager;                                      /* long walks (adversarial input): no more retry rounds */
+        needWin |= refetches >= 2u;                            /* long walks (adversarial input): no more retry rounds */
         return cont;
     }
 };
@@ -473,9 +452,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sFinal3 = sGram4 + words4;
     uint32_t *sShort = sFinal3 + wordsF3;
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
-    uint32_t *sQBytesAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);
-    uint32_t *sQPosAll = sQBytesAll + kWavesPerBlock * kQueueCap;
-    uint32_t *sReduceAll = sQPosAll + kWavesPerBlock * kQueueCap;     /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sQueueAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);   /* 16-byte aligned */
+    uint32_t *sReduceAll = sQueueAll + kWavesPerBlock * kQueueCap * 4;   /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -496,9 +474,9 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform by construction: keep it (and what derives from it) scalar */
-    uint32_t *qBytes = sQBytesAll + wave * kQueueCap;   /* ring: first four input bytes of the position   */
-    uint32_t *qPos = sQPosAll + wave * kQueueCap;       /* ring: byte position in the input (32-bit)      */
-    const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in);
+    /* ring of {byte position (32-bit), input bytes pos..pos+11}: the twelve bytes carry most walks to
+     * their end without a single input load (gathered loads are the scarce resource) */
+    u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQueueCap;
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
@@ -529,18 +507,19 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         for (uint32_t r = qv; r != qu; r = uni(r + (qu - r < 64 ? qu - r : 64))) {
             const uint32_t idx = r + lane;
             const bool act = (uint32_t)lane < qu - r;
-            const uint32_t x = act ? qBytes[idx & kMask] : 0u;
-            const uint32_t e = act ? qPos[idx & kMask] : 0u;
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (act) e = queue[idx & kMask];
+            const uint32_t x = e.y;
             uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
             pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
             if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
 #if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
-            pass = (((e * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
+            pass = (((e.x * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
 #endif
             const bool keep = act && pass != 0;
             const uint64_t keepMask = __ballot(keep);
             const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
-            if (keep) { qPos[at & kMask] = e; qBytes[at & kMask] = x; }
+            if (keep) queue[at & kMask] = e;
             w = uni(w + (uint32_t)__popcll(keepMask));
         }
 #if PFAC_STATS
@@ -640,7 +619,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);
                 bool cont = false;
-                if (take) cont = walk[s].start(wctx, qPos[(qh + rank) & kMask], qBytes[(qh + rank) & kMask]);
+                if (take) cont = walk[s].start(wctx, queue[(qh + rank) & kMask]);
                 report(take & !cont, walk[s], s, false);
                 alive[s] = alive[s] | cont;
                 const uint32_t taken = (uint32_t)__popcll(idle);
@@ -659,7 +638,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         for (int s = 0; s < kWalkSets; s++) any |= alive[s];
         return __ballot(any) != 0;
     };
-    auto appendHit = [&](uint32_t position, uint32_t x, bool has) {
+    auto appendHit = [&](const u32x4 &entry, bool has) {
         if (qu - qh + 64 > kQueueCap) {
             verifyPending();
             while (qu - qh + 64 > kQueueCap) {   /* full: walk until there is room (walks are in flight here) */
@@ -672,7 +651,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         const uint64_t m = __ballot(has);
         if (m) {
             const uint32_t at = (qu + laneRankIn(m)) & kMask;
-            if (has) { qPos[at] = position; qBytes[at] = x; }
+            if (has) queue[at] = entry;
             qu = uni(qu + (uint32_t)__popcll(m));
 #if PFAC_STATS
             stHits += (uint32_t)__popcll(m);
@@ -701,12 +680,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         if (lane == 0) v = atomicAdd(counter, 1u);
         return v;
     };
-    auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], uint32_t &halo) {
+    auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], u32x4 &halo) {
         const uint32_t cc = c < partEnd ? c : partEnd - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
-        halo = in32[(cc + 1) * (kChunkBytes / 4)];                                    /* first dword behind the chunk */
+        halo = in128[(cc + 1) * (kChunkBytes / 16)];                                  /* the 16 bytes behind the chunk */
     };
 
 #if PFAC_ABLATE == 1
@@ -715,7 +694,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t chunk = partBegin + uni(grab());
     uint32_t next = partBegin + uni(grab());
     u32x4 d[kTilesPerIter];
-    uint32_t halo = 0;
+    u32x4 halo = {0, 0, 0, 0};
     if (chunk < partEnd) loadChunk(chunk, d, halo);
 
     while (chunk < partEnd) {
@@ -731,7 +710,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         /* ---- 2. ask for the chunk after next, prefetch the next one */
         const unsigned int afterNext = grab();
         u32x4 nd[kTilesPerIter];
-        uint32_t nhalo;
+        u32x4 nhalo;
         loadChunk(next, nd, nhalo);
 
         /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
@@ -745,10 +724,20 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position */
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) {
-            const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
-            uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
-            const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d[(t + 1) % kTilesPerIter].x) : halo;
-            if (lane == 63) nxtLane = wrap;
+            /* D[0..3] = this lane's 16 bytes, D[4..6] = the 12 bytes behind them (next lane / next tile / halo) */
+            const u32x4 behind = (t + 1 < kTilesPerIter) ? d[(t + 1) % kTilesPerIter] : halo;     /* lane 0's copy is what lane 63 needs */
+            uint32_t D[7] = {d[t].x, d[t].y, d[t].z, d[t].w, 0u, 0u, 0u};
+            {
+                const uint32_t srcs[3] = {d[t].x, d[t].y, d[t].z}, wraps[3] = {behind.x, behind.y, behind.z};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t fromNext = (uint32_t)__shfl_down((int)srcs[k], 1);
+                    const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wraps[k]) : wraps[k];
+                    D[4 + k] = lane == 63 ? wrap : fromNext;
+                }
+            }
+            const uint32_t *dw = D;
+            const uint32_t nxtLane = D[4];
             uint32_t hits = 0;
 #pragma unroll
             for (int half = 0; half < 2; half++) {          /* 8 positions at a time: 8 LDS reads in flight */
@@ -775,10 +764,15 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             while (pending) {                               /* wave-uniform: max hits per lane iterations */
                 const bool has = hits != 0;
                 const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
-                const uint32_t j = b >> 2;
-                const uint32_t lo = j == 0 ? dw[0] : j == 1 ? dw[1] : j == 2 ? dw[2] : dw[3];
-                const uint32_t hi = j == 0 ? dw[1] : j == 1 ? dw[2] : j == 2 ? dw[3] : nxtLane;
-                appendHit(chunk * kChunkBytes + (uint32_t)(t * kTileBytes + (lane << 4)) + b, __builtin_amdgcn_alignbyte(hi, lo, b & 3), has);
+                const uint32_t j = b >> 2, sh = b & 3u;
+                const uint32_t e0 = j == 0 ? D[0] : j == 1 ? D[1] : j == 2 ? D[2] : D[3];
+                const uint32_t e1 = j == 0 ? D[1] : j == 1 ? D[2] : j == 2 ? D[3] : D[4];
+                const uint32_t e2 = j == 0 ? D[2] : j == 1 ? D[3] : j == 2 ? D[4] : D[5];
+                const uint32_t e3 = j == 0 ? D[3] : j == 1 ? D[4] : j == 2 ? D[5] : D[6];
+                const u32x4 entry = {chunk * kChunkBytes + (uint32_t)(t * kTileBytes + (lane << 4)) + b,
+                                     __builtin_amdgcn_alignbyte(e1, e0, sh), __builtin_amdgcn_alignbyte(e2, e1, sh),
+                                     __builtin_amdgcn_alignbyte(e3, e2, sh)};
+                appendHit(entry, has);
                 if (has) hits &= hits - 1;
                 pending = __ballot(hits != 0);
             }
@@ -856,7 +850,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * kQueueCap * 2 * sizeof(uint32_t);
+    bytes += (size_t)kWavesPerBlock * kQueueCap * 4 * sizeof(uint32_t);
     if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }

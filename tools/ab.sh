@@ -1,16 +1,34 @@
 #!/bin/bash
 # tools/ab.sh <variant.so> ...  -- bench pre-built kernel modules against each other on the GPU box.
 # Variants are built here (hipcc cross-compiles) into variants/<name>.so; the script swaps each one in
-# as pfac_amd/lib/libpfac_gfx950.so and prints one compact line per workload.
-WL=${WL:-"c3 c2"}
-for so in "$@"; do
-  cp "$so" pfac_amd/lib/libpfac_gfx950.so
-  for w in $WL; do
-    extra=""
-    case $w in c5h) w=c5; extra="--perf-mode hash";; esac
-    python bench.py --steps ${STEPS:-20} --warmup 3 --workload $w $extra --no-cpu-baseline $EXTRA 2>/dev/null | python -c "
+# as pfac_amd/lib/libpfac_gfx950.so (and variants/libpfac_<name>.so as the host library, if present) and
+# prints one line per workload: min / median kernel ms over REPEAT processes (run-to-run spread of one
+# build is +-5 % on this pool, so single runs cannot rank variants).
+WL=${WL:-"c3 c2"}; REPEAT=${REPEAT:-3}
+for r in $(seq $REPEAT); do
+  for so in "$@"; do
+    name=$(basename $so .so)
+    [ "$so" -ef pfac_amd/lib/libpfac_gfx950.so ] || cp "$so" pfac_amd/lib/libpfac_gfx950.so
+    [ -f variants/libpfac_$name.so ] && cp variants/libpfac_$name.so pfac_amd/lib/libpfac.so
+    for w in $WL; do
+      extra=""; ww=$w
+      case $w in c5h) ww=c5; extra="--perf-mode hash";; esac
+      python bench.py --steps ${STEPS:-20} --warmup 3 --workload $ww $extra --no-cpu-baseline $EXTRA 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$(basename $so .so)', d['config']['workload'][:24], d['value'], 'GB/s', r['kernel_ms_avg'], 'ms frac', round(r['frac'],3), 'exact', d['config']['bit_exact'], 'reduce', d.get('reduce_api',{}).get('value'))"
+print('$name', '$w', r['kernel_ms_avg'], d['config']['bit_exact'], (d.get('reduce_api') or {}).get('ms_per_call'))" >> /tmp/ab_raw.txt
+    done
   done
 done
+python - <<'PY'
+import collections, statistics
+rows = collections.OrderedDict()
+for l in open('/tmp/ab_raw.txt'):
+    n, w, ms, ok, red = l.split()
+    rows.setdefault((n, w), []).append((float(ms), ok, None if red == 'None' else float(red)))
+for (n, w), v in rows.items():
+    ms = [x[0] for x in v]; red = [x[2] for x in v if x[2] is not None]
+    print('%-14s %-4s kernel ms min %.4f median %.4f max %.4f  (n=%d) exact %s  reduce ms min %s' % (
+        n, w, min(ms), statistics.median(ms), max(ms), len(ms), all(x[1] == 'True' for x in v), ('%.3f' % min(red)) if red else '-'))
+PY
+rm -f /tmp/ab_raw.txt

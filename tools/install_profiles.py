@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""tools/install_profiles.py <gpurun_out subdir> <round tag>  -- copy what tools/measure_round.sh
+collected on the GPU box into profiles/ under the names DESIGN.md and bench.py refer to."""
+import csv, json, os, shutil, sys
+src, tag = os.path.join("gpurun_out", sys.argv[1]), sys.argv[2]
+def cp(a, b):
+    shutil.copy(os.path.join(src, a), os.path.join("profiles", f"{tag}_{b}"))
+for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json", "bench_c2.json"),
+             ("bench_c5_dense.json", "bench_c5_dense.json"), ("bench_c5_hashed.json", "bench_c5_hashed.json"),
+             ("bench_c3_naive.json", "bench_c3_naive_kernel.json"), ("bench_c2_naive.json", "bench_c2_naive_kernel.json"),
+             ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json")):
+    cp(a, b)
+for w in ("c3", "c2"):
+    rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
+    keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "radix" in r[0] or "fillBuffer" in r[0]]
+    csv.writer(open(os.path.join("profiles", f"{tag}_{w}_rocprofv3_kernel_stats.csv"), "w")).writerows(keep)
+    cp(os.path.join(f"traffic_{w}", "summary.json"), f"hbm_traffic_{w}.json")
+    d = json.load(open(os.path.join("profiles", f"{tag}_hbm_traffic_{w}.json")))
+    f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if "pfac_scan_filter" in k and not k.rstrip(">( ").endswith("true")][0]
+    wr = [v for k, v in d["WRITE_SIZE"]["scan"].items() if "pfac_scan_filter" in k and not k.rstrip(">( ").endswith("true")][0]
+    filt = [r for r in keep[1:] if "pfac_scan_filter" in r[0] and "false>(" in r[0].replace(" ", "").replace("false,false>", "false>")][:1]
+    print(w, "filter kernel rocprof avg ns:", [(r[0][28:64], r[1], r[3]) for r in keep[1:] if "pfac_scan_filter" in r[0]],
+          "| traffic GB: 2xFETCH %.3f + WRITE %.3f = %.3f" % (2 * f * 1024 / 1e9, wr * 1024 / 1e9, (2 * f + wr) * 1024 / 1e9))

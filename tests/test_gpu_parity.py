@@ -106,6 +106,42 @@ def test_ragged_sizes(workloads, n):
             h.destroy()
 
 
+@pytest.mark.parametrize("perf,tex,mode_name", MODES)
+def test_long_walks_across_every_tile_and_chunk_boundary(workdir, perf, tex, mode_name):
+    """Full matches, prefixes-that-are-patterns and near misses of 60-byte patterns planted so that
+    they straddle a 2 KiB chunk (and 1 KiB tile, 16-byte lane) boundary at every offset 0..71:
+    exercises the 12-byte queue entries across lanes / tiles / chunks, chains longer than a slot,
+    window re-fetches, the one-window-per-step mode and the hand-over to the tail kernel."""
+    import os
+    from oracle import binding as ob
+    from pfac_amd import workloads as wl
+    rng = np.random.Generator(np.random.PCG64(2024))
+    long_a = bytes(rng.integers(97, 123, 60, dtype=np.uint8))          # one long single-successor chain
+    long_b = long_a[:31] + bytes(rng.integers(65, 91, 29, dtype=np.uint8))   # shares 31 bytes, then diverges
+    pats = [long_a, long_b, long_a[:9], long_a[:17], long_b[:40],      # patterns that are prefixes of patterns
+            long_a[5:25], b"zq", b"zqx" * 6]
+    pf = wl.write_pattern_file(os.path.join(workdir, "longwalk.pat"), pats)
+    n = 2048 * 80 + 777
+    data = rng.integers(0, 4, n, dtype=np.uint8) + 48                   # filler that matches nothing
+    plant = [long_a, long_b, long_a[:59], long_a[:30] + b"#", long_b[:45], long_a[:16], long_a[5:24]]
+    for j in range(72):
+        at = 2048 * (3 + j) - j
+        p = plant[j % len(plant)]
+        data[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    tail = np.frombuffer(long_a, dtype=np.uint8)
+    data[n - 60:] = tail                                                # a match that ends exactly at n
+    data[n - 200:n - 141] = tail[:59]                                   # a near miss inside the tail range
+    o = ob.Oracle(pf, hashed=False)
+    want = o.match(data)
+    o.close()
+    assert np.count_nonzero(want) > 100
+    h = make_handle(pf, perf, tex)
+    try:
+        assert_same(device_match(h, data), want, f"long walks/{mode_name}")
+    finally:
+        h.destroy()
+
+
 @pytest.mark.parametrize("in_off,out_off", [(1, 0), (2, 0), (3, 0), (0, 1), (0, 2), (0, 3), (1, 1), (4, 4), (8, 0)])
 def test_misaligned_pointers(workloads, oracle_results, in_off, out_off):
     """The reference casts the input to int* (PFAC_kernel.cu:203); this build accepts any alignment."""

@@ -254,8 +254,11 @@ void buildFilter(const Automaton &fa, Filter &f)
                 const int s3 = fa.edgeNext[e3];
                 setBit(f.gram3, gram3Hash(key3, f.log2Bits));
                 if (s3 <= F) setBit(f.final3, final3Hash(key3, f.log2BitsF3));   /* 3-byte pattern */
-                for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++)
-                    setBit(f.gram4, gram4Hash(key3 | ((uint32_t)fa.edgeCh[e4] << 24), f.log2Bits4));
+                for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++) {
+                    const uint32_t key4 = key3 | ((uint32_t)fa.edgeCh[e4] << 24);
+                    setBit(f.gram4, gram4Hash(key4, f.log2Bits4));
+                    setBit(f.gram4, gram4Hash2(key4, f.log2Bits4));
+                }
             }
         }
     }

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             u32x4 e = {0u, 0u, 0u, 0u};
             if (act) e = queue[idx & kMask];
             const uint32_t x = e.y;
-            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4);
+            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4) & testBit(sGram4, (x * pfac::kGram4Mul2) >> lds.shift4);
             pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
             if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
 #if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */

@@ -201,10 +201,11 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
 
     h3 = (((x & 0xFFFFFF) * 0x797A0B) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits)
     h4 = ((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
+    h4b = ((x * 0x85EBCA77) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
     hf = (((x & 0xFFFFFF) * 0x85EBCB) & 0xFFFFFFFF) >> (32 - info.filterLog2BitsFinal3)
     short = bit(sb, x & 0xFFFF)
     level1 = bit(g3, h3) | short
-    level2 = bit(g4, h4) | bit(f3, hf) | short
+    level2 = (bit(g4, h4) & bit(g4, h4b)) | bit(f3, hf) | short
     hit = oracle_results[name] != 0
     assert np.all(level1[hit] == 1) and np.all(level2[hit] == 1)
     assert info.filterHasShort == int(any(len(p) < 3 for p in open(w.pattern_file, "rb").read().split(b"\n") if p))

@@ -21,6 +21,9 @@
 
 using pfac::Int2;
 
+/* positions per piece of the pipelined PFAC_matchFromHost: 32 Mi positions = 32 MiB up, 128 MiB down */
+static constexpr size_t kHostPiece = size_t(32) << 20;
+
 namespace {
 
 template <class T>
@@ -44,6 +47,22 @@ void freeTables(PFAC_context *c)
     c->numOfTableEntry = c->sizeOfTableEntry = c->sizeOfTableInBytes = 0;
 }
 
+void freeHostStage(PFAC_context *c)
+{
+    for (int b = 0; b < 2; b++) {
+        devFree(c->d_stageIn[b]);
+        devFree(c->d_stageOut[b]);
+        if (c->evUp[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evUp[b]));
+        if (c->evScan[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evScan[b]));
+        if (c->evDown[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evDown[b]));
+        c->evUp[b] = c->evScan[b] = c->evDown[b] = nullptr;
+    }
+    if (c->stageUp) (void)hipStreamDestroy(static_cast<hipStream_t>(c->stageUp));
+    if (c->stageDown) (void)hipStreamDestroy(static_cast<hipStream_t>(c->stageDown));
+    c->stageUp = c->stageDown = nullptr;
+    c->hostStagePositions = 0;
+}
+
 /* ref PFAC_freeResource, PFAC.cpp:221-254 */
 void freeResources(PFAC_context *c)
 {
@@ -57,6 +76,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_workCounters);
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
+    freeHostStage(c);
     devFree(c->d_final3);
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();
@@ -362,26 +382,63 @@ PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size
         return matchHostOnCpuPlatform(handle, h_inputString, size, h_matched_result);
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
 
-    /* ref PFAC.cpp:916-960: per-call temporaries, input padded to a multiple of 4 bytes */
-    char *d_in = nullptr;
-    int *d_out = nullptr;
-    const size_t inBytes = (size + 3) & ~size_t(3);
-    hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&d_in), inBytes);
-    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&d_out), size * sizeof(int));
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        (void)hipGetLastError();
-        if (e1 == hipSuccess) (void)hipFree(d_in);
-        if (e2 == hipSuccess) (void)hipFree(d_out);
-        return PFAC_STATUS_CUDA_ALLOC_FAILED;
+    /*
+     * The reference allocates, uploads, scans, downloads and frees in sequence (PFAC.cpp:916-960), which
+     * leaves the scan idle for the 5 bytes per position that cross the host link.  Here the stream is
+     * cut into pieces of kHostPiece positions: piece i+1 is uploaded and piece i-1 downloaded while
+     * piece i is scanned.  Each piece is scanned together with the maxPatternLen
+     * bytes behind it -- a walk may read that far -- and only its own results go back
+     * (omp_PFAC.cpp:324,377).  The staging buffers, two copy streams and their events belong to the
+     * handle and are created on first use; the scan itself stays on the default stream.
+     */
+    PFAC_context *c = handle;
+    const size_t overlap = (size_t)c->fa.maxPatternLen;
+    const size_t piece = size < kHostPiece ? size : kHostPiece;
+    const size_t need = piece + overlap;
+    if (c->hostStagePositions < need) {
+        freeHostStage(c);
+        bool ok = true;
+        for (int b = 0; b < 2 && ok; b++) {
+            ok = hipMalloc(reinterpret_cast<void **>(&c->d_stageIn[b]), (need + 3) & ~size_t(3)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&c->d_stageOut[b]), need * sizeof(int)) == hipSuccess;
+            hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+            for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&e[k], hipEventDisableTiming) == hipSuccess;
+            c->evUp[b] = e[0]; c->evScan[b] = e[1]; c->evDown[b] = e[2];
+        }
+        hipStream_t up = nullptr, down = nullptr;
+        ok = ok && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithFlags(&down, hipStreamNonBlocking) == hipSuccess;
+        c->stageUp = up; c->stageDown = down;
+        if (!ok) { (void)hipGetLastError(); freeHostStage(c); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+        c->hostStagePositions = need;
     }
+    hipStream_t up = static_cast<hipStream_t>(c->stageUp), down = static_cast<hipStream_t>(c->stageDown);
     PFAC_status_t st = PFAC_STATUS_SUCCESS;
-    if (hipMemcpy(d_in, h_inputString, size, hipMemcpyHostToDevice) != hipSuccess) st = PFAC_STATUS_INTERNAL_ERROR;
-    if (st == PFAC_STATUS_SUCCESS) st = PFAC_matchFromDevice(handle, d_in, size, d_out);
-    if (st == PFAC_STATUS_SUCCESS &&
-        hipMemcpy(h_matched_result, d_out, size * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-        st = PFAC_STATUS_INTERNAL_ERROR;
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    bool used[2] = {false, false};
+    size_t i = 0;
+    for (size_t off = 0; off < size && st == PFAC_STATUS_SUCCESS; off += piece, i++) {
+        const int b = (int)(i & 1);
+        const size_t owned = size - off < piece ? size - off : piece;
+        const size_t scanned = size - off < owned + overlap ? size - off : owned + overlap;
+        hipEvent_t evUp = static_cast<hipEvent_t>(c->evUp[b]), evScan = static_cast<hipEvent_t>(c->evScan[b]),
+                   evDown = static_cast<hipEvent_t>(c->evDown[b]);
+        bool ok = true;
+        if (used[b]) ok = hipStreamWaitEvent(up, evScan, 0) == hipSuccess;          /* the scan of piece i-2 has read this buffer */
+        ok = ok && hipMemcpyAsync(c->d_stageIn[b], h_inputString + off, scanned, hipMemcpyHostToDevice, up) == hipSuccess &&
+             hipEventRecord(evUp, up) == hipSuccess && hipStreamWaitEvent(nullptr, evUp, 0) == hipSuccess;
+        if (ok && used[b]) ok = hipStreamWaitEvent(nullptr, evDown, 0) == hipSuccess;   /* its results have left this buffer */
+        if (!ok) { st = PFAC_STATUS_INTERNAL_ERROR; break; }
+        st = PFAC_matchFromDevice(handle, c->d_stageIn[b], scanned, c->d_stageOut[b]);
+        if (st != PFAC_STATUS_SUCCESS) break;
+        ok = hipEventRecord(evScan, nullptr) == hipSuccess && hipStreamWaitEvent(down, evScan, 0) == hipSuccess &&
+             hipMemcpyAsync(h_matched_result + off, c->d_stageOut[b], owned * sizeof(int), hipMemcpyDeviceToHost, down) == hipSuccess &&
+             hipEventRecord(evDown, down) == hipSuccess;
+        if (!ok) st = PFAC_STATUS_INTERNAL_ERROR;
+        used[b] = true;
+    }
+    const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
+                         hipStreamSynchronize(down) == hipSuccess;
+    if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     return st;
 }
 

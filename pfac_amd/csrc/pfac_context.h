@@ -136,6 +136,13 @@ struct PFAC_context {
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;
     size_t reduceScratchBytes = 0;
+    /* staging of PFAC_matchFromHost on the GPU platform (pfac_api.cpp): two input and two result
+     * buffers of hostStageChunk (+ overlap) positions, two copy streams, events; created on first use */
+    char *d_stageIn[2] = {nullptr, nullptr};
+    int *d_stageOut[2] = {nullptr, nullptr};
+    size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
+    void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */
+    void *evUp[2] = {nullptr, nullptr}, *evScan[2] = {nullptr, nullptr}, *evDown[2] = {nullptr, nullptr};   /* hipEvent_t */
     unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
     uint32_t *d_final3 = nullptr;
 

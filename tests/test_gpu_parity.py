@@ -232,6 +232,34 @@ def test_slices_with_overlap_equal_single_call(workloads, oracle_results):
         h.destroy()
 
 
+def test_match_from_host_pipelined_pieces_equal_match_from_device(workdir):
+    """PFAC_matchFromHost on the GPU platform scans in 32 Mi-position pieces with overlapped copies
+    (SURVEY 8f rank 2): a 70 MiB stream (three pieces, the last one ragged) must give what one
+    PFAC_matchFromDevice call over the whole stream gives, including matches that straddle the cuts."""
+    import os
+    from pfac_amd import workloads as wl
+    pats = wl.snort_patterns(2000)
+    pf = wl.write_pattern_file(os.path.join(workdir, "hostpipe.pat"), pats)
+    n = (70 << 20) + 12345
+    data = wl.http_stream(n, wl.http_message_pool(pats, pool_size=256, embed_fraction=0.3)).copy()
+    longest = max(pats, key=len)
+    straddlers = [((32 << 20) - 1, longest), ((64 << 20) - len(longest) // 2, longest), ((64 << 20) - 300, longest)]
+    for at, p in straddlers:
+        data[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        want = device_match(h, data)
+        got = np.full(n, -7, dtype=np.int32)
+        h.matchFromHost(data.ctypes.data, n, got.ctypes.data)
+        assert_same(got, want, "pipelined matchFromHost")
+        assert all(want[at] != 0 for at, _ in straddlers)                        # matches that straddle a cut
+        got2 = np.full(1000, -7, dtype=np.int32)                                   # a call smaller than the staging buffers
+        h.matchFromHost(data.ctypes.data, 1000, got2.ctypes.data)
+        assert_same(got2[:900], want[:900], "small matchFromHost after a large one")
+    finally:
+        h.destroy()
+
+
 def test_two_handles_interleaved(workloads, oracle_results):
     """Two handles with different pattern sets used alternately (SimpleMultiGPU_pthread.cpp idea)."""
     a = make_handle(workloads["c2"].pattern_file, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON)

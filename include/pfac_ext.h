@@ -24,6 +24,12 @@ extern "C" {
  * PFAC_PLATFORM_CPU. */
 PFAC_status_t PFACX_createHostOnly(PFAC_handle_t *handle);
 
+/* PFAC_readPatternFromFile (ref PFAC.cpp:653-735) for patterns that are already in memory: `patterns`
+ * holds `size` bytes in the pattern-file format, one pattern per '\n'-terminated line (bytes after
+ * the last '\n' are ignored, like in a file).  Same status codes, same pattern IDs; replaces a
+ * previously loaded set.  The buffer is copied. */
+PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patterns, size_t size);
+
 typedef struct {
     int numOfPatterns;        /* F                                             */
     int numOfStates;          /* includes the unused state 0 (ref PFAC.cpp:704) */

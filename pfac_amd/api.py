@@ -72,6 +72,7 @@ EXPORTED_SYMBOLS = (
     "PFAC_matchFromDevice", "PFAC_matchFromHost", "PFAC_matchFromDeviceReduce", "PFAC_matchFromHostReduce",
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
+    "PFACX_readPatternFromMemory",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -113,6 +114,7 @@ def load_library() -> C.CDLL:
     lib.PFACX_getInfo.argtypes = [H, C.POINTER(PFACX_info)]
     lib.PFACX_getTable.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
+    lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name != "PFAC_getErrorString":
@@ -203,6 +205,10 @@ class PFAC:
     def readPatternFromFile(self, filename, check: bool = True) -> int:
         name = None if filename is None else os.fsencode(filename)
         return self._ret(self._lib.PFAC_readPatternFromFile(self._h, name), "PFAC_readPatternFromFile", check)
+
+    def readPatternFromMemory(self, data: bytes, check: bool = True) -> int:
+        """``PFACX_readPatternFromMemory``: the pattern-file bytes without a file."""
+        return self._ret(self._lib.PFACX_readPatternFromMemory(self._h, data, len(data)), "PFACX_readPatternFromMemory", check)
 
     def dumpTransitionTable(self, path: str, check: bool = True) -> int:
         fp = _libc.fopen(os.fsencode(path), b"w")

@@ -107,12 +107,22 @@ PFAC_status_t compilePatternFile(const char *filename, Automaton &fa)
     long fsz = std::ftell(fp);
     std::rewind(fp);
     if (fsz < 0) { std::fclose(fp); return PFAC_STATUS_FILE_OPEN_ERROR; }
+    std::vector<unsigned char> bytes;
     try {
-        fa.file.resize((size_t)fsz);
+        bytes.resize((size_t)fsz);
     } catch (...) { std::fclose(fp); return PFAC_STATUS_ALLOC_FAILED; }
-    size_t got = fsz ? std::fread(fa.file.data(), 1, (size_t)fsz, fp) : 0;
+    size_t got = fsz ? std::fread(bytes.data(), 1, (size_t)fsz, fp) : 0;
     std::fclose(fp);
-    fa.file.resize(got);
+    bytes.resize(got);
+    return compilePatternBytes(std::move(bytes), fa);
+}
+
+/* the pattern-file format from memory: one pattern per '\n'-terminated line (PFAC_reorder_Table.cpp:121-231) */
+PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa)
+{
+    fa = Automaton();
+    fa.file = std::move(bytes);
+    const size_t got = fa.file.size();
 
     /* split into lines; `start` only moves past a NON-empty line (ref :181-190),
      * so a blank line poisons the next pattern -- reported, not asserted. */

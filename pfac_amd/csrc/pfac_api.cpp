@@ -355,6 +355,25 @@ PFAC_status_t PFAC_readPatternFromFile(PFAC_handle_t handle, char *filename)
     return PFAC_STATUS_SUCCESS;
 }
 
+/* pfac_ext.h: the same pattern-file bytes from memory instead of from a file */
+PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patterns, size_t size)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!patterns && size) return PFAC_STATUS_INVALID_PARAMETER;
+    if (handle->isPatternsReady) freeResources(handle);
+    handle->patternFile.clear();
+    PFAC_status_t st;
+    try {
+        st = pfac::compilePatternBytes(std::vector<unsigned char>(patterns, patterns + size), handle->fa);
+    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    if (st != PFAC_STATUS_SUCCESS) { freeResources(handle); return st; }
+    handle->isPatternsReady = true;
+    st = bindCommon(handle);
+    if (st == PFAC_STATUS_SUCCESS) st = bindTable(handle);
+    if (st != PFAC_STATUS_SUCCESS) { freeResources(handle); return st; }
+    return PFAC_STATUS_SUCCESS;
+}
+
 PFAC_status_t PFAC_matchFromDevice(PFAC_handle_t handle, char *d_inputString, size_t size, int *d_matched_result)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;                /* check order: ref PFAC.cpp:846-861 */

@@ -10,6 +10,7 @@ namespace pfac {
 
 /* pattern_compiler.cpp */
 PFAC_status_t compilePatternFile(const char *filename, Automaton &fa);
+PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa);
 void buildInitialRow(const Automaton &fa, std::vector<int> &row);
 void buildFilter(const Automaton &fa, Filter &f);
 

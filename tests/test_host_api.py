@@ -209,3 +209,33 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     hit = oracle_results[name] != 0
     assert np.all(level1[hit] == 1) and np.all(level2[hit] == 1)
     assert info.filterHasShort == int(any(len(p) < 3 for p in open(w.pattern_file, "rb").read().split(b"\n") if p))
+
+
+def test_read_pattern_from_memory_equals_read_from_file(workloads):
+    """PFACX_readPatternFromMemory compiles the same tables and gives the same
+    results as PFAC_readPatternFromFile on the same bytes; error statuses match too."""
+    for name in ("c1", "c3"):
+        w = workloads[name]
+        raw = open(w.pattern_file, "rb").read()
+        a, b = api.PFAC.createHostOnly(), api.PFAC.createHostOnly()
+        try:
+            a.readPatternFromFile(w.pattern_file)
+            b.readPatternFromMemory(raw)
+            ia, ib = a.info(), b.info()
+            assert (ia.numOfPatterns, ia.numOfStates, ia.maxPatternLen) == (ib.numOfPatterns, ib.numOfStates, ib.maxPatternLen)
+            for which in (api.PFACX_TABLE_DENSE, api.PFACX_TABLE_INITIAL_ROW, api.PFACX_TABLE_FILTER_GRAM3):
+                assert np.array_equal(a.table(which), b.table(which))
+            sample = w.data[:20000]
+            assert np.array_equal(a.match_host_array(sample), b.match_host_array(sample))
+            b.readPatternFromMemory(b"second\nset\n")                     # replaces the first set
+            assert b.info().numOfPatterns == 2
+        finally:
+            a.destroy()
+            b.destroy()
+    h = api.PFAC.createHostOnly()
+    try:
+        assert h.readPatternFromMemory(b"AB\n\nCD\n", check=False) == api.STATUS.INVALID_PARAMETER     # blank line
+        assert h.readPatternFromMemory(b"AB\nAB\n", check=False) == api.STATUS.INTERNAL_ERROR          # duplicate
+        assert h.readPatternFromMemory(b"AB\nCD", check=False) == api.STATUS.SUCCESS and h.info().numOfPatterns == 1   # bytes after the last newline are ignored
+    finally:
+        h.destroy()

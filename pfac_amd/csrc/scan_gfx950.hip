@@ -26,7 +26,7 @@
  *   3. QUEUE.  Hits (with their first four bytes) are compacted into a per-wave
  *      LDS ring with ballot/mbcnt; 64 at a time they are re-tested against a
  *      4-gram bitmap (level 2).
- *   4. WALK.  Each lane runs kWalkSets split-phase walkers over the survivors:
+ *   4. WALK.  Each lane runs 2 or 3 split-phase walkers over the survivors:
  *      the loads of a step are issued at the top of an iteration and consumed at
  *      the top of the next one, so a table round trip hides behind a whole chunk
  *      of filter work.  Dense mode: one 4-byte gather per byte.  Hashed mode: a
@@ -427,21 +427,30 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 #ifndef PFAC_STATS
 #define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
 #endif
-#ifndef PFAC_TILES_PER_ITER
-#define PFAC_TILES_PER_ITER 2
+/* Two loop shapes, tuned on MI355X (tools/ab.sh).  SHAPE_LIGHT = 2 KiB chunks, 3 walks per lane: best
+ * when few positions are walked (the stream is what costs).  SHAPE_HEAVY = 4 KiB chunks, 2 walks per
+ * lane: half as many walker rounds, prefetches and counter grabs per KiB; 4 % faster on the 30 k-pattern
+ * set, 4 % slower on the 1 k-pattern set.  The launcher picks by the size of the level-1 key set. */
+#ifndef PFAC_LIGHT_TILES
+#define PFAC_LIGHT_TILES 2
 #endif
-#ifndef PFAC_WALK_SETS
-#define PFAC_WALK_SETS 3
+#ifndef PFAC_LIGHT_WALKS
+#define PFAC_LIGHT_WALKS 3
 #endif
-constexpr int kTilesPerIter = PFAC_TILES_PER_ITER;   /* 1 KiB tiles a wave handles per loop iteration (tuned on MI355X) */
-constexpr int kWalkSets = PFAC_WALK_SETS;            /* independent walks per lane                                      */
-constexpr int kChunkBytes = kTilesPerIter * kTileBytes;
+#ifndef PFAC_HEAVY_TILES
+#define PFAC_HEAVY_TILES 4
+#endif
+#ifndef PFAC_HEAVY_WALKS
+#define PFAC_HEAVY_WALKS 2
+#endif
+constexpr size_t kHeavyMinKeys = 4096;        /* distinct 3-byte pattern prefixes from which SHAPE_HEAVY is used */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
-template <int MODE, bool HAS_SHORT, bool REDUCE>
+template <int MODE, bool HAS_SHORT, bool REDUCE, int kTilesPerIter, int kWalkSets>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_scan_filter(ScanArgs a)
 {
+    constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave takes per loop iteration */
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     using WCtx = typename WalkTypes<MODE>::Ctx;
     using WLane = typename WalkTypes<MODE>::Lane;
@@ -855,10 +864,13 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     return bytes;
 }
 
-template <int MODE, bool HAS_SHORT, bool REDUCE>
-hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
+int tilesPerChunk(const PFAC_context *c) { return c->filter.bitsSet >= kHeavyMinKeys ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES; }
+size_t chunkBytes(const PFAC_context *c) { return (size_t)tilesPerChunk(c) * kTileBytes; }
+
+template <int MODE, bool HAS_SHORT, bool REDUCE, int TILES, int WALKS>
+hipError_t launchShape(const PFAC_context *c, const ScanArgs &a)
 {
-    auto kernel = pfac_scan_filter<MODE, HAS_SHORT, REDUCE>;
+    auto kernel = pfac_scan_filter<MODE, HAS_SHORT, REDUCE, TILES, WALKS>;
     const size_t lds = filterLdsBytes(c, REDUCE);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -867,7 +879,7 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlockThreads, lds);
     if (e != hipSuccess) return e;
     if (perCU < 1) perCU = 1;
-    const size_t numChunks = (a.n + kChunkBytes - 1) / kChunkBytes;
+    const size_t numChunks = a.n / ((size_t)TILES * kTileBytes);
     size_t blocks = (numChunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
@@ -875,6 +887,13 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     return hipGetLastError();
+}
+
+template <int MODE, bool HAS_SHORT, bool REDUCE>
+hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
+{
+    return tilesPerChunk(c) == PFAC_HEAVY_TILES ? launchShape<MODE, HAS_SHORT, REDUCE, PFAC_HEAVY_TILES, PFAC_HEAVY_WALKS>(c, a)
+                                                : launchShape<MODE, HAS_SHORT, REDUCE, PFAC_LIGHT_TILES, PFAC_LIGHT_WALKS>(c, a);
 }
 
 template <int MODE>
@@ -952,7 +971,7 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
     const size_t margin = (size_t)c->fa.maxPatternLen + 32;
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
     const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;
-    return end > first ? (end - first) / kChunkBytes * kChunkBytes : 0;
+    return end > first ? (end - first) / chunkBytes(c) * chunkBytes(c) : 0;
 }
 
 /* The vector kernel keeps byte positions in 32 bits: larger inputs are scanned as consecutive windows */

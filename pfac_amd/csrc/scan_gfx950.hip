@@ -72,11 +72,10 @@ constexpr int kTrap = pfac::kTrapState;
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
-constexpr int kTileBytes = 1024;              /* input bytes per wave per iteration   */
+constexpr int kTileBytes = 1024;              /* input bytes one wave-wide 16 B/lane load covers */
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 enum TableMode { DENSE_GLOBAL = 0, DENSE_BUFFER = 1, HASH_GLOBAL = 2, HASH_BUFFER = 3 };
 
@@ -225,18 +224,18 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
 
 /*
  * Walkers are split-phase: issue() starts the loads of the next transition, consume() finishes it.
- * Each lane runs kWalkSets independent walks; per scan iteration all of them issue, then the tile
- * prefetch and the zero stores are issued, and only then the (single) wait of the iteration happens,
- * so one memory round trip covers kWalkSets x 64 table steps plus the streaming traffic.
+ * Each lane runs 2 or 3 independent walks; all of them issue at the top of a scan iteration, right
+ * before the chunk prefetch and the zero stores, and are consumed at the top of the next one, so one
+ * memory round trip covers up to 192 table steps and hides behind a whole chunk of filter work.
  *
- * On pattern-dense input the kernel is bound by instruction issue, and the walkers are the largest
- * consumer (profiles/): a step is written as straight-line selects (every early `return` costs
- * exec-mask bookkeeping for the whole wave), positions are 32-bit, and nothing checks a bound -- the
- * launcher hands the last maxPatternLen + 32 bytes of the input to the simple kernel, so a walk that
- * starts in this kernel's range can neither run past the input nor load past it.
+ * What is scarce on pattern-dense input is gathered loads, then instruction issue:
+ * a step is written as straight-line selects (every early `return` costs exec-mask bookkeeping for
+ * the whole wave), positions are 32-bit, and nothing checks a bound -- the launcher hands the last
+ * maxPatternLen + 32 bytes of the input to the simple kernel, so a walk that starts in this kernel's
+ * range can neither run past the input nor load past it.
  *
- * DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.  Input bytes come 16 at a
- * time; a step that runs out of window only refills it.
+ * DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.  Input bytes come 8 at a
+ * time (first with the queue entry, then fetched together with the step that uses the last one).
  */
 template <int MODE> struct DenseCtx {
     static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
@@ -252,12 +251,12 @@ template <int MODE> struct DenseLane {
     using Ctx = DenseCtx<MODE>;
     uint32_t pos = 0;
     int state = kTrap, match = 0;
-    uint32_t depth = 0, have = 0;              /* have = input bytes left in win */
+    uint32_t depth = 0, have = 0;              /* have = input bytes left in win (>= 1 while the walk is alive) */
     uint64_t win = 0;
     /* in flight */
     int loadedState = kTrap;
     u32x4 loadedWindow = {0, 0, 0, 0};
-    bool refilling = false;
+    bool refilling = false;                    /* the step in flight uses the last byte of win: the next 8 bytes are in flight too */
 
     /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
      * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
@@ -272,27 +271,23 @@ template <int MODE> struct DenseLane {
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
-        refilling = have == 0;
-        if (refilling) {                                       /* window exhausted: fetch 8 more bytes */
-            loadedWindow = loadWindow16(c.in32, pos + depth);
-        } else {
-            int s = c.lookup(state, (int)(win & 0xFF));
-            if (MODE == DENSE_BUFFER && s == 0) s = kTrap;     /* out-of-range clamp of the descriptor */
-            loadedState = s;
-        }
+        int s = c.lookup(state, (int)(win & 0xFF));
+        if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
+        loadedState = s;
+        refilling = have == 1;
+        if (refilling) loadedWindow = loadWindow16(c.in32, pos + depth + 1);   /* the 8 bytes behind the one being used */
     }
     /* false = the walk is over (trap) */
     __device__ __forceinline__ bool consume(const Ctx &c)
     {
+        state = loadedState;
+        match = (uint32_t)(state - 1) < c.numFinal ? state : match;
+        win >>= 8; have--; depth++;
         if (refilling) {
             const uint32_t o = (pos + depth) & 3u;
             win = ((uint64_t)windowDword(loadedWindow, o + 4) << 32) | windowDword(loadedWindow, o);
             have = 8;
-            return true;
         }
-        state = loadedState;
-        match = (uint32_t)(state - 1) < c.numFinal ? state : match;
-        win >>= 8; have--; depth++;
         return state != kTrap;
     }
 };

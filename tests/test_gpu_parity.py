@@ -142,6 +142,49 @@ def test_long_walks_across_every_tile_and_chunk_boundary(workdir, perf, tex, mod
         h.destroy()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_pattern_sets_over_tiny_alphabets(workdir, seed):
+    """Random pattern sets over 2-4 symbol alphabets: patterns that are prefixes of patterns at every
+    depth (final states with successors, the pattern-ID-in-chain encoding and its chain cut), long
+    single-successor chains, 1- and 2-byte patterns (exact short bitmap), bytes 0x00 / 0xFF, and an
+    input in which almost every position walks.  All four table modes against the oracle."""
+    import os
+    from oracle import binding as ob
+    from pfac_amd import workloads as wl
+    rng = np.random.Generator(np.random.PCG64(900 + seed))
+    alphabet = [bytes([b]) for b in rng.choice([0x00, 0xFF, 0x41, 0x42, 0x7A, 0x20, 0x0D], size=int(rng.integers(2, 5)), replace=False)]
+    pats = set()
+    base = b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), 48))
+    for cut in rng.integers(1, 48, int(rng.integers(3, 14))):           # prefixes of one long string
+        pats.add(base[:int(cut)])
+    while len(pats) < int(rng.integers(8, 70)):
+        ln = int(rng.integers(1 if seed % 2 else 3, 41))
+        pats.add(b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), ln)))
+    pats = sorted(pats, key=lambda p: (rng.random(), p))               # file order = pattern IDs: shuffled
+    pf = wl.write_pattern_file(os.path.join(workdir, f"fuzz{seed}.pat"), pats)
+    n = int(rng.integers(40_000, 200_000))
+    idx = rng.integers(0, len(alphabet), n)
+    data = np.frombuffer(b"".join(alphabet), dtype=np.uint8)[idx].copy()
+    at = int(rng.integers(0, n - 100))
+    data[at:at + len(base)] = np.frombuffer(base, dtype=np.uint8)
+    o = ob.Oracle(pf, hashed=False)
+    want = o.match(data)
+    o.close()
+    for perf, tex, mode_name in MODES:
+        h = make_handle(pf, perf, tex)
+        try:
+            assert_same(device_match(h, data), want, f"fuzz seed {seed}/{mode_name}")
+            d_in = torch.from_numpy(data).to("cuda:0")
+            d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+            d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+            st, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+            nz = np.nonzero(want)[0]
+            assert count == nz.size and np.array_equal(d_pos[:count].cpu().numpy(), nz) and \
+                np.array_equal(d_res[:count].cpu().numpy(), want[nz]), f"fuzz seed {seed}/{mode_name} reduce"
+        finally:
+            h.destroy()
+
+
 @pytest.mark.parametrize("in_off,out_off", [(1, 0), (2, 0), (3, 0), (0, 1), (0, 2), (0, 3), (1, 1), (4, 4), (8, 0)])
 def test_misaligned_pointers(workloads, oracle_results, in_off, out_off):
     """The reference casts the input to int* (PFAC_kernel.cu:203); this build accepts any alignment."""

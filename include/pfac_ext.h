@@ -74,8 +74,10 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
                              size_t *bytes);
 
 /* Kernel variants of the GPU match path. */
-#define PFACX_KERNEL_FILTER 0   /* default: 3-gram LDS prefilter + compacted walkers      */
-#define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic) */
+#define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
+#define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic)           */
+#define PFACX_KERNEL_AUTO   2   /* default: FILTER, except that calls of less than 1 MiB take NAIVE
+                                   alone (lower latency: the filter kernel has a ~35 us floor)      */
 
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 

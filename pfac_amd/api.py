@@ -24,7 +24,7 @@ PFAC_PLATFORM_GPU, PFAC_PLATFORM_CPU, PFAC_PLATFORM_CPU_OMP = 0, 1, 2
 PFAC_AUTOMATIC, PFAC_TEXTURE_ON, PFAC_TEXTURE_OFF = 0, 1, 2
 PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
-PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE = 0, 1
+PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO = 0, 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_GRAM4, PFACX_TABLE_FILTER_FINAL3) = range(8)
 

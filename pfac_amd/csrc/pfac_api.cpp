@@ -586,7 +586,7 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (variant != PFACX_KERNEL_FILTER && variant != PFACX_KERNEL_NAIVE) return PFAC_STATUS_INVALID_PARAMETER;
+    if (variant != PFACX_KERNEL_FILTER && variant != PFACX_KERNEL_NAIVE && variant != PFACX_KERNEL_AUTO) return PFAC_STATUS_INVALID_PARAMETER;
     handle->kernelVariant = variant;
     return PFAC_STATUS_SUCCESS;
 }

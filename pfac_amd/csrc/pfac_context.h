@@ -161,7 +161,7 @@ struct PFAC_context {
     int platform = PFAC_PLATFORM_GPU;
     int perfMode = PFAC_TIME_DRIVEN;
     int textureMode = PFAC_AUTOMATIC;
-    int kernelVariant = PFACX_KERNEL_FILTER;
+    int kernelVariant = PFACX_KERNEL_AUTO;
 
     bool hasDevice = false;
     int device = -1;

@@ -955,6 +955,10 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     return PFAC_STATUS_SUCCESS;
 }
 
+/* below this many positions a call takes the simple kernel alone: ~8 us + 1 us per 60..200 KiB instead of the
+ * filter kernel's ~35 us floor (tools/small_input_latency.py) */
+constexpr size_t kSmallInput = size_t(1) << 20;
+
 /* Launch plan for positions [first, ownEnd) of an input of inputSize readable bytes:
  *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 32 bytes inside the input
  *                              (a walk is at most maxPatternLen deep, a window load reads <= 19 bytes on)
@@ -963,6 +967,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
 size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
 {
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
+    if (c->kernelVariant == PFACX_KERNEL_AUTO && ownEnd - first < kSmallInput) return 0;   /* filling 134 KiB of LDS per block costs more than scanning this */
     const size_t margin = (size_t)c->fa.maxPatternLen + 32;
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
     const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;

@@ -22,6 +22,12 @@ import os
 import sys
 import time
 
+# OpenMP workers (numpy/torch pools, the oracle's cross-check before the timed region) must sleep, not
+# spin, once their parallel region is over: spinning host threads delay the launches of the timed
+# steps.  Has to be in the environment before the first OpenMP runtime is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -281,6 +287,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kname,
                 "kernel_ms_avg": round(kernel_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "kernel_ms_median": round(float(np.median(kernel_ms)), 4), "kernel_ms_max": round(float(np.max(kernel_ms)), 4),
+                "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms] if len(kernel_ms) <= 64 else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_INPUT_BYTE * n_read,
                 "input_only_frac": round(n_read / kernel_avg_s / 1e9 / HBM_PEAK_GBS, 4),
             },

@@ -207,7 +207,7 @@ void buildInitialRow(const Automaton &fa, std::vector<int> &row)
  * The kernel tests (a)/(b) from LDS for every position and (c)/(d) for the survivors; only positions
  * that pass both are walked through the real table, so false positives cost time, never
  * correctness.  gram3 / gram4 / final3 are one-hash Bloom filters sized for <= ~1/64 density
- * within the LDS budget (gram3, gram4: 1..32 KiB each).
+ * within the LDS budget (gram3 1..64 KiB, gram4 1..16 KiB).
  */
 static int sizeLog2(size_t keys, int lo, int hi)
 {
@@ -225,10 +225,13 @@ void buildFilter(const Automaton &fa, Filter &f)
     auto fanout = [&](int s) { return (size_t)(fa.edgeBegin[s + 1] - fa.edgeBegin[s]); };
 
     size_t depth3 = 0, depth4 = 0, len3 = 0;
+    bool anyShort = false;
     for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
         const int s1 = fa.edgeNext[e1];
+        anyShort |= s1 <= F;
         for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
             const int s2 = fa.edgeNext[e2];
+            anyShort |= s2 <= F;
             depth3 += fanout(s2);
             for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
                 const int s3 = fa.edgeNext[e3];
@@ -237,9 +240,22 @@ void buildFilter(const Automaton &fa, Filter &f)
             }
         }
     }
-    f.log2Bits = sizeLog2(depth3, 13, 18);
-    f.log2Bits4 = sizeLog2(depth4, 13, 18);
+    /* Level 1 is tested for every position and each false positive costs queue work (the kernel is bound
+     * by instruction issue): up to 64 KiB, <= 1/64 density.  Level 2 has two hashes and only costs a
+     * short walk when it errs: up to 16 KiB.  Everything lives in LDS next to 78 KiB of queues and
+     * tables (scan_gfx950.hip: filterLdsBytes), so the bitmaps share kFilterLdsBudget. */
+    f.log2Bits = sizeLog2(depth3, 13, 19);
+    f.log2Bits4 = sizeLog2(depth4, 13, 17);
     f.log2BitsF3 = sizeLog2(len3, 10, 16);
+    auto total = [&]() {
+        return ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2Bits4) + (size_t(1) << f.log2BitsF3)) / 8 + (anyShort ? 65536 / 8 : 0);
+    };
+    while (total() > kFilterLdsBudget) {
+        if (f.log2Bits > 16) f.log2Bits--;
+        else if (f.log2BitsF3 > 13) f.log2BitsF3--;
+        else if (f.log2Bits4 > 13) f.log2Bits4--;
+        else break;
+    }
     f.gram3.assign((size_t(1) << f.log2Bits) / 32, 0);
     f.gram4.assign((size_t(1) << f.log2Bits4) / 32, 0);
     f.final3.assign((size_t(1) << f.log2BitsF3) / 32, 0);

@@ -45,6 +45,7 @@ struct ChainSlot {
     unsigned char chain[8];                   /* chain bytes, zero padded; if the end state is final and
                                                  has successors: <= 3 chain bytes, pattern ID in [4..7]  */
 };
+constexpr size_t kFilterLdsBudget = 82 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp) */
 constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state                         */
 constexpr uint32_t kSlotLeaf = 1u << 13;      /* the end state has no outgoing transition               */
 constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */

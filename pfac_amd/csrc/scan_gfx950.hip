@@ -68,7 +68,7 @@ constexpr int kTrap = pfac::kTrapState;
 #define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
 #ifndef PFAC_QUEUE_CAP
-#define PFAC_QUEUE_CAP 256
+#define PFAC_QUEUE_CAP 128
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
@@ -439,6 +439,7 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 #define PFAC_HEAVY_WALKS 2
 #endif
 constexpr size_t kHeavyMinKeys = 4096;        /* distinct 3-byte pattern prefixes from which SHAPE_HEAVY is used */
+constexpr int kStageWords = (kTileBytes + 16) / 4;   /* LDS copy of a tile + 16 bytes, from which queue entries are cut */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sShort = sFinal3 + wordsF3;
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQueueAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);   /* 16-byte aligned */
-    uint32_t *sReduceAll = sQueueAll + kWavesPerBlock * kQueueCap * 4;   /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sStageAll = sQueueAll + kWavesPerBlock * kQueueCap * 4;    /* per wave: the tile being filtered + the 16 bytes behind it */
+    uint32_t *sReduceAll = sStageAll + kWavesPerBlock * kStageWords;     /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     /* ring of {byte position (32-bit), input bytes pos..pos+11}: the twelve bytes carry most walks to
      * their end without a single input load (gathered loads are the scarce resource) */
     u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQueueCap;
+    uint32_t *stage = sStageAll + wave * kStageWords;
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
@@ -728,20 +731,17 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position */
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) {
-            /* D[0..3] = this lane's 16 bytes, D[4..6] = the 12 bytes behind them (next lane / next tile / halo) */
-            const u32x4 behind = (t + 1 < kTilesPerIter) ? d[(t + 1) % kTilesPerIter] : halo;     /* lane 0's copy is what lane 63 needs */
-            uint32_t D[7] = {d[t].x, d[t].y, d[t].z, d[t].w, 0u, 0u, 0u};
-            {
-                const uint32_t srcs[3] = {d[t].x, d[t].y, d[t].z}, wraps[3] = {behind.x, behind.y, behind.z};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const uint32_t fromNext = (uint32_t)__shfl_down((int)srcs[k], 1);
-                    const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wraps[k]) : wraps[k];
-                    D[4 + k] = lane == 63 ? wrap : fromNext;
-                }
-            }
-            const uint32_t *dw = D;
-            const uint32_t nxtLane = D[4];
+            /* the tile goes to LDS as well (lane l -> bytes 16l.., lane 0 also the 16 bytes behind the tile):
+             * a queue entry needs 12 bytes from an arbitrary offset, and picking them out of registers costs
+             * a dozen selects per append round -- issue slots are what this loop is short of */
+            const u32x4 behind = (t + 1 < kTilesPerIter) ? d[(t + 1) % kTilesPerIter] : halo;     /* lane 0's copy is the right one */
+            reinterpret_cast<u32x4 *>(stage)[lane] = d[t];
+            if (lane == 0) reinterpret_cast<u32x4 *>(stage)[64] = behind;
+            const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
+            uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
+            const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)behind.x) : behind.x;
+            if (lane == 63) nxtLane = wrap;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             uint32_t hits = 0;
 #pragma unroll
             for (int half = 0; half < 2; half++) {          /* 8 positions at a time: 8 LDS reads in flight */
@@ -768,11 +768,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             while (pending) {                               /* wave-uniform: max hits per lane iterations */
                 const bool has = hits != 0;
                 const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
-                const uint32_t j = b >> 2, sh = b & 3u;
-                const uint32_t e0 = j == 0 ? D[0] : j == 1 ? D[1] : j == 2 ? D[2] : D[3];
-                const uint32_t e1 = j == 0 ? D[1] : j == 1 ? D[2] : j == 2 ? D[3] : D[4];
-                const uint32_t e2 = j == 0 ? D[2] : j == 1 ? D[3] : j == 2 ? D[4] : D[5];
-                const uint32_t e3 = j == 0 ? D[3] : j == 1 ? D[4] : j == 2 ? D[5] : D[6];
+                const uint32_t at = ((uint32_t)lane << 2) + (b >> 2), sh = b & 3u;       /* dword of the tile the hit starts in */
+                const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3];
                 const u32x4 entry = {chunk * kChunkBytes + (uint32_t)(t * kTileBytes + (lane << 4)) + b,
                                      __builtin_amdgcn_alignbyte(e1, e0, sh), __builtin_amdgcn_alignbyte(e2, e1, sh),
                                      __builtin_amdgcn_alignbyte(e3, e2, sh)};
@@ -854,7 +851,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * kQueueCap * 4 * sizeof(uint32_t);
+    bytes += (size_t)kWavesPerBlock * (kQueueCap * 4 + kStageWords) * sizeof(uint32_t);
     if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }

@@ -3,28 +3,47 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5] [--size-mib 1024]
 
-One "step" = one PFAC_matchFromDevice() pass over the rank's slice of the synthetic stream,
-input and result buffers resident in HBM, transition tables already uploaded.  N > 1 is
-launched by torch.distributed.run (one process per GPU); the stream is sharded as independent
-1 GiB slices with a maxPatternLen+1 read-ahead tail (reference omp_PFAC.cpp:319-377), no
-data-path collective, RCCL only gathers the per-rank (match count, checksum) pairs.
+One "step" = one PFAC_matchFromDevice() pass over the rank's slice of the synthetic stream, input
+and result buffers resident in HBM, transition tables already uploaded.  The stream is sharded as
+independent 1 GiB slices with a maxPatternLen+1 read-ahead tail (reference omp_PFAC.cpp:319-377);
+there is no data-path collective, RCCL only gathers the per-rank (match count, checksum) facts.
+
+Process layout.  Started plainly (`python bench.py --gpus N`), this process is an ORCHESTRATOR that
+never touches the GPU: it builds what is missing, starts N fresh rank processes (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment -- what torch.distributed.run
+would set), relays rank 0's JSON line and exits with the worst child's code.  At N = 1 it also runs the
+CPU baseline in its own process (own OpenMP environment, GPU idle) and the two rocprofv3 PMC passes
+that measure the HBM traffic of the dominant kernel.  Started by `python -m torch.distributed.run`
+(RANK is set), the process is a rank.
 
 Rank 0 prints ONE JSON line (the driver contract) that also carries
-  "roofline":     algorithmic HBM bytes (5 B per input byte: 1 read + 4 written) / kernel time,
-                  kernel time measured with HIP events on the launch stream inside the timed region
-  "cpu_baseline": the reference's own OpenMP matcher (oracle/_ref, compiled from the unmodified
-                  reference sources) timed on this host's cores on a bounded sample, N=1 only.
+  "roofline":      algorithmic HBM bytes (5 B per input byte: 1 read + 4 written) / kernel time,
+                   kernel time measured with HIP events on the launch stream inside the timed region;
+                   "traffic" from the PMC passes of this run (or of the committed profile, see
+                   "traffic_source")
+  "cpu_baseline":  the reference's own OpenMP matcher (oracle/_ref, compiled from the unmodified
+                   reference sources) timed on this host's cores on a bounded sample, N = 1 only
+  "other_configs": the other single-GPU BASELINE configurations (c2 texture on/off, c5 dense/hashed),
+                   10 launches each on the same GPU, N = 1 only
+
+Bit-exactness (outside the timed region): every rank compares its result with the committed digest of
+the REFERENCE's CPU/OMP result for its slice (tests/golden/full_digests.json: match count, position
+checksum, FNV-1a-64 of the int32 vector); at sizes without a digest, with the oracle on sampled
+windows.  At N = 1 the CPU baseline's result (the reference matcher itself) is also compared with the
+GPU result over the whole CPU sample.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-# OpenMP workers (numpy/torch pools, the oracle's cross-check before the timed region) must sleep, not
-# spin, once their parallel region is over: spinning host threads delay the launches of the timed
-# steps.  Has to be in the environment before the first OpenMP runtime is loaded.
+# OpenMP workers of the rank processes (numpy/torch pools, the oracle's window checks before the timed
+# region) must sleep, not spin, once their parallel region is over: spinning host threads delay the
+# launches of the timed steps.  The CPU-baseline worker replaces these (cpu_worker_env).
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
@@ -36,14 +55,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 ALGO_BYTES_PER_INPUT_BYTE = 5    # 1 B input read + 4 B int32 result written
-SETTLE_STEPS = 32                # untimed launches after the host-side cross-check, before the warmup steps
+SETTLE_STEPS = 32                # untimed launches after host-side checks, before the warmup steps
+OTHER_STEPS = 10                 # timed launches per entry of "other_configs"
+DIGESTS = os.path.join(ROOT, "tests", "golden", "full_digests.json")
+SCRATCH = os.path.join(ROOT, "gpurun_out", "bench")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -53,12 +75,39 @@ def parse_args():
     ap.add_argument("--variant", default="filter", choices=["filter", "naive"])
     ap.add_argument("--texture", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--perf-mode", default=None, choices=[None, "dense", "hash"])
+    ap.add_argument("--platform", default="gpu", choices=["gpu", "cpu_omp"],
+                    help="cpu_omp: PFAC_setPlatform(PFAC_PLATFORM_CPU_OMP) + PFAC_matchFromHost -- a dry run of the rank/"
+                         "shard/gather logic on a machine without a GPU (never the reported metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto: measure HBM traffic of the scan kernel with two rocprofv3 --pmc passes (N = 1, orchestrated runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target duration of ONE CPU-baseline run (3 runs are timed)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real path; gloo lets several ranks share one GPU for a dry run")
-    return ap.parse_args()
+    ap.add_argument("--worker", default=None, choices=[None, "cpu", "pmc", "rank"],
+                    help="rank: be the single rank right here, no orchestrator and no child process (the form to put behind `rocprofv3 ... --`); "
+                         "pmc: the same, a few launches only; cpu: the CPU-baseline process")
+    ap.add_argument("--sparse-file", default=None, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------- digests
+
+def load_digest(workload, slice_index, size_mib, last):
+    """Committed digest of the reference's CPU/OMP result for one slice (tests/golden/make_full_digests.py)."""
+    try:
+        doc = json.load(open(DIGESTS))
+    except OSError:
+        return None
+    for r in doc["records"]:
+        if r["workload"] == workload and r["slice"] == slice_index and r["size_mib"] == size_mib:
+            d = dict(r["last" if last else "inner"])
+            d["input_fnv1a"] = r["input_fnv1a"]
+            d["variant"] = "last" if last else "inner"
+            return d
+    return None
 
 
 def sparse_result(d_out, n):
@@ -66,268 +115,609 @@ def sparse_result(d_out, n):
     import torch
     pos = torch.nonzero(d_out[:n]).flatten()
     ids = d_out[:n][pos]
-    return pos.cpu().numpy().astype(np.int64), ids.cpu().numpy().astype(np.int64)
+    return pos.cpu().numpy().astype(np.int64), ids.cpu().numpy().astype(np.int32)
 
 
-def verify(handle, api, ob, cfg_pattern_file, host_in, d_in, d_out, n, n_read, perf_mode, variant):
-    """Bit-exactness outside the timed region:
-       (1) full size: the timed kernel's result == the other, independent kernel's result;
-       (2) sampled 1 MiB windows of the stream re-scanned by the oracle == the same windows of (1)."""
-    import torch
-    torch.cuda.synchronize()
-    pos, ids = sparse_result(d_out, n)
-    # (1) second, independent kernel on the same device buffers
-    d_chk = torch.full_like(d_out, -1)
-    other = api.PFACX_KERNEL_NAIVE if variant == api.PFACX_KERNEL_FILTER else api.PFACX_KERNEL_FILTER
-    handle.setKernelVariant(other)
-    handle.matchFromDevice(d_in.data_ptr(), n_read, d_chk.data_ptr())
-    handle.setKernelVariant(variant)
-    torch.cuda.synchronize()
-    same = bool(torch.equal(d_out[:n_read], d_chk[:n_read]))
-    del d_chk
-    # (2) oracle on windows (window + overlap so matches crossing the window end are exact)
-    oracle = ob.Oracle(cfg_pattern_file, dense=(perf_mode == 0), hashed=(perf_mode == 1))
+def check_against_digest(dg, pos, ids, n, base, host_in):
+    """The result vector is (pos, ids) and zero elsewhere: compare with the reference digest."""
+    from pfac_amd import sharding
+    from pfac_amd import workloads as wl
+    facts = {
+        "match_count": int(pos.size),
+        "checksum": int(sharding.position_checksum(pos, ids, base=base)),
+        "fnv1a64": int(wl.fnv1a_sparse_i32(pos, ids, n)),
+    }
+    ok = all(facts[k] == dg[k] for k in facts)
+    same_input = wl.fnv1a(host_in[:n]) == dg["input_fnv1a"]
+    if not same_input:
+        log("[verify] the generated input differs from the one the digest was made from (generator drift)")
+    return ok and same_input, facts
+
+
+def check_against_oracle_windows(ob, pattern_file, host_in, d_out, n, n_read, perf_mode):
+    """No digest for this size: the oracle re-scans sampled 1 MiB windows (+ overlap)."""
+    oracle = ob.Oracle(pattern_file, dense=(perf_mode == 0), hashed=(perf_mode == 1))
     rng = np.random.Generator(np.random.PCG64(99))
     win = 1 << 20
     tail = oracle.max_pattern_len + 1
     starts = [0, max(0, n - win)] + [int(x) for x in rng.integers(0, max(1, n - win), size=6)]
-    windows_ok = True
+    ok = True
     for s in starts:
         e = min(n, s + win)
         r = min(n_read, e + tail)
         want = oracle.match(host_in[s:r], hashed=(perf_mode == 1), omp=True)[: e - s]
-        got = d_out[s:e].cpu().numpy()
+        got = d_out[s:e].cpu().numpy() if hasattr(d_out, "cpu") else d_out[s:e]
         if not np.array_equal(got, want):
-            windows_ok = False
+            ok = False
             log(f"[verify] MISMATCH in window [{s},{e})")
     oracle.close()
-    return same and windows_ok, pos, ids
+    return ok
 
+
+# ----------------------------------------------------------------------------- PMC traffic
 
 def committed_traffic(workload, kernel_substr):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh ->
-    profiles/rNN_hbm_traffic_<workload>.json): 2 x FETCH_SIZE (gfx950 reports half of coalesced
-    reads -- calibrated on the stream probe in the same file) + WRITE_SIZE, in bytes.  None if no
-    profile of this workload is committed.  PMC passes cannot run inside the timed bench process."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic_<workload>.json):
+    2 x FETCH_SIZE (gfx950 reports half of coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{workload}.json")))
     if not files:
         return None, None
     try:
         d = json.load(open(files[-1]))
-        # pfac_scan_filter<MODE, HAS_SHORT, REDUCE>: the full-result kernel is the REDUCE = false instance
-        def mine(k):
-            return kernel_substr in k and not k.rstrip(">( ").endswith("true")
+
+        def mine(k):   # pfac_scan_filter<MODE, HAS_SHORT, REDUCE, ...>: the full-result kernel has REDUCE = false
+            targs = [a.strip() for a in k.split("<", 1)[-1].split(">", 1)[0].split(",")]
+            return kernel_substr in k and (len(targs) < 3 or targs[2] == "false")
         f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if mine(k)]
         w = [v for k, v in d["WRITE_SIZE"]["scan"].items() if mine(k)]
         if not f or not w:
             return None, None
-        return int((2.0 * f[0] + w[0]) * 1024), os.path.relpath(files[-1], ROOT)
+        return int((2.0 * f[0] + w[0]) * 1024), os.path.relpath(files[-1], ROOT) + " (committed profile, not this run)"
     except Exception:
         return None, None
 
 
-def cpu_baseline(ob, pattern_file, host_in, perf_mode, target_seconds):
-    """Reference OpenMP matcher (oracle/_ref) -- or the C port if _ref is absent -- on a bounded sample."""
-    threads = ob.omp_max_threads()
-    oracle = ob.Oracle(pattern_file, dense=(perf_mode == 0), hashed=(perf_mode == 1))
+def pmc_counter_mean(csv_dir, kernel_substr):
+    """Mean Counter_Value over the dispatches of the full-result scan kernel in a rocprofv3 counter CSV."""
+    import csv
+    import glob
+    vals = []
+    for path in glob.glob(os.path.join(csv_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if kernel_substr in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def measure_traffic(argv_common, kernel_substr):
+    """Two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a short run of the
+    same workload; the profiled program is this script in --worker pmc mode, placed directly after `--`."""
+    import shutil
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(SCRATCH, "pmc_" + counter)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--worker", "pmc"] + argv_common
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        mean, count = pmc_counter_mean(d, kernel_substr)
+        if p.returncode != 0 or mean is None:
+            return None, f"rocprofv3 --pmc {counter} rc {p.returncode}, {count} dispatches"
+        out[counter] = (mean, count)
+    kb_fetch, kb_write = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"bytes": int((2.0 * kb_fetch + kb_write) * 1024), "fetch_size_kb": round(kb_fetch, 1), "write_size_kb": round(kb_write, 1),
+            "dispatches": out["FETCH_SIZE"][1]}, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (2 x FETCH_SIZE + WRITE_SIZE, KB = 1024 B)"
+
+
+# ------------------------------------------------------------------------------ CPU baseline
+
+def lscpu_facts():
+    facts = {}
+    try:
+        for line in subprocess.run(["lscpu"], stdout=subprocess.PIPE, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            facts[k.strip()] = v.strip()
+    except Exception:
+        pass
+
+    def num(k, default):
+        try:
+            return int(facts.get(k, default))
+        except ValueError:
+            return default
+    sockets, cps, tpc = num("Socket(s)", 1), num("Core(s) per socket", 0), num("Thread(s) per core", 1)
+    logical = os.cpu_count() or 1
+    physical = sockets * cps if cps else max(1, logical // max(1, tpc))
+    try:
+        physical = min(physical, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return {"model": facts.get("Model name", "unknown"), "sockets": sockets, "physical_cores": max(1, physical),
+            "logical_cpus": logical, "threads_per_core": tpc}
+
+
+def cpu_worker_env(threads):
+    """OpenMP environment of the CPU-baseline process (SURVEY 8d / BASELINE.md 3): one thread per
+    physical core, bound close to cores; the default (active) wait policy of the OpenMP runtime."""
+    env = dict(os.environ)
+    for k in ("OMP_WAIT_POLICY", "GOMP_SPINCOUNT"):
+        env.pop(k, None)
+    env.update(OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    return env
+
+
+def cpu_worker(args):
+    """--worker cpu: time the reference's OpenMP matcher (oracle/_ref; the C port if _ref is absent) on a
+    bounded prefix of the rank-0 stream, 3 runs; compare its result with the GPU's sparse result."""
+    from oracle import binding as ob   # cpu_baseline leg
+    from pfac_amd import workloads as wl
+    cfg = wl.make_config(args.workload)
+    perf_mode = cfg.perf_mode if args.perf_mode is None else (0 if args.perf_mode == "dense" else 1)
+    os.makedirs(SCRATCH, exist_ok=True)
+    pf = wl.write_pattern_file(os.path.join(SCRATCH, f"{cfg.name}_cpu.pat"), cfg.patterns)
+    oracle = ob.Oracle(pf, dense=(perf_mode == 0), hashed=(perf_mode == 1))
     use_ref = ob.have_reference()
     if perf_mode == 0:
         dense = oracle.dense_table()
     else:
         row, val = oracle.hash_row(), oracle.hash_val()
+    n = args.size_mib << 20
+    host_in = cfg.input_slice(n, 0)
 
     def run(sample):
         t0 = time.perf_counter()
         if use_ref:
             if perf_mode == 0:
-                ob.Reference.match_dense(sample, dense, oracle.num_patterns, oracle.initial_state, omp=True)
+                r = ob.Reference.match_dense(sample, dense, oracle.num_patterns, oracle.initial_state, omp=True)
             else:
-                ob.Reference.match_hash(sample, row, val, oracle.num_patterns, oracle.initial_state, omp=True)
+                r = ob.Reference.match_hash(sample, row, val, oracle.num_patterns, oracle.initial_state, omp=True)
         else:
-            oracle.match(sample, hashed=(perf_mode == 1), omp=True)
-        return time.perf_counter() - t0
+            r = oracle.match(sample, hashed=(perf_mode == 1), omp=True)
+        return time.perf_counter() - t0, r
 
-    pilot = min(host_in.size, 16 << 20)
-    t = run(host_in[:pilot])
-    rate = pilot / t
-    sample = int(min(host_in.size, max(pilot, rate * target_seconds)))
-    sample -= sample % (1 << 20) if sample > (1 << 20) else 0
-    t = run(host_in[:sample])
-    oracle.close()
-    return {
-        "value": round(sample / t / 1e9, 4), "unit": "GB/s", "cores": threads,
+    pilot = min(n, 16 << 20)
+    t, _ = run(host_in[:pilot])
+    sample = int(min(n, max(pilot, pilot / t * args.cpu_seconds)))
+    if sample > (1 << 20):
+        sample -= sample % (1 << 20)
+    times = []
+    for _ in range(3):
+        t, result = run(host_in[:sample])
+        times.append(t)
+    fn = ("PFAC_CPU_OMP_spaceDriven" if perf_mode else "PFAC_CPU_OMP_timeDriven") if use_ref else "oracle C port"
+    facts = lscpu_facts()
+    threads = ob.omp_max_threads()
+    out = {
+        "value": round(sample / min(times) / 1e9, 4), "unit": "GB/s", "cores": threads,
         "kind": "reference" if use_ref else "port",
-        "sample": f"first {sample >> 20} MiB of the rank-0 stream, {'PFAC_CPU_OMP_spaceDriven' if perf_mode else 'PFAC_CPU_OMP_timeDriven'}"
-                  f" ({'reference sources compiled unmodified' if use_ref else 'oracle C port'}), {threads} OpenMP threads, 1 run after a 16 MiB pilot",
+        "best": round(sample / min(times) / 1e9, 4), "median": round(sample / float(np.median(times)) / 1e9, 4),
+        "runs_s": [round(x, 4) for x in times],
+        "sample": f"first {sample >> 20} MiB of the rank-0 {cfg.name} stream, {fn}"
+                  f" ({'reference sources compiled unmodified, oracle/_ref' if use_ref else 'oracle/pfac_oracle.c'}), {threads} OpenMP threads, "
+                  f"3 runs after a 16 MiB pilot, value = best",
+        "cpu": facts,
+        "omp_env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
+    }
+    # cross-check: the reference matcher's result == the GPU's result, over every position of the sample
+    # whose walk cannot reach the end of the sample (the GPU scanned the whole stream)
+    if args.sparse_file and os.path.exists(args.sparse_file):
+        z = np.load(args.sparse_file)
+        limit = sample if sample == n and int(z["n_read"]) == n else sample - oracle.max_pattern_len
+        cpu_pos = np.flatnonzero(result[:limit])
+        keep = z["pos"] < limit
+        same = bool(np.array_equal(cpu_pos, z["pos"][keep]) and np.array_equal(result[cpu_pos], z["ids"][keep]))
+        out["gpu_result_equals_cpu_result"] = same
+        out["compared_positions"] = int(limit)
+        out["compared_matches"] = int(cpu_pos.size)
+    oracle.close()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------- rank process
+
+class Run:
+    """One workload on one device: handle, input slice, device buffers."""
+
+    def __init__(self, args, name, perf_mode, texture, rank, world, device, buffers=None):
+        import torch
+        from pfac_amd import api, sharding
+        from pfac_amd import workloads as wl
+        self.api, self.torch = api, torch
+        self.cfg = wl.make_config(name)
+        self.perf_mode = self.cfg.perf_mode if perf_mode is None else perf_mode
+        os.makedirs(SCRATCH, exist_ok=True)
+        self.pattern_file = wl.write_pattern_file(os.path.join(SCRATCH, f"{self.cfg.name}_rank{rank}.pat"), self.cfg.patterns)
+        self.gpu = args.platform == "gpu"
+        if self.gpu:
+            self.handle = api.PFAC.create()
+        else:
+            self.handle = api.PFAC.createHostOnly()
+            self.handle.setPlatform(api.PFAC_PLATFORM_CPU_OMP)
+        self.handle.setPerfMode(self.perf_mode)
+        self.handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[texture])
+        self.variant = api.PFACX_KERNEL_FILTER if args.variant == "filter" else api.PFACX_KERNEL_NAIVE
+        self.handle.setKernelVariant(self.variant)
+        self.handle.readPatternFromFile(self.pattern_file)
+        self.info = self.handle.info()
+        # slice `rank` of the N x size stream plus the head of the next slice (generators are prefix-stable)
+        self.host_in, self.n = sharding.rank_input(self.cfg, args.size_mib << 20, rank, world, self.info.maxPatternLen)
+        self.n_read = self.host_in.size
+        if self.gpu:
+            if buffers is not None and buffers[0].numel() >= self.n_read:
+                self.d_in, self.d_out = buffers
+                self.d_in[: self.n_read].copy_(torch.from_numpy(self.host_in))
+                self.d_out.fill_(-1)
+            else:
+                self.d_in = torch.from_numpy(self.host_in).to(device)
+                self.d_out = torch.full((self.n_read,), -1, dtype=torch.int32, device=device)
+            torch.cuda.synchronize()
+        else:
+            self.h_out = np.full(self.n_read, -1, dtype=np.int32)
+
+    def step(self):
+        if self.gpu:
+            self.handle.matchFromDevice(self.d_in.data_ptr(), self.n_read, self.d_out.data_ptr())
+        else:
+            self.handle.matchFromHost(self.host_in.ctypes.data, self.n_read, self.h_out.ctypes.data)
+
+    def sparse(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+            return sparse_result(self.d_out, self.n)
+        pos = np.flatnonzero(self.h_out[: self.n])
+        return pos.astype(np.int64), self.h_out[pos]
+
+    def verify(self, args, rank, world):
+        """-> (bit_exact, method, pos, ids)"""
+        pos, ids = self.sparse()
+        if args.no_verify:
+            return True, "not verified (--no-verify)", pos, ids
+        dg = load_digest(self.cfg.name, rank, args.size_mib, last=(rank == world - 1))
+        if dg is not None:
+            ok, facts = check_against_digest(dg, pos, ids, self.n, rank * self.n, self.host_in)
+            if not ok:
+                log(f"[verify r{rank}] result {facts} != reference digest { {k: dg[k] for k in facts} }")
+            return ok, "== digest of the reference's PFAC_CPU_OMP result (tests/golden/full_digests.json: count, checksum, FNV-1a-64)", pos, ids
+        from oracle import binding as ob   # checker only
+        out = self.d_out if self.gpu else self.h_out
+        ok = check_against_oracle_windows(ob, self.pattern_file, self.host_in, out, self.n, self.n_read, self.perf_mode)
+        return ok, "== oracle on 8 sampled 1 MiB windows (no committed digest for this size)", pos, ids
+
+    def timed(self, steps, warmup, settle, barrier=None):
+        """-> (kernel_ms per step from HIP events on the launch stream, wall seconds of the K steps)"""
+        for _ in range(settle + warmup):
+            self.step()
+        if not self.gpu:
+            if barrier:
+                barrier()
+            ms = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                self.step()
+                ms.append((time.perf_counter() - t1) * 1e3)
+            if barrier:
+                barrier()
+            return ms, time.perf_counter() - t0
+        from pfac_amd import hiprt
+        torch = self.torch
+        events = [(hiprt.Event(), hiprt.Event()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in events:
+            a.record(0)
+            self.step()
+            b.record(0)
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        return [a.elapsed_ms(b) for a, b in events], elapsed
+
+    def scan_stats(self):
+        """Counters of the last launch (pfac_ext.h: PFACX_getScanStats), or None."""
+        if not self.gpu:
+            return None
+        st = self.handle.scanStats(self.n_read)
+        return st if st["walkerRounds"] else None
+
+    def close(self):
+        self.handle.destroy()
+
+
+def roofline_block(kernel_ms, n_read, kname):
+    avg_s = float(np.mean(kernel_ms)) / 1e3
+    achieved = ALGO_BYTES_PER_INPUT_BYTE * n_read / avg_s / 1e9
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+        "kernel": kname,
+        "kernel_ms_avg": round(avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+        "kernel_ms_median": round(float(np.median(kernel_ms)), 4), "kernel_ms_max": round(float(np.max(kernel_ms)), 4),
+        "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms] if len(kernel_ms) <= 64 else None,
+        "algorithmic_bytes_per_launch": ALGO_BYTES_PER_INPUT_BYTE * n_read,
+        "input_only_frac": round(n_read / avg_s / 1e9 / HBM_PEAK_GBS, 4),
     }
 
 
-def main():
-    args = parse_args()
+def other_configs(args, device, buffers):
+    """The other single-GPU BASELINE configurations on the same GPU and the same buffers:
+    c2 with texture mode on and off, c5 with the dense and the hashed table."""
+    from pfac_amd import api
+    out = {}
+    todo = [("c2_texture_on", "c2", None, "on"), ("c2_texture_off", "c2", None, "off"),
+            ("c5_dense", "c5", api.PFAC_TIME_DRIVEN, "auto"), ("c5_hashed", "c5", api.PFAC_SPACE_DRIVEN, "auto")]
+    for key, name, perf, tex in todo:
+        t0 = time.perf_counter()
+        run = Run(args, name, perf, tex, 0, 1, device, buffers)
+        run.step()
+        ok, method, pos, _ = run.verify(args, 0, 1)
+        ms, _ = run.timed(OTHER_STEPS, 2, 8)
+        r = roofline_block(ms, run.n_read, "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive")
+        entry = {"workload": run.cfg.description, "table": "hashed" if run.perf_mode else "dense",
+                 "texture_mode": int(run.handle.info().textureMode), "steps": OTHER_STEPS,
+                 "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_min": r["kernel_ms_min"], "frac": r["frac"],
+                 "input_GBps": round(run.n_read / (r["kernel_ms_avg"] / 1e3) / 1e9, 1),
+                 "matches": int(pos.size), "bit_exact": bool(ok), "bit_exact_method": method}
+        st = run.scan_stats()
+        if st:
+            entry["walk_stats"] = st
+        out[key] = entry
+        run.close()
+        log(f"[bench] {key}: {entry['kernel_ms_avg']} ms, frac {entry['frac']}, exact {ok} ({time.perf_counter() - t0:.1f}s)")
+    return out
+
+
+def rank_main(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a number for a different rank count")
+        return 2
+    gpu = args.platform == "gpu"
 
     import torch
     import torch.distributed as dist
-    assert torch.cuda.is_available(), "bench.py needs a GPU: the match path has no CPU fallback"
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()      # dry run: ranks may share a device
-    torch.cuda.set_device(local_rank)
+    device = None
+    if gpu:
+        if not torch.cuda.is_available():
+            log("[bench] no GPU: the match path has no CPU fallback (use --platform cpu_omp --dist-backend gloo for a dry run)")
+            return 2
+        ndev = torch.cuda.device_count()
+        if args.dist_backend == "gloo":
+            local_rank = local_rank % ndev                       # dry run: ranks may share a device
+        elif local_rank >= ndev:
+            log(f"[bench] rank {rank} needs GPU {local_rank} but only {ndev} visible: --gpus {args.gpus} needs {args.gpus} GPUs")
+            return 2
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+    elif args.dist_backend != "gloo":
+        log("[bench] --platform cpu_omp needs --dist-backend gloo")
+        return 2
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build(only_if_missing=True)
-    if world > 1:
-        dist.barrier()
+    from pfac_amd import sharding
 
-    from pfac_amd import api, hiprt, sharding
-    from pfac_amd import workloads as wl
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
-    # ---- workload ---------------------------------------------------------------------------
     t_setup = time.perf_counter()
-    cfg = wl.make_config(args.workload)
-    perf_mode = cfg.perf_mode if args.perf_mode is None else (0 if args.perf_mode == "dense" else 1)
-    tmp = os.path.join(ROOT, "gpurun_out", "bench")
-    os.makedirs(tmp, exist_ok=True)
-    pattern_file = os.path.join(tmp, f"{cfg.name}_rank{rank}.pat")
-    wl.write_pattern_file(pattern_file, cfg.patterns)
-
-    handle = api.PFAC.create()
-    handle.setPerfMode(perf_mode)
-    handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[args.texture])
-    handle.setKernelVariant(api.PFACX_KERNEL_FILTER if args.variant == "filter" else api.PFACX_KERNEL_NAIVE)
-    handle.readPatternFromFile(pattern_file)
-    info = handle.info()
-
-    # slice `rank` of the N x size stream plus the head of the next slice (generators are prefix-stable)
-    host_in, n = sharding.rank_input(cfg, args.size_mib << 20, rank, world, info.maxPatternLen)
-    n_read = host_in.size
-    d_in = torch.from_numpy(host_in).to(f"cuda:{local_rank}")
-    d_out = torch.full((n_read,), -1, dtype=torch.int32, device=f"cuda:{local_rank}")
-    torch.cuda.synchronize()
-    log(f"[bench r{rank}] setup {time.perf_counter() - t_setup:.1f}s: {cfg.description}; F={info.numOfPatterns} "
+    perf_mode = None if args.perf_mode is None else (0 if args.perf_mode == "dense" else 1)
+    run = Run(args, args.workload, perf_mode, args.texture, rank, world, device)
+    info = run.info
+    log(f"[bench r{rank}] setup {time.perf_counter() - t_setup:.1f}s: {run.cfg.description}; F={info.numOfPatterns} "
         f"states={info.numOfStates} table={info.sizeOfTableInBytes / 1e6:.1f} MB filter=2^{info.filterLog2Bits} bits "
         f"({info.filterBitsSet} set) CUs={info.multiProcessorCount}")
 
-    def step():
-        handle.matchFromDevice(d_in.data_ptr(), n_read, d_out.data_ptr())
+    if args.worker == "pmc":                                   # profiled by rocprofv3: a few launches, nothing else
+        for _ in range(4):
+            run.step()
+        torch.cuda.synchronize()
+        run.close()
+        return 0
 
     # ---- correctness gate (outside the timed region) ------------------------------------------
-    step()
-    ok = True
-    pos = ids = None
-    if not args.no_verify:
-        from oracle import binding as ob   # checker only
-        ok, pos, ids = verify(handle, api, ob, pattern_file, host_in, d_in, d_out, n, n_read, perf_mode,
-                              api.PFACX_KERNEL_FILTER if args.variant == "filter" else api.PFACX_KERNEL_NAIVE)
-    else:
-        pos, ids = sparse_result(d_out, n)
+    run.step()
+    ok, method, pos, ids = run.verify(args, rank, world)
     count = int(pos.size)
-    checksum = sharding.position_checksum(pos, ids, base=rank * n)
+    checksum = sharding.position_checksum(pos, ids, base=rank * run.n)
+    if rank == 0 and args.sparse_file:
+        np.savez(args.sparse_file, pos=pos, ids=ids, n=run.n, n_read=run.n_read)
 
-    # ---- timed region ---------------------------------------------------------------------------
-    events = [(hiprt.Event(), hiprt.Event()) for _ in range(args.steps)]
-    # The cross-check above leaves the GPU idle for ~1 s of host work and its clocks drop; the first
-    # ~10 launches after that run up to 15 % slower (profiles/: kernel_ms_steps).  SETTLE_STEPS untimed
-    # launches bring the clocks back before the W warmup steps the caller asked for.
-    for _ in range(SETTLE_STEPS):
-        step()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, b in events:
-        a.record(0)
-        step()
-        b.record(0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: W warmup steps, then exactly K steps between barriers ---------------------
+    # Host-side checks leave the GPU idle for ~1 s and its clocks drop; the first ~10 launches after
+    # that run up to 15 % slower.  SETTLE_STEPS untimed launches precede the W warmup steps.
+    kernel_ms, elapsed = run.timed(args.steps, args.warmup, SETTLE_STEPS if gpu else 0, barrier)
 
-    kernel_ms = [a.elapsed_ms(b) for a, b in events]
-    kernel_avg_s = float(np.mean(kernel_ms)) / 1e3
-
-    # ---- gather per-rank facts (RCCL: 4 x int64 per rank) ----------------------------------------
-    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9)],
-                                     device=f"cuda:{local_rank}" if args.dist_backend == "nccl" else None)
+    # ---- gather per-rank facts (RCCL: 5 x int64 per rank) ----------------------------------------
+    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
+                                     device=device if (gpu and args.dist_backend == "nccl") else None)
     elapsed_max = float(allf[:, 3].max()) / 1e9
-    total_matches = int(allf[:, 0].sum())
+    total_matches, folded = sharding.combine_checksums([(int(c), int(s)) for c, s in allf[:, :2]])
     all_ok = bool(allf[:, 2].all())
+    ranks_seen = sorted(int(r) for r in allf[:, 4])
 
+    rc = 0
     if rank == 0:
-        ms_per_step = elapsed_max / args.steps * 1e3
-        value = world * n / (elapsed_max / args.steps) / 1e9
-        achieved = ALGO_BYTES_PER_INPUT_BYTE * n_read / kernel_avg_s / 1e9
+        # the omp_PFAC.cpp:396-439 check: the folded result of all slices == the reference's folded digests
+        expected = None
+        dgs = [load_digest(run.cfg.name, r, args.size_mib, last=(r == world - 1)) for r in range(world)]
+        if all(d is not None for d in dgs):
+            ec, es = sharding.combine_checksums([(d["match_count"], d["checksum"] & 0x7FFFFFFFFFFFFFFF) for d in dgs])
+            expected = {"match_count": ec, "checksum": es & 0x7FFFFFFFFFFFFFFF,
+                        "equal": bool(ec == total_matches and (es & 0x7FFFFFFFFFFFFFFF) == (folded & 0x7FFFFFFFFFFFFFFF))}
+            all_ok = all_ok and expected["equal"]
+        if ranks_seen != list(range(world)):
+            all_ok = False
+        n = run.n
         kname = "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive"
-        traffic, traffic_src = (committed_traffic(cfg.name, kname) if args.size_mib == 1024 and perf_mode == cfg.perf_mode
-                                else (None, None))
         out = {
-            "metric": "input GB/s scanned (PFAC_matchFromDevice, bit-exact)",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": "input GB/s scanned (PFAC_matchFromDevice, bit-exact)" if gpu else
+                      "input GB/s scanned (DRY RUN on the CPU_OMP platform, not the metric)",
+            "value": round(world * n / (elapsed_max / args.steps) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "settle_steps": SETTLE_STEPS if gpu else 0,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": f"{cfg.name}: {cfg.description}; {args.size_mib} MiB per GPU x {world} GPU(s)"
+                "workload": f"{run.cfg.name}: {run.cfg.description}; {args.size_mib} MiB per GPU x {world} GPU(s)"
                             + (f", slices overlap {sharding.overlap_bytes(info.maxPatternLen)} B" if world > 1 else ""),
                 "patterns": info.numOfPatterns, "states": info.numOfStates,
-                "table": "hashed" if perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
-                "texture_mode": int(handle.info().textureMode), "kernel": args.variant,
-                "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok,
+                "table": "hashed" if run.perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
+                "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "platform": args.platform,
+                "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
+                "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if world > 1 else None,
+                "folded_result": {"match_count": total_matches, "checksum": folded & 0x7FFFFFFFFFFFFFFF},
+                "folded_reference": expected,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kname,
-                "kernel_ms_avg": round(kernel_avg_s * 1e3, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-                "kernel_ms_median": round(float(np.median(kernel_ms)), 4), "kernel_ms_max": round(float(np.max(kernel_ms)), 4),
-                "kernel_ms_steps": [round(float(x), 3) for x in kernel_ms] if len(kernel_ms) <= 64 else None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_INPUT_BYTE * n_read,
-                "input_only_frac": round(n_read / kernel_avg_s / 1e9 / HBM_PEAK_GBS, 4),
-            },
+            "roofline": roofline_block(kernel_ms, run.n_read, kname),
         }
-        if world == 1:
+        st = run.scan_stats()
+        if st:
+            out["config"]["walk_stats"] = st
+        if world == 1 and gpu:
+            torch = run.torch
             # not the headline metric: the compacted-output API (SURVEY 8f rank 1) on the same buffers.
             # Synchronous (the match count returns to the host), so wall clock per call.
-            d_pos = torch.empty_like(d_out)
-            handle.matchFromDeviceReduce(d_in.data_ptr(), n_read, d_out.data_ptr(), d_pos.data_ptr())
+            d_pos = torch.empty_like(run.d_out)
+            run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
             torch.cuda.synchronize()
             t0r = time.perf_counter()
             for _ in range(5):
-                _, rcount = handle.matchFromDeviceReduce(d_in.data_ptr(), n_read, d_out.data_ptr(), d_pos.data_ptr())
+                _, rcount = run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
             torch.cuda.synchronize()
             tr = (time.perf_counter() - t0r) / 5
-            out["reduce_api"] = {"value": round(n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
-                                 "matches": int(rcount), "same_matches_as_full_result": bool(rcount == count),
-                                 "algorithmic_bytes_per_call": int(n_read + 8 * rcount),
-                                 "note": "PFAC_matchFromDeviceReduce incl. count readback and position sort; ~1 B/input byte of HBM traffic"}
+            rp = d_pos[:rcount].cpu().numpy().astype(np.int64)
+            ri = run.d_out[:rcount].cpu().numpy()
+            keep = rp < n
+            same = bool(np.array_equal(rp[keep], pos) and np.array_equal(ri[keep], ids))
+            out["reduce_api"] = {"value": round(run.n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
+                                 "matches": int(rcount), "same_result_as_full_vector": same,
+                                 "algorithmic_bytes_per_call": int(run.n_read + 8 * rcount),
+                                 "note": "PFAC_matchFromDeviceReduce incl. count readback; ~1 B/input byte of HBM traffic"}
+            if not same:
+                all_ok = False
+                out["config"]["bit_exact"] = False
             del d_pos
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import binding as ob   # cpu_baseline leg
-            out["cpu_baseline"] = cpu_baseline(ob, pattern_file, host_in[:n], perf_mode, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+            if not args.no_other_configs:
+                buffers = (run.d_in, run.d_out)
+                out["other_configs"] = other_configs(args, device, buffers)
+                if not all(e["bit_exact"] for e in out["other_configs"].values()):
+                    all_ok = False
+        out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
         if not all_ok:
             log("[bench] RESULT NOT BIT-EXACT")
-
-    handle.destroy()
+            rc = 1
+    run.close()
     if world > 1:
         dist.destroy_process_group()
-    return 0 if all_ok else 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------- orchestrator
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def orchestrate(args, argv):
+    """No GPU call, no torch import in this process: children are started fresh (never exec'ed into)."""
+    p = subprocess.run([sys.executable, "-c", "import __graft_entry__ as e; e.build(only_if_missing=True)"], cwd=ROOT)
+    if p.returncode != 0:
+        log("[bench] build failed")
+        return 2
+    os.makedirs(SCRATCH, exist_ok=True)
+    n = args.gpus
+    single = n == 1 and args.platform == "gpu"
+    sparse_file = os.path.join(SCRATCH, f"{args.workload}_rank0_sparse.npz")
+    if os.path.exists(sparse_file):
+        os.remove(sparse_file)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        extra = ["--sparse-file", sparse_file] if (single and r == 0 and not args.no_cpu_baseline) else []
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    rc = max((abs(c) for c in rcs), default=0)
+    line = None
+    for l in out0.decode(errors="replace").splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            log(l)
+    if line is None:
+        log(f"[bench] rank 0 printed no result (exit codes {rcs})")
+        return rc or 1
+    out = json.loads(line)
+
+    if single and not args.no_cpu_baseline:
+        threads = lscpu_facts()["physical_cores"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", "cpu", "--workload", args.workload,
+               "--size-mib", str(args.size_mib), "--cpu-seconds", str(args.cpu_seconds), "--sparse-file", sparse_file]
+        if args.perf_mode:
+            cmd += ["--perf-mode", args.perf_mode]
+        p = subprocess.run(cmd, cwd=ROOT, env=cpu_worker_env(threads), stdout=subprocess.PIPE)
+        try:
+            out["cpu_baseline"] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            if out["cpu_baseline"].get("gpu_result_equals_cpu_result") is False:
+                out["config"]["bit_exact"] = False
+                rc = rc or 1
+        except Exception:
+            log(f"[bench] CPU baseline worker failed (rc {p.returncode})")
+    if single and args.pmc == "auto" and args.variant == "filter":
+        common = ["--workload", args.workload, "--size-mib", str(args.size_mib), "--texture", args.texture, "--no-verify"]
+        if args.perf_mode:
+            common += ["--perf-mode", args.perf_mode]
+        t0 = time.perf_counter()
+        traffic, src = measure_traffic(common, "pfac_scan_filter")
+        log(f"[bench] PMC passes {time.perf_counter() - t0:.1f}s: {traffic} ({src})")
+        if traffic:
+            out["roofline"]["traffic"] = traffic["bytes"]
+            out["roofline"]["traffic_source"] = src
+            out["roofline"]["traffic_detail"] = traffic
+        else:
+            out["roofline"]["traffic_note"] = src
+    if out["roofline"]["traffic"] is None and args.size_mib == 1024 and args.perf_mode is None:
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = committed_traffic(args.workload, out["roofline"]["kernel"])
+    print(json.dumps(out), flush=True)
+    return rc
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.worker == "cpu":
+        return cpu_worker(args)
+    if args.worker in ("pmc", "rank") or "RANK" in os.environ:
+        return rank_main(args)
+    return orchestrate(args, argv)
 
 
 if __name__ == "__main__":

@@ -81,6 +81,20 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 
+/* Counters of the most recent PFAC_matchFromDevice / ...Reduce launch of the filter kernel on this handle
+ * (configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
+ * stream.  All zero if the last call did not run the filter kernel. */
+typedef struct {
+    unsigned long long walkerRounds;      /* wave-wide walker rounds (one table step for every live walk)      */
+    unsigned long long laneSteps;         /* table steps taken, summed over lanes                              */
+    unsigned long long walksStarted;      /* positions that passed both filter levels and were walked          */
+    unsigned long long level1Hits;        /* positions that passed filter level 1                              */
+    int tilesPerChunk;                    /* KiB per chunk                                                     */
+    int walksPerLane;                     /* independent walks per lane                                        */
+} PFACX_scan_stats_t;
+
+PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,11 @@ class PFACX_info(C.Structure):
     ]
 
 
+class PFACX_scan_stats(C.Structure):
+    _fields_ = [("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
+                ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int)]
+
+
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 _lib: Optional[C.CDLL] = None
 
@@ -72,7 +77,7 @@ EXPORTED_SYMBOLS = (
     "PFAC_matchFromDevice", "PFAC_matchFromHost", "PFAC_matchFromDeviceReduce", "PFAC_matchFromHostReduce",
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
-    "PFACX_readPatternFromMemory",
+    "PFACX_readPatternFromMemory", "PFACX_getScanStats",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -115,6 +120,7 @@ def load_library() -> C.CDLL:
     lib.PFACX_getTable.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
+    lib.PFACX_getScanStats.argtypes = [H, C.POINTER(PFACX_scan_stats)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name != "PFAC_getErrorString":
@@ -253,6 +259,21 @@ class PFAC:
         info = PFACX_info()
         self._ret(self._lib.PFACX_getInfo(self._h, C.byref(info)), "PFACX_getInfo", True)
         return info
+
+    def scanStats(self, positions: int = 0):
+        """``PFACX_getScanStats`` of the last filter-kernel launch, plus the derived SURVEY 8(d) C5 figures
+        (`positions` = input bytes of that launch)."""
+        st = PFACX_scan_stats()
+        self._ret(self._lib.PFACX_getScanStats(self._h, C.byref(st)), "PFACX_getScanStats", True)
+        d = {name: int(getattr(st, name)) for name, _ in PFACX_scan_stats._fields_}
+        if d["walkerRounds"]:
+            d["avg_table_steps_per_walk"] = round(d["laneSteps"] / max(1, d["walksStarted"]), 3)
+            d["lane_utilisation"] = round(d["laneSteps"] / (d["walkerRounds"] * 64.0 * d["walksPerLane"]), 4)
+            if positions:
+                d["early_out_rate"] = round(1.0 - d["walksStarted"] / positions, 6)       # positions that never left LDS
+                d["level1_hit_rate"] = round(d["level1Hits"] / positions, 6)
+                d["walker_rounds_per_KiB"] = round(d["walkerRounds"] * 64.0 / (positions / 1024.0) / 64.0, 4)
+        return d
 
     def table(self, which: int):
         """Host copy of a compiled table as a numpy array (copy)."""

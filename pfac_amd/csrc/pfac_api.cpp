@@ -583,6 +583,24 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
     return PFAC_STATUS_SUCCESS;
 }
 
+PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!stats) return PFAC_STATUS_INVALID_PARAMETER;
+    std::memset(stats, 0, sizeof(*stats));
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!handle->hasDevice || !handle->d_workCounters) return PFAC_STATUS_LIB_NOT_EXIST;
+    unsigned long long v[pfac::kStatsCount];
+    if (hipStreamSynchronize(nullptr) != hipSuccess ||
+        hipMemcpy(v, handle->d_workCounters + pfac::kStatsWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+        return PFAC_STATUS_INTERNAL_ERROR;
+    stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
+    const bool heavy = handle->filter.bitsSet >= pfac::kHeavyMinKeys;
+    stats->tilesPerChunk = heavy ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES;
+    stats->walksPerLane = (heavy || handle->perfMode == PFAC_SPACE_DRIVEN) ? PFAC_HEAVY_WALKS : PFAC_LIGHT_WALKS;
+    return PFAC_STATUS_SUCCESS;
+}
+
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;

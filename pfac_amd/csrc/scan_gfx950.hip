@@ -426,27 +426,43 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
  * when few positions are walked (the stream is what costs).  SHAPE_HEAVY = 4 KiB chunks, 2 walks per
  * lane: half as many walker rounds, prefetches and counter grabs per KiB; 4 % faster on the 30 k-pattern
  * set, 4 % slower on the 1 k-pattern set.  The launcher picks by the size of the level-1 key set. */
-#ifndef PFAC_LIGHT_TILES
-#define PFAC_LIGHT_TILES 2
+/* Level-1 survivors are handled per GROUP of two tiles: the group is staged in LDS (+ the 16 bytes behind
+ * it), every lane's hits go to a per-wave list of 16-bit codes, and 64 list entries at a time are cut out
+ * of the stage, tested against level 2 and appended to the walk queue -- one entry per lane. */
+constexpr int kGroupTiles = 2;
+constexpr int kGroupBytes = kGroupTiles * kTileBytes;
+constexpr int kStageWords = (kGroupBytes + 16) / 4;
+#ifndef PFAC_LIST_CAP
+#define PFAC_LIST_CAP 128
 #endif
-#ifndef PFAC_LIGHT_WALKS
-#define PFAC_LIGHT_WALKS 3
+constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one group take another pass */
+constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
+constexpr uint32_t kReduceQueueCap = kQueueCap < 64 ? kQueueCap : 64;   /* ... which takes the LDS of half the walk queue */
+/* In-order chunk hand-out: 0 = the input is cut into kWorkParts contiguous parts, one
+ * counter each; G > 0 = one moving front: granules of 2^G chunks are dealt round-robin to the parts, so
+ * all parts work inside one window of parts << G chunks that sweeps the input once. */
+#ifndef PFAC_FRONT_LOG2
+#define PFAC_FRONT_LOG2 0
 #endif
-#ifndef PFAC_HEAVY_TILES
-#define PFAC_HEAVY_TILES 4
-#endif
-#ifndef PFAC_HEAVY_WALKS
-#define PFAC_HEAVY_WALKS 2
-#endif
-constexpr size_t kHeavyMinKeys = 4096;        /* distinct 3-byte pattern prefixes from which SHAPE_HEAVY is used */
-constexpr int kStageWords = (kTileBytes + 16) / 4;   /* LDS copy of a tile + 16 bytes, from which queue entries are cut */
-constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant */
+
+/* inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, the gfx9 wave scan) */
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1, 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2, 3 */
+    return v;
+}
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
 template <int MODE, bool HAS_SHORT, bool REDUCE, int kTilesPerIter, int kWalkSets>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_scan_filter(ScanArgs a)
 {
-    constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave takes per loop iteration */
+    constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
+    static_assert(kTilesPerIter == kGroupTiles, "the stage holds one chunk; hit codes have one bit for the tile");
     constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
     using WCtx = typename WalkTypes<MODE>::Ctx;
     using WLane = typename WalkTypes<MODE>::Lane;
@@ -458,8 +474,10 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sShort = sFinal3 + wordsF3;
     uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
     uint32_t *sQueueAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);   /* 16-byte aligned */
-    uint32_t *sStageAll = sQueueAll + kWavesPerBlock * kQueueCap * 4;    /* per wave: the tile being filtered + the 16 bytes behind it */
-    uint32_t *sReduceAll = sStageAll + kWavesPerBlock * kStageWords;     /* REDUCE only: per-wave staging of (position, id) */
+    constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
+    uint32_t *sStageAll = sQueueAll + kWavesPerBlock * kQCap * 4;        /* per wave: the chunk being filtered + the 16 bytes behind it */
+    uint32_t *sListAll = sStageAll + kWavesPerBlock * kStageWords;       /* per wave: 16-bit codes of the group's level-1 hits */
+    uint32_t *sReduceAll = sListAll + kWavesPerBlock * (kListCap / 2);   /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -480,10 +498,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform by construction: keep it (and what derives from it) scalar */
-    /* ring of {byte position (32-bit), input bytes pos..pos+11}: the twelve bytes carry most walks to
-     * their end without a single input load (gathered loads are the scarce resource) */
-    u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQueueCap;
+    /* ring of {byte position (32-bit), input bytes pos..pos+11} that passed both filter levels: the twelve
+     * bytes carry most walks to their end without a single input load (gathered loads are the scarce
+     * resource) */
+    u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQCap;
     uint32_t *stage = sStageAll + wave * kStageWords;
+    uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
@@ -495,51 +515,21 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) alive[s] = false;
     /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
-     *   [qh, qv)  passed both filter levels, waiting for a walker lane
-     *   [qv, qu)  passed level 1 only, waiting until a full wave of them can be tested at once */
-    uint32_t qh = 0, qv = 0, qu = 0;
-    constexpr uint32_t kMask = kQueueCap - 1;
+     *   [qh, qv)  passed both filter levels, waiting for a walker lane */
+    uint32_t qh = 0, qv = 0;
+    constexpr uint32_t kMask = kQCap - 1;
     /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    /* always-on counters of this wave (scalar adds), summed into a.work[kStatsWord..] at kernel end */
+    uint32_t stRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0;
 #if PFAC_STATS
-    uint32_t stIters = 0, stRounds = 0, stFullRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stVerified = 0, stStartDead = 0, stSlotGathers = 0, stWinLoads = 0;
+    uint32_t stFullRounds = 0, stSlotGathers = 0, stWinLoads = 0, stStartDead = 0;
 #endif
-
-    /* filter level 2 over the pending entries, 64 at a time, compacting the survivors in place:
-     * the walk survives four transitions, or a pattern of length <= 3 can match here */
-    auto verifyPending = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t w = qv;
-        for (uint32_t r = qv; r != qu; r = uni(r + (qu - r < 64 ? qu - r : 64))) {
-            const uint32_t idx = r + lane;
-            const bool act = (uint32_t)lane < qu - r;
-            u32x4 e = {0u, 0u, 0u, 0u};
-            if (act) e = queue[idx & kMask];
-            const uint32_t x = e.y;
-            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4) & testBit(sGram4, (x * pfac::kGram4Mul2) >> lds.shift4);
-            pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
-            if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
-#if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
-            pass = (((e.x * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
-#endif
-            const bool keep = act && pass != 0;
-            const uint64_t keepMask = __ballot(keep);
-            const uint32_t at = w + laneRankIn(keepMask);        /* at <= idx: in-place compaction is safe */
-            if (keep) queue[at & kMask] = e;
-            w = uni(w + (uint32_t)__popcll(keepMask));
-        }
-#if PFAC_STATS
-        stVerified += w - qv;
-#endif
-        qv = qu = uni(w);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    };
 
     /* Reporting a finished walk.  Zero stores and walker loads of one wave complete in issue order (a
-     * single in-order vmcnt counter), and a walk that ends in consume() has just consumed loads issued
-     * behind its chunk's zero stores, so its patch lands on top of the zero.  A walk that ends in
-     * start() (resolved from LDS alone) drains this wave's stores first.
+     * single in-order vmcnt counter on gfx9-family hardware), and a walk that ends in consume() has just
+     * consumed loads issued behind its chunk's zero stores, so its patch lands on top of the zero.  A walk
+     * that ends in start() (resolved from LDS alone) drains this wave's stores first.
      * REDUCE: results are staged per wave in LDS and flushed with one atomic per kReduceCap pairs
      * (a single device counter saturates at ~90 increments/us; pattern-dense input has 10^5..10^6 matches) */
     uint32_t *rPos = sReduceAll + wave * (2 * kReduceCap);
@@ -592,13 +582,14 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     };
     auto walkIssue = [&]() {
 #pragma unroll
-        for (int s = 0; s < kWalkSets; s++)
+        for (int s = 0; s < kWalkSets; s++) {
             if (alive[s]) walk[s].issue(wctx);
-#if PFAC_STATS
+            stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
+        }
         stRounds++;
+#if PFAC_STATS
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
-            stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
             if constexpr (kHashed) {
                 stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needSlot));
                 stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
@@ -629,12 +620,13 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                 if (take) cont = walk[s].start(wctx, queue[(qh + rank) & kMask]);
                 report(take & !cont, walk[s], s, false);
                 alive[s] = alive[s] | cont;
-                const uint32_t taken = (uint32_t)__popcll(idle);
+                const uint32_t idleLanes = (uint32_t)__popcll(idle);
+                const uint32_t taken = idleLanes < qv - qh ? idleLanes : qv - qh;
+                stStarts += taken;
 #if PFAC_STATS
-                stStarts += taken < qv - qh ? taken : qv - qh;
                 stStartDead += (uint32_t)__popcll(__ballot(take & !cont));
 #endif
-                qh = uni(qh + (taken < qv - qh ? taken : qv - qh));
+                qh = uni(qh + taken);
             }
         }
         stagePending();
@@ -645,172 +637,189 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         for (int s = 0; s < kWalkSets; s++) any |= alive[s];
         return __ballot(any) != 0;
     };
-    auto appendHit = [&](const u32x4 &entry, bool has) {
-        if (qu - qh + 64 > kQueueCap) {
-            verifyPending();
-            while (qu - qh + 64 > kQueueCap) {   /* full: walk until there is room (walks are in flight here) */
-                walkConsume(); walkRefill(); walkIssue();
-#if PFAC_STATS
-                stFullRounds++;
-#endif
-            }
-        }
-        const uint64_t m = __ballot(has);
-        if (m) {
-            const uint32_t at = (qu + laneRankIn(m)) & kMask;
-            if (has) queue[at] = entry;
-            qu = uni(qu + (uint32_t)__popcll(m));
-#if PFAC_STATS
-            stHits += (uint32_t)__popcll(m);
-#endif
-        }
-    };
 
-    /* Chunks are handed out dynamically and IN ORDER: the input is cut into (up to) kWorkParts parts,
-     * block b serves part b % parts, and a wave takes the next chunk of its part from a device counter.
-     * All waves of a part therefore work inside a window of a few hundred KiB that moves linearly
-     * through memory -- what the hardware does for a grid of small blocks, and worth ~10 % of HBM
-     * throughput over a static grid-stride assignment (profiles/r01_stream_probe2_ordering.txt); it
-     * also balances the load.  (Workgroups are dealt round-robin to the 8 XCDs, so the blocks that
-     * share a counter share an L2.)  The counter value for the chunk after next is requested while
-     * the current chunk is processed.
-     * Every path of the loop issues the same vector-memory instructions (the prefetch past the end of
-     * the part is clamped, not skipped), which keeps the compiler's wait counts exact. */
+    /* Chunks are handed out dynamically and IN ORDER: block b serves part b % parts, and a wave takes the
+     * next chunk of its part from a device counter.  With PFAC_FRONT_LOG2 = 0 a part is a contiguous
+     * 1/parts of the input: all waves of a part work inside a window of a few hundred KiB that moves
+     * linearly through its part.  With G > 0 granules of 2^G chunks are dealt round-robin to the parts,
+     * so the whole grid works inside ONE window that sweeps the input once (two streams -- input and
+     * result -- instead of 2 x parts streams at power-of-two distances).  Either way it is what the
+     * hardware does for a grid of small blocks, worth ~10 % of HBM throughput over a static grid-stride
+     * assignment (profiles/r01_stream_probe2_ordering.txt), and it balances the load.  (Workgroups are
+     * dealt round-robin to the 8 XCDs, so the blocks that share a counter share an L2.)  The counter
+     * value for the chunk after next is requested while the current chunk is processed. */
     const uint32_t numChunks = n / kChunkBytes;
     const uint32_t parts = gridDim.x < (uint32_t)pfac::kWorkParts ? gridDim.x : (uint32_t)pfac::kWorkParts;
     const uint32_t part = blockIdx.x % parts;
-    const uint32_t partBegin = (uint32_t)((uint64_t)numChunks * part / parts);
-    const uint32_t partEnd = (uint32_t)((uint64_t)numChunks * (part + 1) / parts);
+    constexpr uint32_t kFront = PFAC_FRONT_LOG2;
+    const uint32_t partBegin = kFront ? 0u : (uint32_t)((uint64_t)numChunks * part / parts);
+    const uint32_t chunkEnd = kFront ? numChunks : (uint32_t)((uint64_t)numChunks * (part + 1) / parts);
+    auto chunkOf = [&](uint32_t v) {                       /* v-th chunk of this block's part */
+        if (kFront) return ((((v >> kFront) * parts + part) << kFront) | (v & ((1u << kFront) - 1u)));
+        return partBegin + v;
+    };
     unsigned int *const counter = a.work + part * 32;
     auto grab = [&]() {                                    /* lane 0 holds the answer */
         unsigned int v = 0;
         if (lane == 0) v = atomicAdd(counter, 1u);
         return v;
     };
+    /* the chunk's tiles, 1 KiB per instruction, and the 16 bytes behind it; past the end the address is clamped,
+     * not skipped: every path issues the same vector-memory instructions, which keeps the wait counts exact */
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], u32x4 &halo) {
-        const uint32_t cc = c < partEnd ? c : partEnd - 1;
+        const uint32_t cc = c < chunkEnd ? c : chunkEnd - 1;
         const uint32_t q = cc * (kChunkBytes / 16);
 #pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];      /* 1 KiB per instruction */
-        halo = in128[(cc + 1) * (kChunkBytes / 16)];                                  /* the 16 bytes behind the chunk */
+        for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];
+        halo = in128[(cc + 1) * (kChunkBytes / 16)];
     };
 
 #if PFAC_ABLATE == 1
     uint32_t ablateSink = 0;
 #endif
-    uint32_t chunk = partBegin + uni(grab());
-    uint32_t next = partBegin + uni(grab());
+    uint32_t chunk = chunkOf(uni(grab()));
+    uint32_t next = chunkOf(uni(grab()));
     u32x4 d[kTilesPerIter];
     u32x4 halo = {0, 0, 0, 0};
-    if (chunk < partEnd) loadChunk(chunk, d, halo);
+    if (chunk < chunkEnd) loadChunk(chunk, d, halo);
 
-    while (chunk < partEnd) {
-        /* ---- 1. finish the transitions issued one iteration ago, hand idle walker lanes new positions
-         *         (first transition from LDS), start the next transition of every live walk */
+    /* The staged chunk: level-1 hits not yet listed (per lane), listed codes not yet tested [listAt, listEnd),
+     * and its position in the input.  One loop, one copy of every stage: each trip starts with a walker round;
+     * a new chunk is staged only when the previous one is completely listed and tested, and list entries are
+     * tested only while the walk queue has room for a full pass -- otherwise the trip just walks. */
+    uint32_t hits = 0;                          /* bit tt + 2 * i: position i of this lane in tile tt of the staged chunk */
+    uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
+    for (;;) {
+        /* ---- 1. finish the transitions issued one trip ago, hand idle walker lanes new positions (first
+         *         transition from LDS), start the next transition of every live walk */
         walkConsume();
         walkRefill();
         walkIssue();
-#if PFAC_STATS
-        stIters++;
-#endif
 
-        /* ---- 2. ask for the chunk after next, prefetch the next one */
-        const unsigned int afterNext = grab();
-        u32x4 nd[kTilesPerIter];
-        u32x4 nhalo;
-        loadChunk(next, nd, nhalo);
-
-        /* ---- 3. zero stores: 16 B per lane, 1 KiB contiguous per instruction */
-        if (!REDUCE) {
-            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
-            const i32x4 zero = {0, 0, 0, 0};
+        if (listAt == listEnd) {
+            if (__ballot(hits != 0) == 0) {
+                if (chunk >= chunkEnd) {
+                    if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
+                } else {
+                    /* ---- 2. next chunk: ask for the chunk after next; zero stores, 16 B per lane, 1 KiB contiguous
+                     *         per instruction (older than every load of a walk that starts in this chunk) */
+                    const unsigned int afterNext = grab();
+                    if (!REDUCE) {
+                        i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
+                        const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
-        }
-
-        /* ---- 5. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position */
+                        for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
+                    }
+                    /* ---- 3. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position.
+                     * The chunk also goes to LDS (lane l -> bytes 16l.. of its tile, lane 0 also the 16 bytes behind
+                     * it): an entry of the walk queue needs 12 bytes from an arbitrary offset. */
 #pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++) {
-            /* the tile goes to LDS as well (lane l -> bytes 16l.., lane 0 also the 16 bytes behind the tile):
-             * a queue entry needs 12 bytes from an arbitrary offset, and picking them out of registers costs
-             * a dozen selects per append round -- issue slots are what this loop is short of */
-            const u32x4 behind = (t + 1 < kTilesPerIter) ? d[(t + 1) % kTilesPerIter] : halo;     /* lane 0's copy is the right one */
-            reinterpret_cast<u32x4 *>(stage)[lane] = d[t];
-            if (lane == 0) reinterpret_cast<u32x4 *>(stage)[64] = behind;
-            const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
-            uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
-            const uint32_t wrap = (t + 1 < kTilesPerIter) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)behind.x) : behind.x;
-            if (lane == 63) nxtLane = wrap;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            uint32_t hits = 0;
+                    for (int tt = 0; tt < kTilesPerIter; tt++) {
+                        reinterpret_cast<u32x4 *>(stage)[tt * 64 + lane] = d[tt];
+                        const uint32_t dw[4] = {d[tt].x, d[tt].y, d[tt].z, d[tt].w};
+                        uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
+                        const u32x4 &follow = (tt + 1 < kTilesPerIter) ? d[(tt + 1) % kTilesPerIter] : halo;   /* lane 0's copy is the right one */
+                        const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow.x);
+                        if (lane == 63) nxtLane = wrap;
+                        /* kBatch positions at a time (that many LDS reads in flight); the scheduling barrier keeps the
+                         * batches apart, or their temporaries pile up past the register budget */
+                        constexpr int kBatch = HAS_SHORT ? 4 : 8;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {          /* 8 positions at a time: 8 LDS reads in flight */
-                uint32_t product[8], byte[8];
+                        for (int b0 = 0; b0 < 16; b0 += kBatch) {
+                            uint32_t product[kBatch], byte[kBatch], shortWord[kBatch], xs[kBatch];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int j = half * 2 + (q >> 2), i = q & 3;
-                    const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
-                    const uint32_t x = i == 0 ? dw[j] : __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
-                    product[q] = (uint32_t)__umul24(x, pfac::kGram3Mul);       /* __umul24 returns int: shifts must be logical */
-                    byte[q] = loadHashedByteLds0(product[q], lds.shift3);
-                    if (HAS_SHORT) hits |= testBit(sShort, x & 0xFFFFu) << (half * 8 + q);
-                }
+                            for (int q = 0; q < kBatch; q++) {
+                                const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
+                                const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+                                const uint32_t x = i == 0 ? dw[j] : __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
+                                product[q] = (uint32_t)__umul24(x, pfac::kGram3Mul);       /* __umul24 returns int: shifts must be logical */
+                                byte[q] = loadHashedByteLds0(product[q], lds.shift3);
+                                if (HAS_SHORT) { xs[q] = x; shortWord[q] = sShort[(x & 0xFFFFu) >> 5]; }
+                            }
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    hits |= __builtin_amdgcn_ubfe(byte[q], __builtin_amdgcn_ubfe(product[q], lds.shift3, 3u), 1u) << (half * 8 + q);
-            }
+                            for (int q = 0; q < kBatch; q++) {
+                                uint32_t bit = __builtin_amdgcn_ubfe(byte[q], __builtin_amdgcn_ubfe(product[q], lds.shift3, 3u), 1u);
+                                if (HAS_SHORT) bit |= (shortWord[q] >> (xs[q] & 31u)) & 1u;
+                                hits |= bit << ((b0 + q) * 2 + tt);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (lane == 0) reinterpret_cast<u32x4 *>(stage)[kTilesPerIter * 64] = halo;
+                    stagedBase = chunk * kChunkBytes;
+                    /* the registers are free: prefetch the next chunk into them (a whole chunk ahead of its use; the
+                     * loads stay younger than this trip's walker loads, so consuming those does not wait for HBM) */
+                    loadChunk(next, d, halo);
+                    chunk = next;
+                    next = chunkOf(uni(afterNext));
 #if PFAC_ABLATE == 1
-            ablateSink |= hits;
-            hits = 0;
+                    ablateSink |= hits;
+                    hits = 0;
 #endif
-            /* ---- 6. append level-1 survivors (+ their first 4 bytes) to the wave's ring queue */
-            uint64_t pending = __ballot(hits != 0);
-            while (pending) {                               /* wave-uniform: max hits per lane iterations */
-                const bool has = hits != 0;
-                const uint32_t b = (uint32_t)__builtin_ctz(hits | 0x10000u);
-                const uint32_t at = ((uint32_t)lane << 2) + (b >> 2), sh = b & 3u;       /* dword of the tile the hit starts in */
-                const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3];
-                const u32x4 entry = {chunk * kChunkBytes + (uint32_t)(t * kTileBytes + (lane << 4)) + b,
-                                     __builtin_amdgcn_alignbyte(e1, e0, sh), __builtin_amdgcn_alignbyte(e2, e1, sh),
-                                     __builtin_amdgcn_alignbyte(e3, e2, sh)};
-                appendHit(entry, has);
-                if (has) hits &= hits - 1;
-                pending = __ballot(hits != 0);
+                }
             }
+            /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
+             *         counts; hits beyond the list's capacity stay in `hits` for the next round */
+            const uint32_t cnt = (uint32_t)__builtin_popcount(hits);
+            const uint32_t incl = waveInclusiveScan(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t idx = incl - cnt;
+            while (hits != 0 && idx < kListCap) {       /* divergent: as many rounds as the busiest lane has hits */
+                list[idx] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)__builtin_ctz(hits));
+                idx++;
+                hits &= hits - 1;
+            }
+            listAt = 0;
+            listEnd = total < kListCap ? total : kListCap;
+            stHits += listEnd;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (qu - qv >= 64) verifyPending();
+        /* ---- 5. one listed hit per lane: cut its 12 bytes out of the stage, filter level 2 (the walk survives
+         * four transitions, or a pattern of length <= 3 can match here), survivors -> walk queue */
+        while (listAt != listEnd && qv - qh + 64 <= kQCap) {
+            const bool act = listAt + (uint32_t)lane < listEnd;
+            const uint32_t code = act ? (uint32_t)list[listAt + lane] : 0u;
+            const uint32_t o = ((code >> 1) & 0x3FFu) | ((code & 1u) << 10);       /* byte offset inside the chunk */
+            const uint32_t at = o >> 2, sh = o & 3u;
+            const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3];
+            const uint32_t x = __builtin_amdgcn_alignbyte(e1, e0, sh);
+            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4) & testBit(sGram4, (x * pfac::kGram4Mul2) >> lds.shift4);
+            pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
+            if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
+#if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
+            pass = (((o * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
+#endif
+            const bool keep = act && pass != 0;
+            const uint64_t keepMask = __ballot(keep);
+            const u32x4 entry = {stagedBase + o, x, __builtin_amdgcn_alignbyte(e2, e1, sh), __builtin_amdgcn_alignbyte(e3, e2, sh)};
+            if (keep) queue[(qv + laneRankIn(keepMask)) & kMask] = entry;
+            qv = uni(qv + (uint32_t)__popcll(keepMask));
+            listAt = uni(listAt + 64 < listEnd ? listAt + 64 : listEnd);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #if PFAC_ABLATE == 2
         qh = qv;                                        /* timing experiment: drop the verified entries unwalked */
 #endif
-
-#pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++) d[t] = nd[t];
-        halo = nhalo;
-        chunk = next;
-        next = partBegin + uni(afterNext);
     }
 #if PFAC_ABLATE == 1
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
-
-    /* drain: no more chunks to hide behind */
-    if (qu != qv) verifyPending();
-    while (anyAlive() || qh != qv) { walkConsume(); walkRefill(); walkIssue(); }
     if (REDUCE) flushStaged();
-#if PFAC_STATS
+
+    /* counters of this launch (PFACX_getScanStats): per-wave scalars -> LDS -> one atomic per counter and block */
     __syncthreads();
-    if (tid < 16) sGram3[tid] = 0;
+    if (tid < 8) sGram3[tid] = 0;
     __syncthreads();
     if (lane == 0) {
-        atomicAdd(&sGram3[0], stIters); atomicAdd(&sGram3[1], stRounds); atomicAdd(&sGram3[2], stFullRounds);
-        atomicAdd(&sGram3[3], stLaneSteps); atomicAdd(&sGram3[4], stStarts); atomicAdd(&sGram3[5], stHits);
-        atomicAdd(&sGram3[6], stVerified); atomicAdd(&sGram3[7], stStartDead);
-        atomicAdd(&sGram3[8], stSlotGathers); atomicAdd(&sGram3[9], stWinLoads);
+        atomicAdd(&sGram3[0], stRounds); atomicAdd(&sGram3[1], stLaneSteps);
+        atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits);
     }
     __syncthreads();
-    if (tid == 0 && (blockIdx.x % 32) == 0)
-        printf("STATS block %d iters %u rounds %u fullRounds %u laneSteps %u starts %u hits %u verified %u startDead %u slotGathers %u winLoads %u\n", (int)blockIdx.x,
-               sGram3[0], sGram3[1], sGram3[2], sGram3[3], sGram3[4], sGram3[5], sGram3[6], sGram3[7], sGram3[8], sGram3[9]);
+    if (tid < pfac::kStatsCount) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
+#if PFAC_STATS
+    if (lane == 0 && (blockIdx.x % 32) == 0 && wave == 0)
+        printf("STATS block %d wave0 fullRounds %u slotGathers %u winLoads %u startDead %u\n", (int)blockIdx.x, stFullRounds, stSlotGathers, stWinLoads, stStartDead);
 #endif
 }
 
@@ -851,12 +860,12 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * (kQueueCap * 4 + kStageWords) * sizeof(uint32_t);
+    bytes += (size_t)kWavesPerBlock * ((reduce ? kReduceQueueCap : kQueueCap) * 4 + kStageWords + kListCap / 2) * sizeof(uint32_t);
     if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }
 
-int tilesPerChunk(const PFAC_context *c) { return c->filter.bitsSet >= kHeavyMinKeys ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES; }
+int tilesPerChunk(const PFAC_context *c) { return c->filter.bitsSet >= pfac::kHeavyMinKeys ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES; }
 size_t chunkBytes(const PFAC_context *c) { return (size_t)tilesPerChunk(c) * kTileBytes; }
 
 template <int MODE, bool HAS_SHORT, bool REDUCE, int TILES, int WALKS>
@@ -884,8 +893,10 @@ hipError_t launchShape(const PFAC_context *c, const ScanArgs &a)
 template <int MODE, bool HAS_SHORT, bool REDUCE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 {
-    return tilesPerChunk(c) == PFAC_HEAVY_TILES ? launchShape<MODE, HAS_SHORT, REDUCE, PFAC_HEAVY_TILES, PFAC_HEAVY_WALKS>(c, a)
-                                                : launchShape<MODE, HAS_SHORT, REDUCE, PFAC_LIGHT_TILES, PFAC_LIGHT_WALKS>(c, a);
+    /* the chained walker is 17 registers per walk: a third one per lane does not fit the 128 of a 16-wave block */
+    constexpr int kLightWalks = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER) ? PFAC_HEAVY_WALKS : PFAC_LIGHT_WALKS;
+    return c->filter.bitsSet >= pfac::kHeavyMinKeys ? launchShape<MODE, HAS_SHORT, REDUCE, PFAC_HEAVY_TILES, PFAC_HEAVY_WALKS>(c, a)
+                                                     : launchShape<MODE, HAS_SHORT, REDUCE, PFAC_LIGHT_TILES, kLightWalks>(c, a);
 }
 
 template <int MODE>
@@ -898,6 +909,17 @@ hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
     return hipGetLastError();
 }
 
+#ifdef PFAC_QUICK      /* development builds (register / ISA inspection): only the bench instances of the filter kernel */
+template <int MODE>
+hipError_t launchMode(const PFAC_context *c, const ScanArgs &a)
+{
+    if (MODE != HASH_BUFFER && MODE != DENSE_BUFFER) return hipErrorNotSupported;
+    constexpr int M = MODE == HASH_BUFFER ? HASH_BUFFER : DENSE_BUFFER;
+    return c->filter.hasShort ? launchFilter<M, true, false>(c, a) : launchFilter<M, false, false>(c, a);
+}
+template <int MODE>
+hipError_t launchReduceMode(const PFAC_context *, const ScanArgs &) { return hipErrorNotSupported; }
+#else
 template <int MODE>
 hipError_t launchMode(const PFAC_context *c, const ScanArgs &a)
 {
@@ -909,6 +931,7 @@ hipError_t launchReduceMode(const PFAC_context *c, const ScanArgs &a)
 {
     return c->filter.hasShort ? launchFilter<MODE, true, true>(c, a) : launchFilter<MODE, false, true>(c, a);
 }
+#endif
 
 uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes; }
 

@@ -53,6 +53,8 @@ def _load():
         lib.wl_fill_from_pool.restype = None
         lib.wl_fnv1a.argtypes = [C.c_void_p, C.c_uint64]
         lib.wl_fnv1a.restype = C.c_uint64
+        lib.wl_fnv1a_sparse_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        lib.wl_fnv1a_sparse_i32.restype = C.c_uint64
         _lib = lib
     return _lib
 
@@ -60,6 +62,14 @@ def _load():
 def fnv1a(data: np.ndarray) -> int:
     data = np.ascontiguousarray(data).view(np.uint8)
     return int(_load().wl_fnv1a(data.ctypes.data, data.size))
+
+
+def fnv1a_sparse_i32(positions, ids, n: int) -> int:
+    """FNV-1a-64 of the int32 vector of n elements that is `ids` at `positions` (ascending) and 0 elsewhere."""
+    pos = np.ascontiguousarray(positions, dtype=np.int64)
+    val = np.ascontiguousarray(ids, dtype=np.int32)
+    assert pos.size == val.size and (pos.size == 0 or (pos[0] >= 0 and pos[-1] < n and np.all(np.diff(pos) > 0)))
+    return int(_load().wl_fnv1a_sparse_i32(pos.ctypes.data, val.ctypes.data, pos.size, n))
 
 
 # ----------------------------------------------------------------------------- patterns

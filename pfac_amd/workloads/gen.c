@@ -74,3 +74,28 @@ uint64_t wl_fnv1a(const uint8_t *p, uint64_t n)
     for (uint64_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ULL; }
     return h;
 }
+
+
+static uint64_t pow_u64(uint64_t b, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) { if (e & 1) r *= b; b *= b; e >>= 1; }
+    return r;
+}
+
+/* FNV-1a 64 over the little-endian int32 vector of n elements that is zero everywhere except
+ * v[pos[i]] = ids[i] (pos ascending): a zero byte only multiplies the state by the FNV prime, so a run
+ * of zeros is one modular power.  Lets a test pin a 4 GiB result vector from its sparse form. */
+uint64_t wl_fnv1a_sparse_i32(const int64_t *pos, const int32_t *ids, uint64_t count, uint64_t n)
+{
+    const uint64_t P = 0x100000001b3ULL;
+    uint64_t h = 0xcbf29ce484222325ULL, prev = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        const uint64_t p = (uint64_t)pos[i];
+        h *= pow_u64(P, 4 * (p - prev));
+        uint32_t v = (uint32_t)ids[i];
+        for (int j = 0; j < 4; j++) { h ^= (v >> (8 * j)) & 0xFF; h *= P; }
+        prev = p + 1;
+    }
+    return h * pow_u64(P, 4 * (n - prev));
+}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab.sh <variant.so> ...  -- bench pre-built kernel modules against each other on the GPU box.
-# Variants are built here (hipcc cross-compiles) into variants/<name>.so; the script swaps each one in
-# as pfac_amd/lib/libpfac_gfx950.so (and variants/libpfac_<name>.so as the host library, if present) and
+# Variants are built in the container (tools/build_variants.sh) into tools/bin/variants/<name>.so; the script swaps each one in
+# as pfac_amd/lib/libpfac_gfx950.so (and tools/bin/variants/libpfac_<name>.so as the host library, if present) and
 # prints one line per workload: min / median kernel ms over REPEAT processes (run-to-run spread of one
 # build is +-5 % on this pool, so single runs cannot rank variants).
 WL=${WL:-"c3 c2"}; REPEAT=${REPEAT:-3}
@@ -9,11 +9,11 @@ for r in $(seq $REPEAT); do
   for so in "$@"; do
     name=$(basename $so .so)
     [ "$so" -ef pfac_amd/lib/libpfac_gfx950.so ] || cp "$so" pfac_amd/lib/libpfac_gfx950.so
-    [ -f variants/libpfac_$name.so ] && cp variants/libpfac_$name.so pfac_amd/lib/libpfac.so
+    [ -f tools/bin/variants/libpfac_$name.so ] && cp tools/bin/variants/libpfac_$name.so pfac_amd/lib/libpfac.so
     for w in $WL; do
       extra=""; ww=$w
       case $w in c5h) ww=c5; extra="--perf-mode hash";; esac
-      python bench.py --steps ${STEPS:-20} --warmup 3 --workload $ww $extra --no-cpu-baseline $EXTRA 2>/dev/null | python -c "
+      python bench.py --steps ${STEPS:-20} --warmup 3 --workload $ww $extra --no-cpu-baseline --no-other-configs --pmc off $EXTRA 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$name', '$w', r['kernel_ms_avg'], d['config']['bit_exact'], (d.get('reduce_api') or {}).get('ms_per_call'))" >> /tmp/ab_raw.txt

@@ -1,0 +1,8 @@
+#!/bin/bash
+O=gpurun_out/r02c; mkdir -p $O; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.txt
+cp pfac_amd/lib/libpfac_gfx950.so /tmp/keep.so
+REPEAT=3 WL="c3 c2 c5h" timeout 1500 tools/ab.sh tools/bin/variants/base.so tools/bin/variants/new.so tools/bin/variants/t768.so tools/bin/variants/front4.so tools/bin/variants/q256.so > $O/ab.txt 2>&1
+timeout 600 tools/pmc_mini.sh tools/bin/variants/base.so tools/bin/variants/new.so > $O/pmc_mini.txt 2>&1
+cp /tmp/keep.so pfac_amd/lib/libpfac_gfx950.so
+tail -3 $O/pytest_gpu.txt; cat $O/ab.txt; cat $O/pmc_mini.txt

@@ -9,7 +9,7 @@ timeout 300 python bench.py --workload c5 --perf-mode hash --cpu-seconds 5 > $O/
 timeout 300 python bench.py --variant naive --no-cpu-baseline --steps 5 > $O/bench_c3_naive.json 2> /dev/null
 timeout 300 python bench.py --workload c2 --variant naive --no-cpu-baseline --steps 5 > $O/bench_c2_naive.json 2> /dev/null
 for w in c3 c2; do
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o prof -- python3 bench.py --workload $w --no-cpu-baseline > $O/bench_${w}_under_rocprof.json 2> $O/prof_$w.err
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o prof -- python3 bench.py --worker rank --workload $w --no-other-configs > $O/bench_${w}_under_rocprof.json 2> $O/prof_$w.err
   timeout 400 tools/pmc_traffic.sh $w $O/traffic_$w > $O/traffic_$w.log 2>&1
 done
 grep -h '"metric"' $O/bench_*.json | python3 -c "

@@ -14,7 +14,7 @@ for so in "$@"; do
   i=0
   for set in "${SETS[@]}"; do
     i=$((i+1))
-    timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -o s$i -- python3 bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-verify > $OUT/s$i.json 2> $OUT/s$i.err
+    timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -o s$i -- python3 bench.py --worker pmc --workload $W --no-verify > $OUT/s$i.json 2> $OUT/s$i.err
   done
 done
 python3 - "$@" <<'PY'

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 for so in "$@"; do
   name=$(basename $so .so); cp $so pfac_amd/lib/libpfac_gfx950.so
   OUT=gpurun_out/pmc_mini/$name; mkdir -p $OUT
-  timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/s1 -o s1 -- python3 bench.py --steps 3 --warmup 1 --workload c3 --no-cpu-baseline --no-verify > $OUT/s1.json 2> $OUT/s1.err
+  timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/s1 -o s1 -- python3 bench.py --worker pmc --workload c3 --no-verify > $OUT/s1.json 2> $OUT/s1.err
 done
 python3 - "$@" <<'PY'
 import csv, glob, collections, sys, os

@@ -4,7 +4,7 @@ W=$1; OUT=$2; shift 2; mkdir -p $OUT; export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -o s$i -- python3 bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-verify > $OUT/s$i.json 2> $OUT/s$i.err
+  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -o s$i -- python3 bench.py --worker pmc --workload $W --no-verify > $OUT/s$i.json 2> $OUT/s$i.err
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys

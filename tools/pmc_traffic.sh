@@ -7,7 +7,7 @@ W=$1; OUT=$2; mkdir -p $OUT /tmp/pb
 export TMPDIR=/tmp PATH=/opt/rocm/bin:$PATH
 hipcc -O3 --offload-arch=gfx950 -o /tmp/pb/stream_probe tools/stream_probe.hip > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/scan_$c -o scan -- python3 bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline --no-verify > $OUT/scan_$c.json 2> $OUT/scan_$c.err
+  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/scan_$c -o scan -- python3 bench.py --worker pmc --workload $W --no-verify > $OUT/scan_$c.json 2> $OUT/scan_$c.err
   timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/probe_$c -o probe -- /tmp/pb/stream_probe > $OUT/probe_$c.log 2> $OUT/probe_$c.err
 done
 python3 - "$OUT" "$W" <<'PY'

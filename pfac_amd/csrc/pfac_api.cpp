@@ -99,11 +99,20 @@ PFAC_status_t upload(T *&dst, const T *src, size_t count)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* upload the chained device form of the hashed table (tables.cpp: buildChainedHashTable) */
+/* Upload the chained device form of the hashed table (tables.cpp: buildChainedHashTable): what the scan kernel
+ * walks in BOTH perf modes.  In PFAC_TIME_DRIVEN mode the hashed layout it derives from is built here and
+ * dropped again: the handle's reference-layout table (PFACX_getTable, the dump, the simple kernel) stays dense. */
 PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 {
     std::vector<pfac::ChainSlot> slots, root;
-    PFAC_status_t st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, slots, root);
+    PFAC_status_t st;
+    if (c->perfMode == PFAC_SPACE_DRIVEN) {
+        st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, slots, root);
+    } else {
+        std::vector<Int2> rowPtr, valPtr;
+        st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
+        if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, slots, root);
+    }
     if (st != PFAC_STATUS_SUCCESS) return st;
     c->numChainSlots = slots.size();
     st = upload(c->d_chainSlots, slots.data(), slots.size());
@@ -126,6 +135,7 @@ PFAC_status_t bindTable(PFAC_context *c)
         c->sizeOfTableInBytes = c->numOfTableEntry * c->sizeOfTableEntry;
         if (c->hasDevice && !c->d_dense) {
             st = upload(c->d_dense, c->h_dense.data(), c->h_dense.size());
+            if (st == PFAC_STATUS_SUCCESS) st = uploadChainedHashTable(c);
             if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
         }
     } else {
@@ -595,9 +605,8 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
         hipMemcpy(v, handle->d_workCounters + pfac::kStatsWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;
     stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
-    const bool heavy = handle->filter.bitsSet >= pfac::kHeavyMinKeys;
-    stats->tilesPerChunk = heavy ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES;
-    stats->walksPerLane = (heavy || handle->perfMode == PFAC_SPACE_DRIVEN) ? PFAC_HEAVY_WALKS : PFAC_LIGHT_WALKS;
+    stats->tilesPerChunk = pfac::kChunkTiles;
+    stats->walksPerLane = PFAC_WALK_SETS;
     return PFAC_STATUS_SUCCESS;
 }
 

@@ -36,21 +36,11 @@ constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel ha
 constexpr int kWorkCounterWords = 64 * 32;   /* one counter per 128-byte line */
 constexpr int kStatsWord = 1536;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 4;                  /* walker rounds, lane steps, walks started, level-1 hits */
-/* Loop shapes of the scan kernel (scan_gfx950.hip), picked by the size of the level-1 key set: LIGHT = 2 KiB
- * chunks and 3 walks per lane, HEAVY (>= kHeavyMinKeys distinct 3-byte prefixes) = 4 KiB chunks and 2 walks */
-#ifndef PFAC_LIGHT_TILES
-#define PFAC_LIGHT_TILES 2
+/* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
+#ifndef PFAC_WALK_SETS
+#define PFAC_WALK_SETS 2                       /* independent walks per lane */
 #endif
-#ifndef PFAC_LIGHT_WALKS
-#define PFAC_LIGHT_WALKS 3
-#endif
-#ifndef PFAC_HEAVY_TILES
-#define PFAC_HEAVY_TILES 2
-#endif
-#ifndef PFAC_HEAVY_WALKS
-#define PFAC_HEAVY_WALKS 2
-#endif
-constexpr size_t kHeavyMinKeys = 4096;
+constexpr int kChunkTiles = 2;                 /* KiB of input a wave stages at a time */
 constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
 /* 16-byte device slot of the chained hashed table: one gathered 16-byte load per transition.
  * meta = edge byte | chain length << 8 | flags | k << 15 | (S-1) << 24, where {k, S} are the hash

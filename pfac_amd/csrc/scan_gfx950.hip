@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -201,8 +202,6 @@ __device__ __forceinline__ uint32_t loadHashedByteLds0(uint32_t product, uint32_
 /* LDS view of one block */
 struct Lds {
     const uint32_t *gram3, *gram4, *final3, *shortBits;
-    const int *init;                           /* dense modes: transition row of the initial state   */
-    const u32x4 *root;                         /* hashed modes: ChainSlot[256] of the initial state  */
     uint32_t shift3, shift4, shiftF3;
 };
 
@@ -213,20 +212,11 @@ __device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos
     return *reinterpret_cast<const u32x4_a4 *>(in32 + (pos >> 2));
 }
 
-/* 4 bytes of a 16-byte window starting at byte offset o (0..12) */
-__device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
-{
-    const uint32_t j = o >> 2;
-    const uint32_t lo = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-    const uint32_t hi = j == 0 ? w.y : j == 1 ? w.z : w.w;          /* j == 3 only with (o & 3) == 0 */
-    return __builtin_amdgcn_alignbyte(hi, lo, o & 3u);
-}
-
 /*
- * Walkers are split-phase: issue() starts the loads of the next transition, consume() finishes it.
- * Each lane runs 2 or 3 independent walks; all of them issue at the top of a scan iteration, right
- * before the chunk prefetch and the zero stores, and are consumed at the top of the next one, so one
- * memory round trip covers up to 192 table steps and hides behind a whole chunk of filter work.
+ * Walkers are split-phase: issue() starts the load of the next transition, consume() finishes it.
+ * Each lane runs kWalkSets independent walks; all of them issue at the top of a trip of the scan loop
+ * and are consumed at the top of the next one, so one memory round trip covers up to 64 x kWalkSets
+ * table steps and hides behind a whole chunk of filter work.
  *
  * What is scarce on pattern-dense input is gathered loads, then instruction issue:
  * a step is written as straight-line selects (every early `return` costs exec-mask bookkeeping for
@@ -234,82 +224,25 @@ __device__ __forceinline__ uint32_t windowDword(const u32x4 &w, uint32_t o)
  * maxPatternLen + 32 bytes of the input to the simple kernel, so a walk that starts in this kernel's
  * range can neither run past the input nor load past it.
  *
- * DENSE walkers (ref PFAC_kernel.cu:255-299): one 4-byte gather per byte.  Input bytes come 8 at a
- * time (first with the queue entry, then fetched together with the step that uses the last one).
+ * Both table modes walk the CHAINED table (tables.cpp: buildChainedHashTable): a device-only copy of the
+ * reference's hashed table with 16-byte slots.  A step consumes the edge byte plus the slot's
+ * single-successor chain (up to 7 bytes) with one dependent memory round trip and ONE gathered load (the
+ * reference's dense walk needs one per byte, its hashed walk two: PFAC_kernel.cu:255-299,
+ * PFAC_kernel_spaceDriven.cu:76-124).  Gathered loads that miss the L1 cost ~2.3 cycles per lane on a
+ * CU whatever their size (tools/gather_probe.hip), hence the packed slot.  The input comes with the
+ * walk: the queue entry carries the 20 bytes from the start position, which is where 99.9 % of the walks
+ * of the Snort-style workload end (84 % within 16, 62 % within 12); only a walk that outruns them loads
+ * input, 16 bytes at a time.
  */
-template <int MODE> struct DenseCtx {
-    static_assert(MODE == DENSE_GLOBAL || MODE == DENSE_BUFFER, "dense walker");
-    const Lookup<MODE> lookup;
-    const uint32_t *in32;
-    uint32_t numFinal;
-    const int *sInit;
-    __device__ DenseCtx(const ScanArgs &a, const Lds &lds)
-        : lookup(a), in32(reinterpret_cast<const uint32_t *>(a.in)), numFinal((uint32_t)a.numFinal), sInit(lds.init) {}
-};
-
-template <int MODE> struct DenseLane {
-    using Ctx = DenseCtx<MODE>;
-    uint32_t pos = 0;
-    int state = kTrap, match = 0;
-    uint32_t depth = 0, have = 0;              /* have = input bytes left in win (>= 1 while the walk is alive) */
-    uint64_t win = 0;
-    /* in flight */
-    int loadedState = kTrap;
-    u32x4 loadedWindow = {0, 0, 0, 0};
-    bool refilling = false;                    /* the step in flight uses the last byte of win: the next 8 bytes are in flight too */
-
-    /* The first transition comes from the initial-state row in LDS (ref phi_s02s1,
-     * PFAC_kernel.cu:259) and is taken right here; returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &entry)
-    {
-        pos = entry.x; refilling = false;
-        state = c.sInit[entry.y & 0xFF];
-        match = (uint32_t)(state - 1) < c.numFinal ? state : 0;       /* final states are 1..F; trap is -1 */
-        win = ((uint64_t)__builtin_amdgcn_alignbyte(entry.w, entry.z, 1) << 32) | __builtin_amdgcn_alignbyte(entry.z, entry.y, 1);
-        have = 8; depth = 1;                                           /* bytes pos+1 .. pos+8 came with the queue entry */
-        return state != kTrap;
-    }
-    __device__ __forceinline__ void issue(const Ctx &c)
-    {
-        int s = c.lookup(state, (int)(win & 0xFF));
-        if (MODE == DENSE_BUFFER && s == 0) s = kTrap;         /* out-of-range clamp of the descriptor */
-        loadedState = s;
-        refilling = have == 1;
-        if (refilling) loadedWindow = loadWindow16(c.in32, pos + depth + 1);   /* the 8 bytes behind the one being used */
-    }
-    /* false = the walk is over (trap) */
-    __device__ __forceinline__ bool consume(const Ctx &c)
-    {
-        state = loadedState;
-        match = (uint32_t)(state - 1) < c.numFinal ? state : match;
-        win >>= 8; have--; depth++;
-        if (refilling) {
-            const uint32_t o = (pos + depth) & 3u;
-            win = ((uint64_t)windowDword(loadedWindow, o + 4) << 32) | windowDword(loadedWindow, o);
-            have = 8;
-        }
-        return state != kTrap;
-    }
-};
-
-/*
- * CHAINED hashed table walkers (tables.cpp: buildChainedHashTable).  A step consumes the edge byte
- * plus the slot's single-successor chain (up to 7 bytes) with one dependent memory round trip and two
- * gathered 16-byte loads: the slot and the aligned input window behind the edge byte, which always
- * contains the chain and the edge byte of the NEXT step (3 + 7 + 1 <= 16 bytes).  Gathered loads that
- * miss the L1 cost ~2.3 cycles per lane on a CU whatever their size (tools/gather_probe.hip), hence
- * the packed slot.
- */
-template <int MODE> struct ChainCtx {
-    static_assert(MODE == HASH_GLOBAL || MODE == HASH_BUFFER, "chained walker");
+template <bool TEX> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
     const u32x4 *sRoot;
     const uint32_t *in32;
-    __device__ ChainCtx(const ScanArgs &a, const Lds &lds)
+    __device__ ChainCtx(const ScanArgs &a, const u32x4 *rootInLds)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(lds.root), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
+          sRoot(rootInLds), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
 };
 
 /* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
@@ -321,30 +254,35 @@ __device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
     return min(r, r + (uint32_t)pfac::kHashP) & (ks >> 9);      /* a negative r is huge as unsigned: picks r + 257 */
 }
 
-template <int MODE> struct ChainLane {
-    using Ctx = ChainCtx<MODE>;
+constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brings along */
+
+template <bool TEX> struct ChainLane {
+    using Ctx = ChainCtx<TEX>;
     uint32_t pos = 0;
     uint32_t row = 0;                          /* first slot of the current state's bucket */
     int match = 0;
     uint32_t ks = 0, b0 = 0, depth = 0;
-    /* The 16-byte input window stays in registers across steps (wpos = position of its first byte) and
-     * is only re-fetched when a MATCHING slot needs bytes beyond it: gathered loads are what bounds
-     * the kernel on pattern-dense input (each costs as much as ~60 ALU instructions, tools/ab.sh
-     * sensitivity runs), and the step that ends a walk -- a slot for some other byte -- needs none. */
-    u32x4 t = {0, 0, 0, 0}, w = {0, 0, 0, 0};
-    uint32_t wpos = 0, wend = 0;               /* the window holds input bytes [wpos, wend) */
+    /* The input window stays in registers across steps: five dwords that hold the bytes [wend - 20, wend).
+     * It starts as the queue entry's 20 bytes and is only re-fetched (16 bytes into W1..W4) when a MATCHING
+     * slot needs bytes beyond it: the step that ends a walk -- a slot for some other byte -- needs none. */
+    u32x4 t = {0, 0, 0, 0};
+    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0;
+    uint32_t wend = 0;
     bool needWin = false, needSlot = true;
     uint32_t refetches = 0;                    /* a walk that outran its window twice fetches one every step from then on */
 
-    /* input bytes q .. q+7 out of the window (q - wpos in 0..15; bytes beyond the window read as 0) */
+    /* input bytes q .. q+7 out of the window (q - (wend - 20) in 0..19; bytes beyond the window are garbage:
+     * callers only use bytes below wend).  A three-level binary shifter on the dword number: selects, no
+     * branches -- as a `switch` this is a dozen exec-mask regions. */
     __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
     {
-        const uint32_t o = q - wpos, j = o >> 2;
-        const uint32_t lo = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-        const uint32_t mid = j == 0 ? w.y : j == 1 ? w.z : j == 2 ? w.w : 0u;
-        const uint32_t hi = j == 0 ? w.z : j == 1 ? w.w : 0u;
-        x0 = __builtin_amdgcn_alignbyte(mid, lo, o & 3u);
-        x1 = __builtin_amdgcn_alignbyte(hi, mid, o & 3u);
+        const uint32_t o = q - (wend - kEntryBytes);
+        const bool b1 = (o & 4u) != 0, b2 = (o & 8u) != 0, b4 = (o & 16u) != 0;
+        const uint32_t T0 = b1 ? W1 : W0, T1 = b1 ? W2 : W1, T2 = b1 ? W3 : W2, T3 = b1 ? W4 : W3, T4 = b1 ? 0u : W4;
+        const uint32_t U0 = b2 ? T2 : T0, U1 = b2 ? T3 : T1, U2 = b2 ? T4 : T2;
+        const uint32_t lo = b4 ? W4 : U0;
+        x0 = __builtin_amdgcn_alignbyte(U1, lo, o & 3u);
+        x1 = __builtin_amdgcn_alignbyte(U2, U1, o & 3u);
     }
 
     /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0, given the input
@@ -354,10 +292,11 @@ template <int MODE> struct ChainLane {
     __device__ __forceinline__ bool advance(const u32x4 &s, uint32_t x0, uint32_t x1)
     {
         const uint32_t meta = s.x;
-        const uint32_t len = (meta >> 8) & 0xFu;
+        const uint32_t len = (meta >> 8) & 0xFu;               /* <= kChainMax = 7 */
         const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
-        /* the slot is this byte's (not empty, not another byte's), and the chain matches the input */
-        const bool ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & ((len == 0) | ((diff << (64u - 8u * len)) == 0));
+        /* the slot is this byte's (not empty, not another byte's), and the first len chain bytes equal the
+         * input: two shifts by less than 64 each, so that len == 0 shifts everything out */
+        const bool ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & (((diff << 8) << (56u - 8u * len)) == 0);
         const bool leaf = (meta & pfac::kSlotLeaf) != 0;
         const int id = (int)(leaf ? s.y : s.w);                /* kSlotFinal: see pfac::ChainSlot */
         match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
@@ -368,28 +307,28 @@ template <int MODE> struct ChainLane {
         return ok & !leaf;
     }
 
-    /* The slots of the initial state live in LDS and the queue entry brings input bytes pos..pos+11,
-     * so the first transition is taken right here without touching memory; those twelve bytes are
-     * also the walk's first window.  Returns false if the walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &entry)
+    /* The slots of the initial state live in LDS and the queue entry {position, 20 input bytes} is the walk's
+     * first window, so the first transition is taken right here without touching memory.  Returns false if the
+     * walk is already over. */
+    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1)
     {
-        pos = entry.x; match = 0; depth = 0; b0 = entry.y & 0xFF;
-        w = u32x4{entry.y, entry.z, entry.w, 0u};
-        wpos = pos; wend = pos + 12u;
+        pos = ea.x; match = 0; depth = 0; b0 = ea.y & 0xFF;
+        W0 = ea.y; W1 = ea.z; W2 = ea.w; W3 = eb0; W4 = eb1;
+        wend = pos + kEntryBytes;
         needWin = false; needSlot = true; refetches = 0;
-        return advance(c.sRoot[b0], __builtin_amdgcn_alignbyte(entry.z, entry.y, 1), __builtin_amdgcn_alignbyte(entry.w, entry.z, 1));
+        return advance(c.sRoot[b0], __builtin_amdgcn_alignbyte(ea.z, ea.y, 1), __builtin_amdgcn_alignbyte(ea.w, ea.z, 1));
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
         if (needSlot) {
             const uint32_t idx = row + chainHashSlot(ks, b0);
-            if (MODE == HASH_BUFFER) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+            if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
             else t = c.slots[idx];
         }
-        if (needWin) {
-            w = loadWindow16(c.in32, pos + depth + 1);         /* pos + depth = position of the edge byte b0 */
-            wpos = (pos + depth + 1) & ~3u;
-            wend = wpos + 16u;
+        if (needWin) {                                         /* rare: the walk is more than 20 bytes deep */
+            const u32x4 w = loadWindow16(c.in32, pos + depth + 1);     /* pos + depth = position of the edge byte b0 */
+            W1 = w.x; W2 = w.y; W3 = w.z; W4 = w.w;
+            wend = ((pos + depth + 1) & ~3u) + 16u;
         }
     }
     __device__ __forceinline__ bool consume(const Ctx &)
@@ -410,10 +349,6 @@ template <int MODE> struct ChainLane {
     }
 };
 
-template <int MODE> struct WalkTypes { using Ctx = DenseCtx<MODE>; using Lane = DenseLane<MODE>; };
-template <> struct WalkTypes<HASH_GLOBAL> { using Ctx = ChainCtx<HASH_GLOBAL>; using Lane = ChainLane<HASH_GLOBAL>; };
-template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; using Lane = ChainLane<HASH_BUFFER>; };
-
 /* --------------------------------------------------------- filter kernel */
 
 #ifndef PFAC_ABLATE
@@ -429,21 +364,55 @@ template <> struct WalkTypes<HASH_BUFFER> { using Ctx = ChainCtx<HASH_BUFFER>; u
 /* Level-1 survivors are handled per GROUP of two tiles: the group is staged in LDS (+ the 16 bytes behind
  * it), every lane's hits go to a per-wave list of 16-bit codes, and 64 list entries at a time are cut out
  * of the stage, tested against level 2 and appended to the walk queue -- one entry per lane. */
-constexpr int kGroupTiles = 2;
+constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
-constexpr int kStageWords = (kGroupBytes + 16) / 4;
+constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
 #ifndef PFAC_LIST_CAP
-#define PFAC_LIST_CAP 128
+#define PFAC_LIST_CAP 96
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one group take another pass */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
-constexpr uint32_t kReduceQueueCap = kQueueCap < 64 ? kQueueCap : 64;   /* ... which takes the LDS of half the walk queue */
-/* In-order chunk hand-out: 0 = the input is cut into kWorkParts contiguous parts, one
- * counter each; G > 0 = one moving front: granules of 2^G chunks are dealt round-robin to the parts, so
- * all parts work inside one window of parts << G chunks that sweeps the input once. */
+constexpr int kReduceScanners = kWavesPerBlock - 4;   /* ... whose LDS comes from leaving four waves of the block without work */
+/* In-order hand-out of the input: -1 = the input is cut into kWorkParts contiguous parts, one
+ * counter each; G >= 0 = one moving front: granules of 2^G pieces are dealt round-robin to the parts, so
+ * all parts work inside one window of parts << G pieces that sweeps the input once. */
 #ifndef PFAC_FRONT_LOG2
-#define PFAC_FRONT_LOG2 0
+#define PFAC_FRONT_LOG2 2
 #endif
+
+/* Zero-fill by dedicated WRITER waves (full-result kernel only).  The API writes 4 bytes per input byte, almost
+ * all zero, and that stream does not depend on the input.  Issued by the scanning waves themselves it ties
+ * their progress to the store path: a wave that waits for room in the store queue is not filtering, and with 4
+ * waves per SIMD there is little else to run.  So the last kWriters waves of a block do nothing but zero-fill:
+ * a writer claims the next SPAN (kSpanChunks chunks) of the block's part, fills its results with zeros, waits
+ * until the stores have reached L2 and publishes the span in an LDS ring; the other waves take chunks of
+ * published spans from an LDS ticket counter and only ever store matches, on top of zeros that are already in
+ * L2 (same CU, same L2: ordered).  Writers run at most kRunAhead spans ahead of the scanners. */
+#ifndef PFAC_WRITERS
+#define PFAC_WRITERS 2
+#endif
+#ifndef PFAC_SPAN_LOG2
+#define PFAC_SPAN_LOG2 2
+#endif
+constexpr int kSpanLog2 = PFAC_SPAN_LOG2;
+constexpr uint32_t kSpanChunks = 1u << kSpanLog2;      /* chunks per span (4 chunks = 8 KiB of input, 32 KiB of results) */
+/* writers run up to kRunAhead spans (>= 128 KiB of input) ahead of the tickets handed out; a scanner holds at
+ * most 2 tickets it has not resolved yet, so a ring slot is reused only kRing - kRunAhead >= 32 tickets later */
+constexpr uint32_t kRunAhead = (64u >> kSpanLog2) > 4u ? (64u >> kSpanLog2) : 4u;
+constexpr uint32_t kRing = 2 * kRunAhead;
+static_assert((kRing - kRunAhead) * kSpanChunks >= 2 * 16 + kSpanChunks, "ring slack covers the unresolved tickets of 16 waves");
+constexpr uint32_t kEnd = 0xFFFFFFFFu;
+struct Control {                                         /* LDS, one per block */
+    uint32_t popCount;                                   /* tickets handed to scanners (chunk number in ring order) */
+    uint32_t pubCount;                                   /* spans published, in order                               */
+    uint32_t claimTurn;                                  /* next block-local span number allowed to claim           */
+    uint32_t endSpan;                                    /* first block-local span number past the part's end       */
+    uint32_t ring[kRing];                                /* span ids of the published spans                         */
+};
+constexpr int kControlWords = (sizeof(Control) / 4 + 3) / 4 * 4;
+
+__device__ __forceinline__ uint32_t ldsLoad(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ldsStore(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 /* inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, the gfx9 wave scan) */
 __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
@@ -458,26 +427,29 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
 }
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
-template <int MODE, bool HAS_SHORT, bool REDUCE, int kTilesPerIter, int kWalkSets>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_scan_filter(ScanArgs a)
 {
+    constexpr int kTilesPerIter = kGroupTiles;
     constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
-    static_assert(kTilesPerIter == kGroupTiles, "the stage holds one chunk; hit codes have one bit for the tile");
-    constexpr bool kHashed = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER);
-    using WCtx = typename WalkTypes<MODE>::Ctx;
-    using WLane = typename WalkTypes<MODE>::Lane;
+    using WCtx = ChainCtx<TEX>;
+    using WLane = ChainLane<TEX>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words3 = 1 << (a.log2Bits - 5), words4 = 1 << (a.log2Bits4 - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sGram4 = sGram3 + words3;
     uint32_t *sFinal3 = sGram4 + words4;
     uint32_t *sShort = sFinal3 + wordsF3;
-    uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* hashed: ChainSlot[256]; dense: int[256] */
-    uint32_t *sQueueAll = sFirst + (kHashed ? pfac::kCharSet * 4 : pfac::kCharSet);   /* 16-byte aligned */
-    constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
-    uint32_t *sStageAll = sQueueAll + kWavesPerBlock * kQCap * 4;        /* per wave: the chunk being filtered + the 16 bytes behind it */
-    uint32_t *sListAll = sStageAll + kWavesPerBlock * kStageWords;       /* per wave: 16-bit codes of the group's level-1 hits */
-    uint32_t *sReduceAll = sListAll + kWavesPerBlock * (kListCap / 2);   /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* ChainSlot[256] of the initial state */
+    constexpr int kWriters = REDUCE ? 0 : PFAC_WRITERS;             /* the compacted-output variant has no zeros to write */
+    constexpr int kScanners = REDUCE ? kReduceScanners : kWavesPerBlock - kWriters;
+    Control *ctl = reinterpret_cast<Control *>(sFirst + pfac::kCharSet * 4);
+    uint32_t *sQueueAll = reinterpret_cast<uint32_t *>(ctl) + kControlWords;           /* 16-byte aligned */
+    constexpr uint32_t kQCap = kQueueCap;
+    uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * 4;            /* ... second part of the entries: input bytes 12..19 */
+    uint32_t *sStageAll = sQueueBAll + kScanners * kQCap * 2;            /* per scanning wave: the chunk being filtered + the 32 bytes behind it */
+    uint32_t *sListAll = sStageAll + kScanners * kStageWords;            /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
+    uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
@@ -491,25 +463,26 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         copy16(sGram4, a.gram4, words4);
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
-        if (kHashed) copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
-        else copy16(sFirst, a.initialRow, pfac::kCharSet);
+        copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
+        if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == 3) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform by construction: keep it (and what derives from it) scalar */
-    /* ring of {byte position (32-bit), input bytes pos..pos+11} that passed both filter levels: the twelve
-     * bytes carry most walks to their end without a single input load (gathered loads are the scarce
-     * resource) */
+    /* ring of {byte position (32-bit), input bytes pos..pos+19} that passed both filter levels, kept as a 16-byte
+     * and an 8-byte array: the twenty bytes carry practically every walk to its end without a single input load
+     * (gathered loads are the scarce resource) */
     u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQCap;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 *queueB = reinterpret_cast<u32x2 *>(sQueueBAll) + wave * kQCap;
     uint32_t *stage = sStageAll + wave * kStageWords;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
-    const Lds lds{sGram3, sGram4, sFinal3, sShort, reinterpret_cast<const int *>(sFirst),
-                  reinterpret_cast<const u32x4 *>(sFirst),
+    const Lds lds{sGram3, sGram4, sFinal3, sShort,
                   32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
-    const WCtx wctx(a, lds);
+    const WCtx wctx(a, reinterpret_cast<const u32x4 *>(sFirst));
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
 #pragma unroll
@@ -546,7 +519,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                 pendMatch[s] = w.match;
                 pendPos[s] = w.pos;
             } else {
-                if (!afterLoad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!afterLoad && !kWriters) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 a.out[w.pos] = w.match;
             }
         }
@@ -590,10 +563,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #if PFAC_STATS
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
-            if constexpr (kHashed) {
-                stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needSlot));
-                stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
-            }
+            stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needSlot));
+            stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
         }
 #endif
     };
@@ -617,7 +588,11 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);
                 bool cont = false;
-                if (take) cont = walk[s].start(wctx, queue[(qh + rank) & kMask]);
+                if (take) {
+                    const uint32_t qi = (qh + rank) & kMask;
+                    const u32x2 eb = queueB[qi];
+                    cont = walk[s].start(wctx, queue[qi], eb.x, eb.y);
+                }
                 report(take & !cont, walk[s], s, false);
                 alive[s] = alive[s] | cont;
                 const uint32_t idleLanes = (uint32_t)__popcll(idle);
@@ -638,50 +613,101 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         return __ballot(any) != 0;
     };
 
-    /* Chunks are handed out dynamically and IN ORDER: block b serves part b % parts, and a wave takes the
-     * next chunk of its part from a device counter.  With PFAC_FRONT_LOG2 = 0 a part is a contiguous
-     * 1/parts of the input: all waves of a part work inside a window of a few hundred KiB that moves
-     * linearly through its part.  With G > 0 granules of 2^G chunks are dealt round-robin to the parts,
-     * so the whole grid works inside ONE window that sweeps the input once (two streams -- input and
-     * result -- instead of 2 x parts streams at power-of-two distances).  Either way it is what the
-     * hardware does for a grid of small blocks, worth ~10 % of HBM throughput over a static grid-stride
-     * assignment (profiles/r01_stream_probe2_ordering.txt), and it balances the load.  (Workgroups are
-     * dealt round-robin to the 8 XCDs, so the blocks that share a counter share an L2.)  The counter
-     * value for the chunk after next is requested while the current chunk is processed. */
+    /* Work is handed out dynamically and IN ORDER: block b serves part b % parts of the input and takes the
+     * next piece of its part from a device counter (one per part, in a.work).  With PFAC_FRONT_LOG2 = 0 a part
+     * is a contiguous 1/parts of the input: all waves of a part work inside a window of a few hundred KiB that
+     * moves linearly through its part.  With G > 0 granules of 2^G pieces are dealt round-robin to the parts,
+     * so the whole grid works inside ONE window that sweeps the input once.  Either way it is what the hardware
+     * does for a grid of small blocks, worth ~10 % of HBM throughput over a static grid-stride assignment
+     * (profiles/r01_stream_probe2_ordering.txt), and it balances the load.  (Workgroups are dealt round-robin
+     * to the 8 XCDs, so the blocks that share a counter share an L2.)
+     * A piece is a span of kSpanChunks chunks claimed by a writer wave (kWriters > 0), or a single chunk claimed
+     * by the scanning wave itself (kWriters == 0). */
     const uint32_t numChunks = n / kChunkBytes;
+    const uint32_t numPieces = kWriters ? (numChunks + kSpanChunks - 1) >> kSpanLog2 : numChunks;
     const uint32_t parts = gridDim.x < (uint32_t)pfac::kWorkParts ? gridDim.x : (uint32_t)pfac::kWorkParts;
     const uint32_t part = blockIdx.x % parts;
-    constexpr uint32_t kFront = PFAC_FRONT_LOG2;
-    const uint32_t partBegin = kFront ? 0u : (uint32_t)((uint64_t)numChunks * part / parts);
-    const uint32_t chunkEnd = kFront ? numChunks : (uint32_t)((uint64_t)numChunks * (part + 1) / parts);
-    auto chunkOf = [&](uint32_t v) {                       /* v-th chunk of this block's part */
-        if (kFront) return ((((v >> kFront) * parts + part) << kFront) | (v & ((1u << kFront) - 1u)));
+    constexpr bool kFrontOn = PFAC_FRONT_LOG2 >= 0;
+    constexpr uint32_t kFront = kFrontOn ? PFAC_FRONT_LOG2 : 0;
+    const uint32_t partBegin = kFrontOn ? 0u : (uint32_t)((uint64_t)numPieces * part / parts);
+    const uint32_t pieceEnd = kFrontOn ? numPieces : (uint32_t)((uint64_t)numPieces * (part + 1) / parts);
+    auto pieceOf = [&](uint32_t v) {                       /* v-th piece of this block's part */
+        if (kFrontOn) return ((((v >> kFront) * parts + part) << kFront) | (v & ((1u << kFront) - 1u)));
         return partBegin + v;
     };
     unsigned int *const counter = a.work + part * 32;
-    auto grab = [&]() {                                    /* lane 0 holds the answer */
+
+    if (!kWriters && wave >= kScanners) {
+        /* no per-wave LDS for this wave (REDUCE) */
+    } else if (kWriters && wave >= kScanners) {
+        /* ---- writer wave: claim, zero-fill, publish */
+        const i32x4 zero = {0, 0, 0, 0};
+        for (uint32_t k = (uint32_t)(wave - kScanners);; k += kWriters) {
+            for (;;) {                                      /* my turn to claim, and a ring slot nobody still reads */
+                const uint32_t turn = ldsLoad(&ctl->claimTurn), pops = ldsLoad(&ctl->popCount);
+                if (turn == k && k < (pops >> kSpanLog2) + kRunAhead) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            unsigned int v = 0;
+            if (lane == 0) v = atomicAdd(counter, 1u);
+            const uint32_t span = pieceOf(uni(v));
+            ldsStore(&ctl->claimTurn, k + 1);
+            if (span >= pieceEnd) {
+                if (lane == 0) atomicMin(&ctl->endSpan, k);
+                break;
+            }
+            const uint32_t c0 = span << kSpanLog2;
+            const uint32_t cN = c0 + kSpanChunks < numChunks ? c0 + kSpanChunks : numChunks;
+            i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)c0 * kChunkBytes);
+            const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);                 /* 1 KiB per instruction */
+            for (uint32_t i = 0; i < stores; i++) __builtin_nontemporal_store(zero, &o4[i * 64 + lane]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              /* the zeros are in L2 */
+            while (ldsLoad(&ctl->pubCount) != k) __builtin_amdgcn_s_sleep(2);             /* publish in order */
+            ldsStore(&ctl->ring[k & (kRing - 1)], span);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ldsStore(&ctl->pubCount, k + 1);
+        }
+    } else {
+    /* ---- scanning wave */
+    /* ticket for the next chunk (lane 0 holds the answer): cheap, asked for one chunk ahead ... */
+    auto pop = [&]() {
         unsigned int v = 0;
-        if (lane == 0) v = atomicAdd(counter, 1u);
+        if (lane == 0) v = kWriters ? atomicAdd(&ctl->popCount, 1u) : atomicAdd(counter, 1u);
         return v;
     };
-    /* the chunk's tiles, 1 KiB per instruction, and the 16 bytes behind it; past the end the address is clamped,
-     * not skipped: every path issues the same vector-memory instructions, which keeps the wait counts exact */
+    /* ... and turned into a chunk number when its data is to be prefetched: waits for the writers if they are
+     * behind (then the launch is bound by the result stream, as it should be).  kEnd = the part is finished. */
+    auto resolve = [&](uint32_t ticket) -> uint32_t {
+        if (!kWriters) {
+            const uint32_t c = pieceOf(ticket);
+            return c < pieceEnd ? c : kEnd;
+        }
+        const uint32_t slot = ticket >> kSpanLog2;
+        for (;;) {
+            if (slot < ldsLoad(&ctl->pubCount)) break;
+            if (slot >= ldsLoad(&ctl->endSpan)) return kEnd;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t c = (uni(ldsLoad(&ctl->ring[slot & (kRing - 1)])) << kSpanLog2) | (ticket & (kSpanChunks - 1u));
+        return c < numChunks ? c : kEnd;                   /* the last span of the input may be partial */
+    };
+    /* the chunk's tiles, 1 KiB per instruction, and the 16 bytes behind it */
     auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], u32x4 &halo) {
-        const uint32_t cc = c < chunkEnd ? c : chunkEnd - 1;
-        const uint32_t q = cc * (kChunkBytes / 16);
+        const uint32_t q = c * (kChunkBytes / 16);
 #pragma unroll
         for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];
-        halo = in128[(cc + 1) * (kChunkBytes / 16)];
+        halo = in128[(c + 1) * (kChunkBytes / 16) + (lane & 1)];       /* lane 0: bytes 0..15 behind the chunk, lane 1: 16..31 */
     };
 
 #if PFAC_ABLATE == 1
     uint32_t ablateSink = 0;
 #endif
-    uint32_t chunk = chunkOf(uni(grab()));
-    uint32_t next = chunkOf(uni(grab()));
+    uint32_t chunk = resolve(uni(pop()));
+    uint32_t nextTicket = uni(pop());
     u32x4 d[kTilesPerIter];
     u32x4 halo = {0, 0, 0, 0};
-    if (chunk < chunkEnd) loadChunk(chunk, d, halo);
+    if (chunk != kEnd) loadChunk(chunk, d, halo);
 
     /* The staged chunk: level-1 hits not yet listed (per lane), listed codes not yet tested [listAt, listEnd),
      * and its position in the input.  One loop, one copy of every stage: each trip starts with a walker round;
@@ -698,13 +724,14 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 
         if (listAt == listEnd) {
             if (__ballot(hits != 0) == 0) {
-                if (chunk >= chunkEnd) {
+                if (chunk == kEnd) {
                     if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
                 } else {
-                    /* ---- 2. next chunk: ask for the chunk after next; zero stores, 16 B per lane, 1 KiB contiguous
-                     *         per instruction (older than every load of a walk that starts in this chunk) */
-                    const unsigned int afterNext = grab();
-                    if (!REDUCE) {
+                    /* ---- 2. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
+                     *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
+                     *         this chunk) */
+                    const unsigned int afterNext = pop();
+                    if (!REDUCE && !kWriters) {
                         i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
                         const i32x4 zero = {0, 0, 0, 0};
 #pragma unroll
@@ -745,13 +772,16 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (lane == 0) reinterpret_cast<u32x4 *>(stage)[kTilesPerIter * 64] = halo;
+                    if (lane < 2) reinterpret_cast<u32x4 *>(stage)[kTilesPerIter * 64 + lane] = halo;
                     stagedBase = chunk * kChunkBytes;
                     /* the registers are free: prefetch the next chunk into them (a whole chunk ahead of its use; the
-                     * loads stay younger than this trip's walker loads, so consuming those does not wait for HBM) */
-                    loadChunk(next, d, halo);
+                     * loads stay younger than this trip's walker loads, so consuming those does not wait for HBM).
+                     * Past the end the previous address is loaded again, not nothing: every path issues the same
+                     * vector-memory instructions, which keeps the wait counts exact. */
+                    const uint32_t next = resolve(nextTicket);
+                    loadChunk(next != kEnd ? next : chunk, d, halo);
                     chunk = next;
-                    next = chunkOf(uni(afterNext));
+                    nextTicket = uni(afterNext);
 #if PFAC_ABLATE == 1
                     ablateSink |= hits;
                     hits = 0;
@@ -782,7 +812,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             const uint32_t code = act ? (uint32_t)list[listAt + lane] : 0u;
             const uint32_t o = ((code >> 1) & 0x3FFu) | ((code & 1u) << 10);       /* byte offset inside the chunk */
             const uint32_t at = o >> 2, sh = o & 3u;
-            const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3];
+            const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
             const uint32_t x = __builtin_amdgcn_alignbyte(e1, e0, sh);
             uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4) & testBit(sGram4, (x * pfac::kGram4Mul2) >> lds.shift4);
             pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
@@ -793,7 +823,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             const bool keep = act && pass != 0;
             const uint64_t keepMask = __ballot(keep);
             const u32x4 entry = {stagedBase + o, x, __builtin_amdgcn_alignbyte(e2, e1, sh), __builtin_amdgcn_alignbyte(e3, e2, sh)};
-            if (keep) queue[(qv + laneRankIn(keepMask)) & kMask] = entry;
+            const u32x2 entryB = {__builtin_amdgcn_alignbyte(e4, e3, sh), __builtin_amdgcn_alignbyte(e5, e4, sh)};
+            if (keep) {
+                const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
+                queue[qi] = entry;
+                queueB[qi] = entryB;
+            }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
             listAt = uni(listAt + 64 < listEnd ? listAt + 64 : listEnd);
         }
@@ -806,6 +841,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
     if (REDUCE) flushStaged();
+    }   /* scanning wave */
 
     /* counters of this launch (PFACX_getScanStats): per-wave scalars -> LDS -> one atomic per counter and block */
     __syncthreads();
@@ -859,44 +895,51 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
-    bytes += c->perfMode == PFAC_SPACE_DRIVEN ? pfac::kCharSet * sizeof(pfac::ChainSlot) : pfac::kCharSet * sizeof(int);
-    bytes += (size_t)kWavesPerBlock * ((reduce ? kReduceQueueCap : kQueueCap) * 4 + kStageWords + kListCap / 2) * sizeof(uint32_t);
-    if (reduce) bytes += (size_t)kWavesPerBlock * kReduceCap * 2 * sizeof(uint32_t);
+    bytes += pfac::kCharSet * sizeof(pfac::ChainSlot);
+    const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
+    bytes += kControlWords * sizeof(uint32_t);
+    bytes += scanners * (kQueueCap * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
+    if (reduce) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }
 
-int tilesPerChunk(const PFAC_context *c) { return c->filter.bitsSet >= pfac::kHeavyMinKeys ? PFAC_HEAVY_TILES : PFAC_LIGHT_TILES; }
-size_t chunkBytes(const PFAC_context *c) { return (size_t)tilesPerChunk(c) * kTileBytes; }
+constexpr size_t kChunkBytesHost = (size_t)kGroupTiles * kTileBytes;
+size_t chunkBytes(const PFAC_context *) { return kChunkBytesHost; }
 
-template <int MODE, bool HAS_SHORT, bool REDUCE, int TILES, int WALKS>
-hipError_t launchShape(const PFAC_context *c, const ScanArgs &a)
+/* The launch shape of an instantiation depends on the kernel and its LDS size only (fixed per loaded pattern
+ * set): hipFuncSetAttribute and the occupancy query run once per (instantiation, LDS size), not per call. */
+struct ShapeCache { std::mutex lock; size_t lds = 0; int perCU = 0; };
+
+template <bool TEX, bool HAS_SHORT, bool REDUCE>
+hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 {
-    auto kernel = pfac_scan_filter<MODE, HAS_SHORT, REDUCE, TILES, WALKS>;
+    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, PFAC_WALK_SETS>;
+    static ShapeCache cache;
     const size_t lds = filterLdsBytes(c, REDUCE);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    int perCU = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kBlockThreads, lds);
-    if (e != hipSuccess) return e;
-    if (perCU < 1) perCU = 1;
-    const size_t numChunks = a.n / ((size_t)TILES * kTileBytes);
-    size_t blocks = (numChunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    int perCU;
+    {
+        std::lock_guard<std::mutex> g(cache.lock);
+        if (cache.lds != lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            int n = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, lds);
+            if (e != hipSuccess) return e;
+            cache.perCU = n < 1 ? 1 : n;
+            cache.lds = lds;
+        }
+        perCU = cache.perCU;
+    }
+    const size_t numChunks = a.n / kChunkBytesHost;
+    constexpr size_t scanners = REDUCE ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
+    size_t blocks = (numChunks + scanners - 1) / scanners;
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
-    e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
+    hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     return hipGetLastError();
-}
-
-template <int MODE, bool HAS_SHORT, bool REDUCE>
-hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
-{
-    /* the chained walker is 17 registers per walk: a third one per lane does not fit the 128 of a 16-wave block */
-    constexpr int kLightWalks = (MODE == HASH_GLOBAL || MODE == HASH_BUFFER) ? PFAC_HEAVY_WALKS : PFAC_LIGHT_WALKS;
-    return c->filter.bitsSet >= pfac::kHeavyMinKeys ? launchShape<MODE, HAS_SHORT, REDUCE, PFAC_HEAVY_TILES, PFAC_HEAVY_WALKS>(c, a)
-                                                     : launchShape<MODE, HAS_SHORT, REDUCE, PFAC_LIGHT_TILES, kLightWalks>(c, a);
 }
 
 template <int MODE>
@@ -909,29 +952,18 @@ hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
     return hipGetLastError();
 }
 
-#ifdef PFAC_QUICK      /* development builds (register / ISA inspection): only the bench instances of the filter kernel */
-template <int MODE>
-hipError_t launchMode(const PFAC_context *c, const ScanArgs &a)
+/* the filter kernel walks the chained table in both perf modes; "texture" = buffer-resource loads */
+template <bool REDUCE>
+hipError_t launchChained(const PFAC_context *c, const ScanArgs &a, bool tex)
 {
-    if (MODE != HASH_BUFFER && MODE != DENSE_BUFFER) return hipErrorNotSupported;
-    constexpr int M = MODE == HASH_BUFFER ? HASH_BUFFER : DENSE_BUFFER;
-    return c->filter.hasShort ? launchFilter<M, true, false>(c, a) : launchFilter<M, false, false>(c, a);
-}
-template <int MODE>
-hipError_t launchReduceMode(const PFAC_context *, const ScanArgs &) { return hipErrorNotSupported; }
+#ifdef PFAC_QUICK      /* development builds (register / ISA inspection): the bench instances only */
+    if (REDUCE || !tex) return hipErrorNotSupported;
+    return c->filter.hasShort ? launchFilter<true, true, false>(c, a) : launchFilter<true, false, false>(c, a);
 #else
-template <int MODE>
-hipError_t launchMode(const PFAC_context *c, const ScanArgs &a)
-{
-    return c->filter.hasShort ? launchFilter<MODE, true, false>(c, a) : launchFilter<MODE, false, false>(c, a);
-}
-
-template <int MODE>
-hipError_t launchReduceMode(const PFAC_context *c, const ScanArgs &a)
-{
-    return c->filter.hasShort ? launchFilter<MODE, true, true>(c, a) : launchFilter<MODE, false, true>(c, a);
-}
+    if (tex) return c->filter.hasShort ? launchFilter<true, true, REDUCE>(c, a) : launchFilter<true, false, REDUCE>(c, a);
+    return c->filter.hasShort ? launchFilter<false, true, REDUCE>(c, a) : launchFilter<false, false, REDUCE>(c, a);
 #endif
+}
 
 uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes; }
 
@@ -940,7 +972,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
                        int *d_matched_result, ScanArgs &a)
 {
     if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
-    if (hashed ? (!c->d_hashRow || !c->d_hashVal || !c->d_chainSlots || !c->d_rootSlots) : !c->d_dense)
+    if (!c->d_chainSlots || !c->d_rootSlots || (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense))
         return PFAC_STATUS_INTERNAL_ERROR;
     a = ScanArgs{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
@@ -969,8 +1001,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     /* the buffer-resource ("texture") path addresses the table with 32-bit byte offsets; the
      * reference fails the texture bind for an oversized table the same way (PFAC_kernel.cu:139-142) */
     if (c->textureMode == PFAC_TEXTURE_ON) {
-        const size_t biggest = hashed ? c->numChainSlots * sizeof(pfac::ChainSlot) : c->h_dense.size() * sizeof(int);
-        if (biggest > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
+        const size_t chained = c->numChainSlots * sizeof(pfac::ChainSlot), dense = hashed ? 0 : c->h_dense.size() * sizeof(int);
+        if ((chained > dense ? chained : dense) > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
     return PFAC_STATUS_SUCCESS;
 }
@@ -1015,8 +1047,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         part.out = a.out + first;
         if (mainLen) {
             part.n = part.owned = mainLen;
-            if (hashed) e = tex ? launchMode<HASH_BUFFER>(c, part) : launchMode<HASH_GLOBAL>(c, part);
-            else        e = tex ? launchMode<DENSE_BUFFER>(c, part) : launchMode<DENSE_GLOBAL>(c, part);
+            e = launchChained<false>(c, part, tex);
         }
         if (e == hipSuccess && first + mainLen < ownEnd) {
             part.in += mainLen;
@@ -1068,8 +1099,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         part.reduceBase = 0;
         if (hipMemsetAsync(c->d_reduceCount, 0, sizeof(unsigned int), 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         hipError_t e;
-        if (hashed) e = tex ? launchReduceMode<HASH_BUFFER>(c, part) : launchReduceMode<HASH_GLOBAL>(c, part);
-        else        e = tex ? launchReduceMode<DENSE_BUFFER>(c, part) : launchReduceMode<DENSE_GLOBAL>(c, part);
+        e = launchChained<true>(c, part, tex);
         if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (count > 1) {                                   /* order by position */

@@ -257,6 +257,7 @@ def cpu_worker_env(threads):
 def cpu_worker(args):
     """--worker cpu: time the reference's OpenMP matcher (oracle/_ref; the C port if _ref is absent) on a
     bounded prefix of the rank-0 stream, 3 runs; compare its result with the GPU's sparse result."""
+    facts = lscpu_facts()              # before the OpenMP runtime binds this thread to one core (OMP_PROC_BIND)
     from oracle import binding as ob   # cpu_baseline leg
     from pfac_amd import workloads as wl
     cfg = wl.make_config(args.workload)
@@ -293,7 +294,6 @@ def cpu_worker(args):
         t, result = run(host_in[:sample])
         times.append(t)
     fn = ("PFAC_CPU_OMP_spaceDriven" if perf_mode else "PFAC_CPU_OMP_timeDriven") if use_ref else "oracle C port"
-    facts = lscpu_facts()
     threads = ob.omp_max_threads()
     out = {
         "value": round(sample / min(times) / 1e9, 4), "unit": "GB/s", "cores": threads,

@@ -94,15 +94,18 @@ struct Filter {
     std::vector<uint32_t> shortBits;          /* 65536 bits, index c0 | c1<<8                    */
 };
 
-constexpr uint32_t kGram3Mul = 0x797A0Bu;     /* 24-bit odd multiplier of the 3-gram hash, picked by
-                                                 scanning 150 candidates for the lowest false-positive
-                                                 rate on text, binary and near-miss streams */
-constexpr uint32_t kGram4Mul = 0x9E3779B1u;   /* 32-bit odd multiplier of the 4-gram hash */
-constexpr uint32_t kFinal3Mul = 0x85EBCBu;    /* 24-bit odd multiplier of the length-3 hash */
+constexpr uint32_t kGram3Mul = 0x8B92C5u;     /* 24-bit odd multiplier of the 3-gram hash, picked by scanning 160
+                                                 candidates for the lowest false-positive rate on the text, binary
+                                                 and near-miss streams */
+/* Bit of the level-1 bitmap that stands for a 3-gram: the dword comes from the top bits of the 24 x 24 -> 32 bit
+ * product, the bit inside the dword from the low five bits of the first byte -- the kernel gets the dword address
+ * with a shift and an AND and the bit with the implicit mod-32 of a shift by the gram itself (scan_gfx950.hip). */
 inline uint32_t gram3Hash(uint32_t key24, int log2Bits)
 {
-    return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (32 - log2Bits);
+    return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits)) << 5 | (key24 & 31u);
 }
+constexpr uint32_t kGram4Mul = 0x9E3779B1u;   /* 32-bit odd multiplier of the 4-gram hash */
+constexpr uint32_t kFinal3Mul = 0x85EBCBu;    /* 24-bit odd multiplier of the length-3 hash */
 inline uint32_t gram4Hash(uint32_t key32, int log2Bits) { return (uint32_t)(key32 * kGram4Mul) >> (32 - log2Bits); }
 /* level 2 is a two-hash Bloom filter: it runs for a few positions per hundred, 64 at a time, so the
  * second lookup is free, and at the bench set's 9 % density it cuts the false walks 5x */

@@ -187,18 +187,6 @@ __device__ __forceinline__ uint32_t laneRankIn(uint64_t mask)
 
 __device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) { return (bitmap[h >> 5] >> (h & 31)) & 1u; }
 
-/* Bit (product >> shift) of the little-endian bitmap that starts at LDS address 0 (the level-1 bitmap
- * is the first thing in the block's dynamic LDS, and the kernel has no static LDS: checked at kernel
- * entry).  Read as a byte: one shift for the LDS address, one bit-field extract for the bit number, one
- * for the bit.  Addressing LDS by number instead of through the `smem` symbol saves the add of a
- * link-time constant (0) per test -- the level-1 filter runs this 1024 times per KiB, and VALU issue
- * slots are what bounds the kernel on pattern-dense input. */
-typedef const __attribute__((address_space(3))) unsigned char LdsByte;
-__device__ __forceinline__ uint32_t loadHashedByteLds0(uint32_t product, uint32_t shift)
-{
-    return *reinterpret_cast<LdsByte *>(product >> (shift + 3u));
-}
-
 /* LDS view of one block */
 struct Lds {
     const uint32_t *gram3, *gram4, *final3, *shortBits;
@@ -452,7 +440,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
 
     const int tid = threadIdx.x;
-    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* loadHashedByteLds0: sGram3 must sit at LDS address 0 */
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* the level-1 bitmap is addressed by number: sGram3 must sit at LDS address 0 */
     {   /* fill the LDS tables once per (persistent) block, 16 B per lane */
         auto copy16 = [&](uint32_t *dst, const void *src, int words) {
             const u32x4 *g = reinterpret_cast<const u32x4 *>(src);
@@ -481,7 +469,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort,
-                  32u - (uint32_t)a.log2Bits, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
+                  35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
     const WCtx wctx(a, reinterpret_cast<const u32x4 *>(sFirst));
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
@@ -713,7 +701,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
      * and its position in the input.  One loop, one copy of every stage: each trip starts with a walker round;
      * a new chunk is staged only when the previous one is completely listed and tested, and list entries are
      * tested only while the walk queue has room for a full pass -- otherwise the trip just walks. */
-    uint32_t hits = 0;                          /* bit tt + 2 * i: position i of this lane in tile tt of the staged chunk */
+    uint32_t hits = 0;                          /* bit 16 * tt + i: position i of this lane in tile tt of the staged chunk */
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     for (;;) {
         /* ---- 1. finish the transitions issued one trip ago, hand idle walker lanes new positions (first
@@ -749,26 +737,28 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                         const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow.x);
                         if (lane == 63) nxtLane = wrap;
                         /* kBatch positions at a time (that many LDS reads in flight); the scheduling barrier keeps the
-                         * batches apart, or their temporaries pile up past the register budget */
+                         * batches apart, or their temporaries pile up past the register budget.  Per position: the gram
+                         * (a shift or v_alignbyte), v_mul_u32_u24, shift + AND = dword address, ds_read_b32, a shift by the
+                         * gram (mod 32: the bit), v_alignbit to push the bit into the mask.  Plain VOP2 instructions
+                         * wherever possible: they issue twice as fast as VOP3 ones here (tools/valu_probe.hip). */
                         constexpr int kBatch = HAS_SHORT ? 4 : 8;
 #pragma unroll
                         for (int b0 = 0; b0 < 16; b0 += kBatch) {
-                            uint32_t product[kBatch], byte[kBatch], shortWord[kBatch], xs[kBatch];
+                            uint32_t word[kBatch], xs[kBatch];
 #pragma unroll
                             for (int q = 0; q < kBatch; q++) {
                                 const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
                                 const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
-                                const uint32_t x = i == 0 ? dw[j] : __builtin_amdgcn_alignbyte(nx, dw[j], i);   /* bytes pos..pos+3 */
-                                product[q] = (uint32_t)__umul24(x, pfac::kGram3Mul);       /* __umul24 returns int: shifts must be logical */
-                                byte[q] = loadHashedByteLds0(product[q], lds.shift3);
-                                if (HAS_SHORT) { xs[q] = x; shortWord[q] = sShort[(x & 0xFFFFu) >> 5]; }
+                                /* bytes pos..pos+2 in the low 24 bits (the multiply ignores the rest) */
+                                const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
+                                const uint32_t product = (uint32_t)__umul24(x, pfac::kGram3Mul);   /* __umul24 returns int: shifts must be logical */
+                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> lds.shift3) & ~3u);
+                                if (HAS_SHORT) word[q] |= sShort[(x & 0xFFFFu) >> 5] >> 0;      /* same bit number: (x & 0xFFFF) & 31 == x & 31 */
+                                xs[q] = x;
                             }
 #pragma unroll
-                            for (int q = 0; q < kBatch; q++) {
-                                uint32_t bit = __builtin_amdgcn_ubfe(byte[q], __builtin_amdgcn_ubfe(product[q], lds.shift3, 3u), 1u);
-                                if (HAS_SHORT) bit |= (shortWord[q] >> (xs[q] & 31u)) & 1u;
-                                hits |= bit << ((b0 + q) * 2 + tt);
-                            }
+                            for (int q = 0; q < kBatch; q++)
+                                hits = __builtin_amdgcn_alignbit(word[q] >> (xs[q] & 31u), hits, 1);   /* bit 0 of the shifted word enters at the top */
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -810,7 +800,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         while (listAt != listEnd && qv - qh + 64 <= kQCap) {
             const bool act = listAt + (uint32_t)lane < listEnd;
             const uint32_t code = act ? (uint32_t)list[listAt + lane] : 0u;
-            const uint32_t o = ((code >> 1) & 0x3FFu) | ((code & 1u) << 10);       /* byte offset inside the chunk */
+            const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
             const uint32_t at = o >> 2, sh = o & 3u;
             const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
             const uint32_t x = __builtin_amdgcn_alignbyte(e1, e0, sh);

@@ -199,7 +199,7 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     def bit(bitmap, hv):
         return (bitmap[(hv >> 5).astype(np.int64)] >> (hv & 31).astype(np.uint32)) & 1
 
-    h3 = (((x & 0xFFFFFF) * 0x797A0B) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits)
+    h3 = (((((x & 0xFFFFFF) * 0x8B92C5) & 0xFFFFFFFF) >> (37 - info.filterLog2Bits)) << 5) | (x & 31)
     h4 = ((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
     h4b = ((x * 0x85EBCA77) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
     hf = (((x & 0xFFFFFF) * 0x85EBCB) & 0xFFFFFFFF) >> (32 - info.filterLog2BitsFinal3)

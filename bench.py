@@ -704,7 +704,8 @@ def orchestrate(args, argv):
             out["roofline"]["traffic_detail"] = traffic
         else:
             out["roofline"]["traffic_note"] = src
-    if out["roofline"]["traffic"] is None and args.size_mib == 1024 and args.perf_mode is None:
+    if single and args.pmc == "auto" and args.variant == "filter" and out["roofline"]["traffic"] is None \
+            and args.size_mib == 1024 and args.perf_mode is None:      # the PMC passes of this run failed: last committed profile
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = committed_traffic(args.workload, out["roofline"]["kernel"])
     print(json.dumps(out), flush=True)
     return rc

@@ -81,6 +81,22 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 
+/* A compiled pattern set on disk: everything PFAC_readPatternFromFile derives from the pattern
+ * file -- trie, hashed / chained tables, prefilter bitmaps -- with a version + layout fingerprint + checksum
+ * header.  PFACX_loadCompiled replaces the handle's pattern set like PFAC_readPatternFromFile does (and sets the
+ * perf mode the set was saved with); a file of another build or a damaged one is PFAC_STATUS_INVALID_PARAMETER,
+ * a missing one PFAC_STATUS_FILE_OPEN_ERROR.  Works on host-only handles too. */
+PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename);
+PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename);
+
+/* One call shards a host stream over several GPUs of the node (reference users write this
+ * themselves after PFAC/test/omp_PFAC.cpp:257-394): one worker thread and one internal handle per entry of
+ * `devices` (NULL = devices 0..numDevices-1; numDevices 0 = every visible device), contiguous slices scanned
+ * with a maxPatternLen read-ahead, no exchange between devices.  `handle` supplies the pattern set and modes
+ * and keeps the per-device handles for the next call.  A device may be listed more than once. */
+PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size,
+                                          int *h_matched_result, int numDevices, const int *devices);
+
 /* Counters of the most recent PFAC_matchFromDevice / ...Reduce launch of the filter kernel on this handle
  * (configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
  * stream.  All zero if the last call did not run the filter kernel. */

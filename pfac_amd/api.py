@@ -77,7 +77,8 @@ EXPORTED_SYMBOLS = (
     "PFAC_matchFromDevice", "PFAC_matchFromHost", "PFAC_matchFromDeviceReduce", "PFAC_matchFromHostReduce",
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
-    "PFACX_readPatternFromMemory", "PFACX_getScanStats",
+    "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
+    "PFACX_matchFromHostMultiGPU",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -121,6 +122,9 @@ def load_library() -> C.CDLL:
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
     lib.PFACX_getScanStats.argtypes = [H, C.POINTER(PFACX_scan_stats)]
+    lib.PFACX_saveCompiled.argtypes = [H, C.c_char_p]
+    lib.PFACX_loadCompiled.argtypes = [H, C.c_char_p]
+    lib.PFACX_matchFromHostMultiGPU.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name != "PFAC_getErrorString":
@@ -215,6 +219,23 @@ class PFAC:
     def readPatternFromMemory(self, data: bytes, check: bool = True) -> int:
         """``PFACX_readPatternFromMemory``: the pattern-file bytes without a file."""
         return self._ret(self._lib.PFACX_readPatternFromMemory(self._h, data, len(data)), "PFACX_readPatternFromMemory", check)
+
+    def saveCompiled(self, filename, check: bool = True) -> int:
+        """``PFACX_saveCompiled``: the compiled pattern set (trie, tables, prefilter) to a file."""
+        return self._ret(self._lib.PFACX_saveCompiled(self._h, os.fsencode(filename)), "PFACX_saveCompiled", check)
+
+    def loadCompiled(self, filename, check: bool = True) -> int:
+        """``PFACX_loadCompiled``: replaces the pattern set with a saved one."""
+        return self._ret(self._lib.PFACX_loadCompiled(self._h, os.fsencode(filename)), "PFACX_loadCompiled", check)
+
+    def matchFromHostMultiGPU(self, h_input: int, size: int, h_result: int, devices=None, check: bool = True) -> int:
+        """``PFACX_matchFromHostMultiGPU``: `devices` = list of device ordinals (None = every visible device)."""
+        if devices is None:
+            st = self._lib.PFACX_matchFromHostMultiGPU(self._h, h_input, size, h_result, 0, None)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            st = self._lib.PFACX_matchFromHostMultiGPU(self._h, h_input, size, h_result, len(devices), arr)
+        return self._ret(st, "PFACX_matchFromHostMultiGPU", check)
 
     def dumpTransitionTable(self, path: str, check: bool = True) -> int:
         fp = _libc.fopen(os.fsencode(path), b"w")

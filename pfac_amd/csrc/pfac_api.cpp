@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "pfac_host.h"
 
@@ -43,6 +44,8 @@ void freeTables(PFAC_context *c)
     devFree(c->d_hashVal);
     devFree(c->d_chainSlots);
     devFree(c->d_rootSlots);
+    std::vector<pfac::ChainSlot>().swap(c->h_chainSlots);
+    std::vector<pfac::ChainSlot>().swap(c->h_rootSlots);
     c->numChainSlots = 0;
     c->numOfTableEntry = c->sizeOfTableEntry = c->sizeOfTableInBytes = 0;
 }
@@ -78,6 +81,10 @@ void freeResources(PFAC_context *c)
     c->reduceScratchBytes = 0;
     freeHostStage(c);
     devFree(c->d_final3);
+    if (c->h_statsPinned) { (void)hipHostFree(c->h_statsPinned); c->h_statsPinned = nullptr; }
+    c->autoCalls = 0;
+    for (auto &child : c->children) (void)PFAC_destroy(child.second);
+    c->children.clear();
     c->fa = pfac::Automaton();
     c->filter = pfac::Filter();
     c->isPatternsReady = false;
@@ -99,24 +106,27 @@ PFAC_status_t upload(T *&dst, const T *src, size_t count)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* Upload the chained device form of the hashed table (tables.cpp: buildChainedHashTable): what the scan kernel
- * walks in BOTH perf modes.  In PFAC_TIME_DRIVEN mode the hashed layout it derives from is built here and
- * dropped again: the handle's reference-layout table (PFACX_getTable, the dump, the simple kernel) stays dense. */
+/* Build (unless a compiled file brought it along) and upload the chained device form of the hashed table
+ * (tables.cpp: buildChainedHashTable): what the scan kernel walks in BOTH perf modes.  In PFAC_TIME_DRIVEN mode
+ * the hashed layout it derives from is built here and dropped again: the handle's reference-layout table
+ * (PFACX_getTable, the dump, the simple kernel) stays dense. */
 PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 {
-    std::vector<pfac::ChainSlot> slots, root;
-    PFAC_status_t st;
-    if (c->perfMode == PFAC_SPACE_DRIVEN) {
-        st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, slots, root);
-    } else {
-        std::vector<Int2> rowPtr, valPtr;
-        st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
-        if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, slots, root);
+    PFAC_status_t st = PFAC_STATUS_SUCCESS;
+    if (c->h_chainSlots.empty() || c->h_rootSlots.size() != (size_t)pfac::kCharSet) {
+        if (c->perfMode == PFAC_SPACE_DRIVEN) {
+            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->h_rootSlots);
+        } else {
+            std::vector<Int2> rowPtr, valPtr;
+            st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
+            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->h_rootSlots);
+        }
+        if (st != PFAC_STATUS_SUCCESS) return st;
     }
-    if (st != PFAC_STATUS_SUCCESS) return st;
-    c->numChainSlots = slots.size();
-    st = upload(c->d_chainSlots, slots.data(), slots.size());
-    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_rootSlots, root.data(), root.size());
+    if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
+    c->numChainSlots = c->h_chainSlots.size();
+    st = upload(c->d_chainSlots, c->h_chainSlots.data(), c->h_chainSlots.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_rootSlots, c->h_rootSlots.data(), c->h_rootSlots.size());
     return st;
 }
 
@@ -156,12 +166,23 @@ PFAC_status_t bindTable(PFAC_context *c)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* tables that do not depend on perfMode: initial-state row and prefilter */
-PFAC_status_t bindCommon(PFAC_context *c)
+/* tables that do not depend on perfMode: initial-state row and prefilter (built, or brought along by a compiled file) */
+PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
 {
-    pfac::buildInitialRow(c->fa, c->h_initialRow);
-    pfac::buildFilter(c->fa, c->filter);
+    if (build) {
+        pfac::buildInitialRow(c->fa, c->h_initialRow);
+        pfac::buildFilter(c->fa, c->filter);
+    }
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
+    if (!c->h_statsPinned) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, pfac::kStatsCount * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+            c->h_statsPinned = static_cast<unsigned long long *>(p);
+            std::memset(p, 0, pfac::kStatsCount * sizeof(unsigned long long));
+        } else {
+            (void)hipGetLastError();                   /* the AUTO heuristic simply has no data then */
+        }
+    }
     PFAC_status_t st = upload(c->d_initialRow, c->h_initialRow.data(), c->h_initialRow.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram3, c->filter.gram3.data(), c->filter.gram3.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
@@ -384,45 +405,37 @@ PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patt
     return PFAC_STATUS_SUCCESS;
 }
 
-PFAC_status_t PFAC_matchFromDevice(PFAC_handle_t handle, char *d_inputString, size_t size, int *d_matched_result)
+} /* extern "C" */
+
+namespace {
+
+/* PFAC_matchFromDevice behind the argument checks; the caller holds handle->lock */
+PFAC_status_t matchDeviceLocked(PFAC_context *c, char *d_inputString, size_t size, int *d_matched_result)
 {
-    if (!handle) return PFAC_STATUS_INVALID_HANDLE;                /* check order: ref PFAC.cpp:846-861 */
-    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
-    if (!d_inputString) return PFAC_STATUS_INVALID_PARAMETER;
-    if (!d_matched_result) return PFAC_STATUS_INVALID_PARAMETER;
-    if (size == 0) return PFAC_STATUS_SUCCESS;
-    if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;   /* never a CPU fallback */
-    correctTextureMode(handle);
-    if (handle->perfMode == PFAC_TIME_DRIVEN)
-        return handle->kernel_time_driven_ptr(handle, d_inputString, size, d_matched_result);
-    if (handle->perfMode == PFAC_SPACE_DRIVEN)
-        return handle->kernel_space_driven_ptr(handle, d_inputString, size, d_matched_result);
+    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;      /* never a CPU fallback */
+    correctTextureMode(c);
+    if (c->perfMode == PFAC_TIME_DRIVEN) return c->kernel_time_driven_ptr(c, d_inputString, size, d_matched_result);
+    if (c->perfMode == PFAC_SPACE_DRIVEN) return c->kernel_space_driven_ptr(c, d_inputString, size, d_matched_result);
     return PFAC_STATUS_INTERNAL_ERROR;
 }
 
-PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result)
+/*
+ * Host buffers through the GPU: results for positions [0, owned) of a stream of which `readable` >= owned bytes
+ * may be read (walks that start before `owned` may run into the rest: the slices of a sharded stream,
+ * omp_PFAC.cpp:324,377).  The caller holds c->lock.
+ *
+ * The reference allocates, uploads, scans, downloads and frees in sequence (PFAC.cpp:916-960), which leaves the
+ * scan idle for the 5 bytes per position that cross the host link.  Here the stream is cut into pieces of
+ * kHostPiece positions: piece i+1 is uploaded and piece i-1 downloaded while piece i is scanned (SURVEY 8f
+ * rank 2).  Each piece is scanned together with the maxPatternLen bytes behind it -- a walk may read that far --
+ * and only its own results go back.  The staging buffers, two copy streams and their events belong to the
+ * handle and are created on first use; the scan itself stays on the default stream.
+ */
+PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
 {
-    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
-    if (!h_inputString) return PFAC_STATUS_INVALID_PARAMETER;
-    if (!h_matched_result) return PFAC_STATUS_INVALID_PARAMETER;
-    if (size == 0) return PFAC_STATUS_SUCCESS;
-    if (handle->platform != PFAC_PLATFORM_GPU)
-        return matchHostOnCpuPlatform(handle, h_inputString, size, h_matched_result);
-    if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
-
-    /*
-     * The reference allocates, uploads, scans, downloads and frees in sequence (PFAC.cpp:916-960), which
-     * leaves the scan idle for the 5 bytes per position that cross the host link.  Here the stream is
-     * cut into pieces of kHostPiece positions: piece i+1 is uploaded and piece i-1 downloaded while
-     * piece i is scanned.  Each piece is scanned together with the maxPatternLen
-     * bytes behind it -- a walk may read that far -- and only its own results go back
-     * (omp_PFAC.cpp:324,377).  The staging buffers, two copy streams and their events belong to the
-     * handle and are created on first use; the scan itself stays on the default stream.
-     */
-    PFAC_context *c = handle;
+    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
     const size_t overlap = (size_t)c->fa.maxPatternLen;
-    const size_t piece = size < kHostPiece ? size : kHostPiece;
+    const size_t piece = owned < kHostPiece ? owned : kHostPiece;
     const size_t need = piece + overlap;
     if (c->hostStagePositions < need) {
         freeHostStage(c);
@@ -445,10 +458,10 @@ PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size
     PFAC_status_t st = PFAC_STATUS_SUCCESS;
     bool used[2] = {false, false};
     size_t i = 0;
-    for (size_t off = 0; off < size && st == PFAC_STATUS_SUCCESS; off += piece, i++) {
+    for (size_t off = 0; off < owned && st == PFAC_STATUS_SUCCESS; off += piece, i++) {
         const int b = (int)(i & 1);
-        const size_t owned = size - off < piece ? size - off : piece;
-        const size_t scanned = size - off < owned + overlap ? size - off : owned + overlap;
+        const size_t mine = owned - off < piece ? owned - off : piece;
+        const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
         hipEvent_t evUp = static_cast<hipEvent_t>(c->evUp[b]), evScan = static_cast<hipEvent_t>(c->evScan[b]),
                    evDown = static_cast<hipEvent_t>(c->evDown[b]);
         bool ok = true;
@@ -457,10 +470,10 @@ PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size
              hipEventRecord(evUp, up) == hipSuccess && hipStreamWaitEvent(nullptr, evUp, 0) == hipSuccess;
         if (ok && used[b]) ok = hipStreamWaitEvent(nullptr, evDown, 0) == hipSuccess;   /* its results have left this buffer */
         if (!ok) { st = PFAC_STATUS_INTERNAL_ERROR; break; }
-        st = PFAC_matchFromDevice(handle, c->d_stageIn[b], scanned, c->d_stageOut[b]);
+        st = matchDeviceLocked(c, c->d_stageIn[b], scanned, c->d_stageOut[b]);
         if (st != PFAC_STATUS_SUCCESS) break;
         ok = hipEventRecord(evScan, nullptr) == hipSuccess && hipStreamWaitEvent(down, evScan, 0) == hipSuccess &&
-             hipMemcpyAsync(h_matched_result + off, c->d_stageOut[b], owned * sizeof(int), hipMemcpyDeviceToHost, down) == hipSuccess &&
+             hipMemcpyAsync(h_matched_result + off, c->d_stageOut[b], mine * sizeof(int), hipMemcpyDeviceToHost, down) == hipSuccess &&
              hipEventRecord(evDown, down) == hipSuccess;
         if (!ok) st = PFAC_STATUS_INTERNAL_ERROR;
         used[b] = true;
@@ -469,6 +482,110 @@ PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size
                          hipStreamSynchronize(down) == hipSuccess;
     if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     return st;
+}
+
+} // namespace
+
+extern "C" {
+
+PFAC_status_t PFAC_matchFromDevice(PFAC_handle_t handle, char *d_inputString, size_t size, int *d_matched_result)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;                /* check order: ref PFAC.cpp:846-861 */
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!d_inputString) return PFAC_STATUS_INVALID_PARAMETER;
+    if (!d_matched_result) return PFAC_STATUS_INVALID_PARAMETER;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    std::lock_guard<std::mutex> guard(handle->lock);
+    return matchDeviceLocked(handle, d_inputString, size, d_matched_result);
+}
+
+PFAC_status_t PFAC_matchFromHost(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!h_inputString) return PFAC_STATUS_INVALID_PARAMETER;
+    if (!h_matched_result) return PFAC_STATUS_INVALID_PARAMETER;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    if (handle->platform != PFAC_PLATFORM_GPU)
+        return matchHostOnCpuPlatform(handle, h_inputString, size, h_matched_result);
+    std::lock_guard<std::mutex> guard(handle->lock);
+    return matchHostOnGpu(handle, h_inputString, size, size, h_matched_result);
+}
+
+/*
+ * pfac_ext.h: one call shards a host stream over several GPUs (what every user of the
+ * reference re-writes from PFAC/test/omp_PFAC.cpp:257-394 or SimpleMultiGPU_pthread.cpp:50-174).  One worker
+ * thread per listed device: hipSetDevice, a per-device handle with this handle's pattern set and modes (kept in
+ * the handle for the next call), a contiguous slice of the stream scanned together with the maxPatternLen bytes
+ * behind it, only the slice's own results written (omp_PFAC.cpp:324,377).  No exchange between devices.
+ */
+PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result,
+                                          int numDevices, const int *devices)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!h_inputString || !h_matched_result || numDevices < 0) return PFAC_STATUS_INVALID_PARAMETER;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
+    std::vector<int> devs;
+    if (numDevices == 0) {
+        for (int d = 0; d < visible; d++) devs.push_back(d);
+    } else {
+        for (int i = 0; i < numDevices; i++) {
+            const int d = devices ? devices[i] : i;
+            if (d < 0 || d >= visible) return PFAC_STATUS_INVALID_PARAMETER;
+            devs.push_back(d);
+        }
+    }
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    const size_t workers = devs.size();
+    /* the i-th worker's handle: bound to devs[i]; a device listed twice gets two handles (two streams of work) */
+    while (c->children.size() < workers) c->children.emplace_back(-1, nullptr);
+    std::vector<PFAC_status_t> status(workers, PFAC_STATUS_SUCCESS);
+    /* slice boundaries: contiguous, rounded to the 1 KiB tile (pfac_amd/sharding.py plan_slices is the Python mirror) */
+    std::vector<size_t> bound(workers + 1, 0);
+    for (size_t i = 1; i < workers; i++) {
+        size_t b = (size * i / workers) / 1024 * 1024;
+        bound[i] = b > bound[i - 1] ? b : bound[i - 1];
+    }
+    bound[workers] = size;
+    auto work = [&](size_t i) {
+        if (bound[i + 1] == bound[i]) return;
+        if (hipSetDevice(devs[i]) != hipSuccess) { status[i] = PFAC_STATUS_INTERNAL_ERROR; return; }
+        auto &child = c->children[i];
+        if (child.second && child.first != devs[i]) { (void)PFAC_destroy(child.second); child.second = nullptr; }
+        if (!child.second) {
+            PFAC_handle_t h = nullptr;
+            PFAC_status_t st = PFAC_create(&h);                    /* binds the current device */
+            if (st == PFAC_STATUS_SUCCESS) st = PFAC_setPerfMode(h, (PFAC_perfMode_t)c->perfMode);
+            if (st == PFAC_STATUS_SUCCESS) st = PFAC_setTextureMode(h, (PFAC_textureMode_t)c->textureMode);
+            if (st == PFAC_STATUS_SUCCESS) st = PFACX_setKernelVariant(h, c->kernelVariant);
+            if (st == PFAC_STATUS_SUCCESS)
+                st = PFACX_readPatternFromMemory(h, reinterpret_cast<const char *>(c->fa.file.data()), c->fa.file.size());
+            if (st != PFAC_STATUS_SUCCESS) { if (h) (void)PFAC_destroy(h); status[i] = st; return; }
+            child = {devs[i], h};
+        }
+        PFAC_context *w = child.second;
+        std::lock_guard<std::mutex> g(w->lock);
+        status[i] = matchHostOnGpu(w, h_inputString + bound[i], bound[i + 1] - bound[i], size - bound[i], h_matched_result + bound[i]);
+    };
+    int callerDevice = 0;
+    (void)hipGetDevice(&callerDevice);
+    std::vector<std::thread> threads;
+    try {
+        for (size_t i = 1; i < workers; i++) threads.emplace_back(work, i);
+    } catch (...) {
+        for (auto &t : threads) t.join();
+        return PFAC_STATUS_ALLOC_FAILED;
+    }
+    work(0);
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(callerDevice);
+    for (PFAC_status_t st : status)
+        if (st != PFAC_STATUS_SUCCESS) return st;
+    return PFAC_STATUS_SUCCESS;
 }
 
 PFAC_status_t PFAC_matchFromDeviceReduce(PFAC_handle_t handle, char *d_inputString, size_t size,
@@ -480,6 +597,7 @@ PFAC_status_t PFAC_matchFromDeviceReduce(PFAC_handle_t handle, char *d_inputStri
     if (size == 0) return PFAC_STATUS_SUCCESS;
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
     if (size > (size_t)0x7fffffff) return PFAC_STATUS_INVALID_PARAMETER;   /* int positions */
+    std::lock_guard<std::mutex> guard(handle->lock);          /* the match counter and the sort scratch belong to the handle */
     correctTextureMode(handle);
     PFAC_reduce_kernel_protoType fn =
         handle->perfMode == PFAC_TIME_DRIVEN ? handle->reduce_kernel_ptr : handle->reduce_inplace_kernel_ptr;
@@ -508,6 +626,7 @@ PFAC_status_t PFAC_matchFromHostReduce(PFAC_handle_t handle, char *h_inputString
         return PFAC_STATUS_SUCCESS;
     }
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
+    std::lock_guard<std::mutex> guard(handle->lock);
 
     char *d_in = nullptr;
     int *d_out = nullptr, *d_pos = nullptr;
@@ -590,6 +709,206 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
     default: return PFAC_STATUS_INVALID_PARAMETER;
     }
+    return PFAC_STATUS_SUCCESS;
+}
+
+} /* extern "C" */
+
+/* ---- compiled pattern sets on disk: the reference rebuilds everything per run
+ * (PFAC_reorder_Table.cpp:121-231, PFAC.cpp:653-735).  File = header + tagged sections; the dense table is not
+ * stored (S KiB: 0.5 GB for the 30 k-pattern set), it is refilled from the edges in a fraction of a second. */
+namespace {
+
+constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
+constexpr uint32_t kCompiledVersion = 1;
+/* what the stored tables depend on besides the patterns: hash constants and slot layout */
+constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kGram4Mul * 3u) ^ (pfac::kGram4Mul2 * 5u) ^ (pfac::kFinal3Mul * 7u) ^
+                                        ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;
+struct CompiledHeader {
+    char magic[8];
+    uint32_t version, fingerprint, perfMode, reserved;
+    uint64_t payloadBytes, payloadFnv1a;
+};
+enum Section : uint32_t { kSecFile = 1, kSecScalars, kSecPatOff, kSecPatLen, kSecSorted, kSecEdgeBegin, kSecEdgeCh, kSecEdgeNext,
+                          kSecFilter, kSecGram3, kSecGram4, kSecFinal3, kSecShort, kSecHashRow, kSecHashVal, kSecChain, kSecRoot, kSecInitialRow };
+
+uint64_t fnv1a64(const unsigned char *p, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+template <class T>
+void putSection(std::vector<unsigned char> &out, uint32_t tag, const T *data, size_t count)
+{
+    const uint64_t bytes = (uint64_t)count * sizeof(T);
+    const unsigned char *t = reinterpret_cast<const unsigned char *>(&tag), *b = reinterpret_cast<const unsigned char *>(&bytes);
+    out.insert(out.end(), t, t + 4);
+    out.insert(out.end(), b, b + 8);
+    const unsigned char *d = reinterpret_cast<const unsigned char *>(data);
+    out.insert(out.end(), d, d + bytes);
+}
+
+template <class T>
+bool takeSection(const unsigned char *p, uint64_t bytes, std::vector<T> &v)
+{
+    if (bytes % sizeof(T)) return false;
+    v.resize(bytes / sizeof(T));
+    if (bytes) std::memcpy(v.data(), p, bytes);
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!filename) return PFAC_STATUS_INVALID_PARAMETER;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    try {
+        if (c->h_chainSlots.empty()) {                         /* host-only handle: the chained table was never needed */
+            const bool dev = c->hasDevice;
+            c->hasDevice = false;
+            const PFAC_status_t st = uploadChainedHashTable(c);
+            c->hasDevice = dev;
+            if (st != PFAC_STATUS_SUCCESS) return st;
+        }
+        const pfac::Automaton &fa = c->fa;
+        const pfac::Filter &f = c->filter;
+        std::vector<unsigned char> payload;
+        putSection(payload, kSecFile, fa.file.data(), fa.file.size());
+        const int32_t scalars[5] = {fa.numPatterns, fa.maxPatternLen, fa.initialState, fa.numStates, fa.numLeaves};
+        putSection(payload, kSecScalars, scalars, 5);
+        putSection(payload, kSecPatOff, fa.patternOff.data(), fa.patternOff.size());
+        putSection(payload, kSecPatLen, fa.patternLen.data(), fa.patternLen.size());
+        putSection(payload, kSecSorted, fa.sortedId.data(), fa.sortedId.size());
+        putSection(payload, kSecEdgeBegin, fa.edgeBegin.data(), fa.edgeBegin.size());
+        putSection(payload, kSecEdgeCh, fa.edgeCh.data(), fa.edgeCh.size());
+        putSection(payload, kSecEdgeNext, fa.edgeNext.data(), fa.edgeNext.size());
+        const uint64_t filt[6] = {(uint64_t)f.log2Bits, (uint64_t)f.log2Bits4, (uint64_t)f.log2BitsF3, f.hasShort ? 1u : 0u, f.bitsSet, f.bitsSet4};
+        putSection(payload, kSecFilter, filt, 6);
+        putSection(payload, kSecGram3, f.gram3.data(), f.gram3.size());
+        putSection(payload, kSecGram4, f.gram4.data(), f.gram4.size());
+        putSection(payload, kSecFinal3, f.final3.data(), f.final3.size());
+        putSection(payload, kSecShort, f.shortBits.data(), f.shortBits.size());
+        if (c->perfMode == PFAC_SPACE_DRIVEN) {
+            putSection(payload, kSecHashRow, c->h_hashRow.data(), c->h_hashRow.size());
+            putSection(payload, kSecHashVal, c->h_hashVal.data(), c->h_hashVal.size());
+        }
+        putSection(payload, kSecChain, c->h_chainSlots.data(), c->h_chainSlots.size());
+        putSection(payload, kSecRoot, c->h_rootSlots.data(), c->h_rootSlots.size());
+        putSection(payload, kSecInitialRow, c->h_initialRow.data(), c->h_initialRow.size());
+        CompiledHeader h;
+        std::memset(&h, 0, sizeof(h));
+        std::memcpy(h.magic, kCompiledMagic, 8);
+        h.version = kCompiledVersion; h.fingerprint = kLayoutFingerprint; h.perfMode = (uint32_t)c->perfMode;
+        h.payloadBytes = payload.size(); h.payloadFnv1a = fnv1a64(payload.data(), payload.size());
+        FILE *fp = std::fopen(filename, "wb");
+        if (!fp) return PFAC_STATUS_FILE_OPEN_ERROR;
+        const bool ok = std::fwrite(&h, sizeof(h), 1, fp) == 1 && (payload.empty() || std::fwrite(payload.data(), payload.size(), 1, fp) == 1);
+        return (std::fclose(fp) == 0 && ok) ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+}
+
+PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!filename) return PFAC_STATUS_INVALID_PARAMETER;
+    FILE *fp = std::fopen(filename, "rb");
+    if (!fp) return PFAC_STATUS_FILE_OPEN_ERROR;
+    CompiledHeader h;
+    std::vector<unsigned char> payload;
+    bool ok = std::fread(&h, sizeof(h), 1, fp) == 1 && std::memcmp(h.magic, kCompiledMagic, 8) == 0 && h.version == kCompiledVersion &&
+              h.fingerprint == kLayoutFingerprint && (h.perfMode == PFAC_TIME_DRIVEN || h.perfMode == PFAC_SPACE_DRIVEN) &&
+              h.payloadBytes < (uint64_t(1) << 40);
+    try {
+        if (ok) {
+            payload.resize((size_t)h.payloadBytes);
+            ok = payload.empty() || std::fread(payload.data(), payload.size(), 1, fp) == 1;
+        }
+    } catch (const std::bad_alloc &) { std::fclose(fp); return PFAC_STATUS_ALLOC_FAILED; }
+    std::fclose(fp);
+    if (!ok || fnv1a64(payload.data(), payload.size()) != h.payloadFnv1a) return PFAC_STATUS_INVALID_PARAMETER;   /* not a compiled set of this build, or damaged */
+
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    if (c->isPatternsReady) freeResources(c);
+    c->patternFile = filename;
+    c->perfMode = (int)h.perfMode;
+    pfac::Automaton &fa = c->fa;
+    pfac::Filter &f = c->filter;
+    std::vector<int32_t> scalars;
+    std::vector<uint64_t> filt;
+    try {
+        size_t at = 0;
+        while (ok && at + 12 <= payload.size()) {
+            uint32_t tag; uint64_t bytes;
+            std::memcpy(&tag, &payload[at], 4); std::memcpy(&bytes, &payload[at + 4], 8);
+            at += 12;
+            if (bytes > payload.size() - at) { ok = false; break; }
+            const unsigned char *p = payload.data() + at;
+            switch (tag) {
+            case kSecFile: ok = takeSection(p, bytes, fa.file); break;
+            case kSecScalars: ok = takeSection(p, bytes, scalars); break;
+            case kSecPatOff: ok = takeSection(p, bytes, fa.patternOff); break;
+            case kSecPatLen: ok = takeSection(p, bytes, fa.patternLen); break;
+            case kSecSorted: ok = takeSection(p, bytes, fa.sortedId); break;
+            case kSecEdgeBegin: ok = takeSection(p, bytes, fa.edgeBegin); break;
+            case kSecEdgeCh: ok = takeSection(p, bytes, fa.edgeCh); break;
+            case kSecEdgeNext: ok = takeSection(p, bytes, fa.edgeNext); break;
+            case kSecFilter: ok = takeSection(p, bytes, filt); break;
+            case kSecGram3: ok = takeSection(p, bytes, f.gram3); break;
+            case kSecGram4: ok = takeSection(p, bytes, f.gram4); break;
+            case kSecFinal3: ok = takeSection(p, bytes, f.final3); break;
+            case kSecShort: ok = takeSection(p, bytes, f.shortBits); break;
+            case kSecHashRow: ok = takeSection(p, bytes, c->h_hashRow); break;
+            case kSecHashVal: ok = takeSection(p, bytes, c->h_hashVal); break;
+            case kSecChain: ok = takeSection(p, bytes, c->h_chainSlots); break;
+            case kSecRoot: ok = takeSection(p, bytes, c->h_rootSlots); break;
+            case kSecInitialRow: ok = takeSection(p, bytes, c->h_initialRow); break;
+            default: break;                                    /* unknown section of a later writer: skipped */
+            }
+            at += (size_t)bytes;
+        }
+        ok = ok && scalars.size() == 5 && filt.size() == 6;
+        if (ok) {
+            fa.numPatterns = scalars[0]; fa.maxPatternLen = scalars[1]; fa.initialState = scalars[2];
+            fa.numStates = scalars[3]; fa.numLeaves = scalars[4];
+            f.log2Bits = (int)filt[0]; f.log2Bits4 = (int)filt[1]; f.log2BitsF3 = (int)filt[2]; f.hasShort = filt[3] != 0;
+            f.bitsSet = (size_t)filt[4]; f.bitsSet4 = (size_t)filt[5];
+            const size_t S = (size_t)(fa.numStates > 0 ? fa.numStates : 0), F = (size_t)(fa.numPatterns >= 0 ? fa.numPatterns : 0);
+            ok = fa.numStates > 0 && fa.numPatterns >= 0 && fa.initialState == fa.numPatterns + 1 && (size_t)fa.initialState < S &&
+                 fa.patternOff.size() == F + 1 && fa.patternLen.size() == F + 1 && fa.sortedId.size() == F &&
+                 fa.edgeBegin.size() == S + 1 && fa.edgeCh.size() == fa.edgeNext.size() && !fa.edgeBegin.empty() &&
+                 (size_t)fa.edgeBegin.back() == fa.edgeCh.size() &&
+                 f.log2Bits >= 5 && f.log2Bits <= 19 && f.log2Bits4 >= 5 && f.log2Bits4 <= 17 && f.log2BitsF3 >= 5 && f.log2BitsF3 <= 16 &&
+                 f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.gram4.size() == (size_t(1) << f.log2Bits4) / 32 &&
+                 f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
+                 c->h_initialRow.size() == (size_t)pfac::kCharSet && c->h_rootSlots.size() == (size_t)pfac::kCharSet &&
+                 (h.perfMode == PFAC_TIME_DRIVEN || (c->h_hashRow.size() == S && c->h_hashVal.size() == c->h_chainSlots.size()));
+            for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0;
+            for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S;
+            /* a slot's bucket must lie inside the slot array: the walker indexes it without a bound on the global path */
+            const size_t slots = c->h_chainSlots.size();
+            auto slotOk = [&](const pfac::ChainSlot &sl) {
+                if (sl.meta & (pfac::kSlotEmpty | pfac::kSlotLeaf)) return true;
+                const size_t sizeMask = sl.meta >> 24;
+                return sl.endRow >= 0 && (size_t)sl.endRow + sizeMask < slots;
+            };
+            for (size_t i = 0; ok && i < slots; i++) ok = slotOk(c->h_chainSlots[i]);
+            for (size_t i = 0; ok && i < c->h_rootSlots.size(); i++) ok = slotOk(c->h_rootSlots[i]);
+        }
+    } catch (const std::bad_alloc &) { freeResources(c); return PFAC_STATUS_ALLOC_FAILED; }
+    if (!ok) { freeResources(c); return PFAC_STATUS_INVALID_PARAMETER; }
+    c->isPatternsReady = true;
+    PFAC_status_t st = bindCommon(c, /*build=*/false);
+    if (st == PFAC_STATUS_SUCCESS) st = bindTable(c);
+    if (st != PFAC_STATUS_SUCCESS) { freeResources(c); return st; }
     return PFAC_STATUS_SUCCESS;
 }
 

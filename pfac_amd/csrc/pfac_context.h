@@ -13,7 +13,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "PFAC.h"
@@ -35,7 +37,8 @@ struct Int2 { int x, y; };                    /* device layout of the hashed tab
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
 constexpr int kWorkCounterWords = 64 * 32;   /* one counter per 128-byte line */
 constexpr int kStatsWord = 1536;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
-constexpr int kStatsCount = 4;                  /* walker rounds, lane steps, walks started, level-1 hits */
+constexpr int kStatsCount = 5;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned */
+constexpr double kAutoDenseHitRate = 0.6;     /* PFACX_KERNEL_AUTO: above this level-1 hit rate the simple kernel is the faster one */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS
 #define PFAC_WALK_SETS 2                       /* independent walks per lane */
@@ -136,6 +139,7 @@ struct PFAC_context {
     pfac::Int2 *d_hashRow = nullptr;
     pfac::Int2 *d_hashVal = nullptr;
     int *d_initialRow = nullptr;
+    std::vector<pfac::ChainSlot> h_chainSlots, h_rootSlots;   /* host copies of the chained table (PFACX_saveCompiled)    */
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
     pfac::ChainSlot *d_rootSlots = nullptr;   /* the 256 transitions of the initial state, same encoding           */
     size_t numChainSlots = 0;
@@ -173,6 +177,17 @@ struct PFAC_context {
     int perfMode = PFAC_TIME_DRIVEN;
     int textureMode = PFAC_AUTOMATIC;
     int kernelVariant = PFACX_KERNEL_AUTO;
+
+    /* One handle may be shared by host threads (the reference serialises them with its texture mutex,
+     * PFAC.cpp:37-56): every entry point that touches per-handle device state -- chunk counters, the counter and
+     * scratch of the compacted-output path, the host staging buffers -- holds this lock for the call. */
+    std::mutex lock;
+    /* per-device handles of PFACX_matchFromHostMultiGPU, created on first use: (device, handle) */
+    std::vector<std::pair<int, PFAC_context *>> children;
+    /* PFACX_KERNEL_AUTO: level-1 hit density of recent filter launches, copied to pinned host memory behind each
+     * launch (no synchronisation: a heuristic reads whatever has arrived) */
+    unsigned long long *h_statsPinned = nullptr;          /* kStatsCount counters + the positions they refer to */
+    unsigned int autoCalls = 0;
 
     bool hasDevice = false;
     int device = -1;

@@ -842,7 +842,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits);
     }
     __syncthreads();
-    if (tid < pfac::kStatsCount) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
+    if (tid < 4) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
+    if (tid == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord)[4] = a.n;
 #if PFAC_STATS
     if (lane == 0 && (blockIdx.x % 32) == 0 && wave == 0)
         printf("STATS block %d wave0 fullRounds %u slotGathers %u winLoads %u startDead %u\n", (int)blockIdx.x, stFullRounds, stSlotGathers, stWinLoads, stStartDead);
@@ -929,7 +930,13 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
-    return hipGetLastError();
+    e = hipGetLastError();
+    /* PFACX_KERNEL_AUTO looks at the level-1 hit density of recent launches: their counters follow the kernel
+     * into pinned host memory, nobody waits for them */
+    if (e == hipSuccess && c->kernelVariant == PFACX_KERNEL_AUTO && c->h_statsPinned)
+        e = hipMemcpyAsync(c->h_statsPinned, c->d_workCounters + pfac::kStatsWord, pfac::kStatsCount * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, 0);
+    return e;
 }
 
 template <int MODE>
@@ -1009,7 +1016,18 @@ constexpr size_t kSmallInput = size_t(1) << 20;
 size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
 {
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
-    if (c->kernelVariant == PFACX_KERNEL_AUTO && ownEnd - first < kSmallInput) return 0;   /* filling 134 KiB of LDS per block costs more than scanning this */
+    if (c->kernelVariant == PFACX_KERNEL_AUTO) {
+        if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
+        /* pattern-dense input (most positions pass level 1, e.g. 1-byte patterns over text): the prefilter only adds
+         * work and the simple kernel is faster.  Judged by what recent launches on this handle saw; every 8th call
+         * takes the filter kernel anyway, so the estimate follows the data. */
+        if (c->h_statsPinned) {
+            const volatile unsigned long long *st = c->h_statsPinned;
+            const unsigned long long hits = st[3], positions = st[4];
+            PFAC_context *mc = const_cast<PFAC_context *>(c);
+            if (positions && (double)hits > pfac::kAutoDenseHitRate * (double)positions && (++mc->autoCalls & 7u) != 0) return 0;
+        }
+    }
     const size_t margin = (size_t)c->fa.maxPatternLen + 32;
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
     const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;

@@ -1,0 +1,387 @@
+"""GPU parity, second batch: full-size results against digests of the REFERENCE's CPU/OMP output, the host-buffer
+path against the oracle, hostile pattern sets (1..243-byte patterns, 600 / 2000-byte patterns, an input in which
+every position matches), compiled-set files, the multi-GPU driver and shared handles.
+
+Reference models: PFAC/test/omp_PFAC.cpp:257-439 (sliced run == single run), PFAC/test/SimpleMultiGPU_pthread.cpp:
+50-174 (one thread per context), PFAC/src/PFAC_kernel.cu:102-108,301-345 (patterns longer than 511 bytes),
+PFAC/doc/PFAC_algorithm.pdf 6.1 (Snort pattern lengths 1..243).
+"""
+
+import hashlib
+import json
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from pfac_amd import api, sharding  # noqa: E402
+from pfac_amd import workloads as wl  # noqa: E402
+from tests.test_gpu_parity import MODES, assert_same, device_match, make_handle  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert torch.cuda.is_available(), "GPU tests need a device; there is no CPU fallback to test"
+    torch.cuda.set_device(0)
+
+
+def _digest_record(workload, slice_index, size_mib):
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "full_digests.json")))
+    for r in doc["records"]:
+        if (r["workload"], r["slice"], r["size_mib"]) == (workload, slice_index, size_mib):
+            return r
+    raise KeyError((workload, slice_index, size_mib))
+
+
+# ------------------------------------------------------------------------------------- full size == reference
+
+@pytest.mark.parametrize("workload,perf,slice_index,variant", [
+    ("c2", api.PFAC_TIME_DRIVEN, 0, "last"), ("c3", api.PFAC_SPACE_DRIVEN, 0, "last"),
+    ("c5", api.PFAC_TIME_DRIVEN, 0, "last"), ("c5", api.PFAC_SPACE_DRIVEN, 0, "last"),
+    ("c3", api.PFAC_SPACE_DRIVEN, 1, "inner"),
+])
+def test_full_size_result_equals_reference_digest(workdir, workload, perf, slice_index, variant):
+    """BASELINE.json sizes (1 GiB): the whole int32 result vector of PFAC_matchFromDevice has the SHA-256,
+    FNV-1a-64, match count and position checksum of the REFERENCE's own PFAC_CPU_OMP result on the same stream
+    (tests/golden/full_digests.json, produced by tests/golden/make_full_digests.py from oracle/_ref).  `inner`
+    = a slice of the multi-GPU stream scanned with the head of its successor (BASELINE config 4)."""
+    n = 1 << 30
+    rec = _digest_record(workload, slice_index, 1024)
+    cfg = wl.make_config(workload)
+    pf = wl.write_pattern_file(f"{workdir}/digest_{workload}.pat", cfg.patterns)
+    assert wl.fnv1a(np.fromfile(pf, dtype=np.uint8)) == rec["pattern_file_fnv1a"], "pattern generator drifted"
+    overlap = rec["overlap"] if variant == "inner" else 0
+    host = np.empty(n + overlap, dtype=np.uint8)
+    host[:n] = cfg.input_slice(n, slice_index)
+    if overlap:
+        host[n:] = cfg.input_slice(overlap, slice_index + 1)
+    assert wl.fnv1a(host[:n]) == rec["input_fnv1a"], "input generator drifted"
+    d_in = torch.from_numpy(host).to("cuda:0")
+    d_out = torch.full((n + overlap,), -1, dtype=torch.int32, device="cuda:0")
+    h = make_handle(pf, perf, api.PFAC_AUTOMATIC)
+    try:
+        h.matchFromDevice(d_in.data_ptr(), n + overlap, d_out.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        h.destroy()
+    got = d_out[:n].cpu().numpy()
+    del d_in, d_out
+    want = rec[variant]
+    pos = np.flatnonzero(got)
+    assert int(pos.size) == want["match_count"]
+    assert sharding.position_checksum(pos, got[pos], base=slice_index * n) == want["checksum"]
+    assert wl.fnv1a_sparse_i32(pos, got[pos], n) == want["fnv1a64"]
+    assert hashlib.sha256(got.view(np.uint8)).hexdigest() == want["sha256"]
+
+
+# ------------------------------------------------------------------------------------- host buffers
+
+def test_match_from_host_pieces_equal_oracle(workdir):
+    """PFAC_matchFromHost on the GPU platform scans in 32 Mi-position pieces with overlapped copies (SURVEY 8f
+    rank 2): a 70 MiB stream (three pieces) and a 64 MiB + 10 stream (last piece shorter than the longest
+    pattern) against the ORACLE, including matches that straddle the cuts; matchFromDevice as well."""
+    from oracle import binding as ob
+    pats = wl.snort_patterns(2000)
+    pf = wl.write_pattern_file(os.path.join(workdir, "hostpipe2.pat"), pats)
+    n = (70 << 20) + 12345
+    data = wl.http_stream(n, wl.http_message_pool(pats, pool_size=256, embed_fraction=0.3)).copy()
+    longest = max(pats, key=len)
+    straddlers = [(32 << 20) - 1, (64 << 20) - len(longest) // 2, (64 << 20) - 300]
+    for at in straddlers:
+        data[at:at + len(longest)] = np.frombuffer(longest, dtype=np.uint8)
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF)
+    try:
+        for size in (n, (64 << 20) + 10):
+            if size != n:                                        # a match that ends with the 10-byte last piece
+                data[size - len(longest):size] = np.frombuffer(longest, dtype=np.uint8)
+                straddlers = [(32 << 20) - 1, size - len(longest)]
+            want = o.match(data[:size], hashed=True, omp=True)
+            got = np.full(size, -7, dtype=np.int32)
+            h.matchFromHost(data.ctypes.data, size, got.ctypes.data)
+            assert_same(got, want, f"pipelined matchFromHost, {size} bytes")
+            assert_same(device_match(h, data[:size]), want, f"matchFromDevice, {size} bytes")
+            assert all(want[at] != 0 for at in straddlers)      # matches that straddle a cut
+    finally:
+        h.destroy()
+        o.close()
+
+
+# ------------------------------------------------------------------------------------- hostile pattern sets
+
+def _timed_match(h, data, steps=5):
+    from pfac_amd import hiprt
+    n = int(data.size)
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
+    d_out = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+    h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+    torch.cuda.synchronize()
+    a, b = hiprt.Event(), hiprt.Event()
+    a.record(0)
+    for _ in range(steps):
+        h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+    b.record(0)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), n / (a.elapsed_ms(b) / steps / 1e3) / 1e9
+
+
+def test_snort_length_distribution_with_1_and_2_byte_patterns(workdir, capsys):
+    """PFAC_algorithm.pdf 6.1: the published Snort set has lengths 1..243.  3 000 patterns with that range --
+    1- and 2-byte patterns included, which set whole rows of the exact short-pattern bitmap -- over 64 MiB of
+    text: every mode and both kernels against the oracle; GB/s of the two kernels reported."""
+    from oracle import binding as ob
+    rng = np.random.Generator(np.random.PCG64(2431))
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 /.-_=&%:", dtype=np.uint8)
+    pats = {b"q", b"Z", b"zq", b"0x", b"%%"}
+    while len(pats) < 3000:
+        u = rng.random()
+        ln = int(rng.integers(1, 3)) if u < 0.01 else int(rng.integers(3, 40)) if u < 0.8 else int(rng.integers(40, 244))
+        pats.add(alpha[rng.integers(0, alpha.size, ln)].tobytes())
+    pats = sorted(pats, key=lambda p: (rng.random(), p))
+    assert max(map(len, pats)) > 200 and min(map(len, pats)) == 1
+    pf = wl.write_pattern_file(os.path.join(workdir, "snortlen.pat"), pats)
+    n = 64 << 20
+    data = alpha[rng.integers(0, alpha.size, n)].copy()
+    for k in range(400):                                         # plant long patterns, some across 2 KiB / 8 KiB boundaries
+        p = np.frombuffer(pats[int(rng.integers(0, len(pats)))], dtype=np.uint8)
+        at = int(rng.integers(0, n - 300)) if k % 4 else (int(rng.integers(1, n >> 13)) << 13) - int(rng.integers(1, 200))
+        data[at:at + p.size] = p
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    assert np.count_nonzero(want) > n // 64                     # the 1-byte patterns make matches dense
+    rates = {}
+    for perf, tex, mode_name in MODES:
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto")):
+            h = make_handle(pf, perf, tex, variant)
+            try:
+                got, rate = _timed_match(h, data)
+                assert_same(got, want, f"snort lengths / {mode_name} / {vname}")
+                rates[f"{mode_name}/{vname}"] = round(rate, 1)
+            finally:
+                h.destroy()
+    with capsys.disabled():
+        print("\n[snort-length set, 64 MiB, 1-byte patterns present] input GB/s:", rates)
+
+
+@pytest.mark.parametrize("perf,tex,mode_name", MODES)
+def test_patterns_longer_than_511_bytes(workdir, perf, tex, mode_name):
+    """The reference has a separate code path for maxPatternLen > 511 (PFAC_kernel.cu:102-108, 301-345).  One
+    600-byte and one 2 000-byte pattern (plus short ones), planted across chunk (2 KiB), span (8 KiB) and
+    filter-kernel / tail-kernel boundaries, complete and with a wrong last byte."""
+    from oracle import binding as ob
+    rng = np.random.Generator(np.random.PCG64(600))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    p600 = alpha[rng.integers(0, 4, 600)].tobytes()
+    p2000 = alpha[rng.integers(0, 4, 2000)].tobytes()
+    pats = [p600, p2000, p600[:40] + b"N", b"ACGTNN", p2000[100:130]]
+    pf = wl.write_pattern_file(os.path.join(workdir, "long.pat"), pats)
+    n = (3 << 20) + 777
+    data = np.frombuffer(b"N", dtype=np.uint8).repeat(n).copy()
+    spots = [5, 2048 - 300, 8192 - 1000, (1 << 20) - 1999, (2 << 20) - 17, n - 2000, n - 2600, n - 4096 - 600, n - 2032 - 600 + 3]
+    for k, at in enumerate(spots):
+        p = np.frombuffer(p2000 if k % 2 else p600, dtype=np.uint8)
+        at = min(at, n - p.size)
+        data[at:at + p.size] = p
+        if k % 3 == 2:
+            data[at + p.size - 1] = ord("N")                     # near miss: walks the whole pattern, reports a shorter one or nothing
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    assert set(np.unique(want)) >= {0, 1, 2}
+    for variant in (api.PFACX_KERNEL_FILTER, api.PFACX_KERNEL_AUTO):
+        h = make_handle(pf, perf, tex, variant)
+        try:
+            assert h.info().maxPatternLen == 2000
+            assert_same(device_match(h, data), want, f"long patterns / {mode_name} / variant {variant}")
+            got = np.full(n, -3, dtype=np.int32)
+            h.matchFromHost(data.ctypes.data, n, got.ctypes.data)
+            assert_same(got, want, f"long patterns / matchFromHost / {mode_name}")
+        finally:
+            h.destroy()
+
+
+def test_every_position_matches_256_mib(workdir, capsys):
+    """Patterns a, aa, ..., a x 8 over 256 MiB of 'a': every position reports a pattern (the longest that fits).
+    All 2^28 level-1 tests hit, every queue is full all the time, every walk patches its zero: the ordering of
+    zero stores and patches and the back-pressure paths at scale.  Must be bit-exact and must not hang."""
+    from oracle import binding as ob
+    pats = [b"a" * k for k in range(1, 9)]
+    pf = wl.write_pattern_file(os.path.join(workdir, "allmatch.pat"), pats)
+    n = 256 << 20
+    data = np.full(n, ord("a"), dtype=np.uint8)
+    data[n // 3] = ord("b")                                      # one hole: results count down towards it
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    assert np.count_nonzero(want) == n - 1
+    rates = {}
+    for perf, tex, mode_name in (MODES[1], MODES[3]):
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")):
+            h = make_handle(pf, perf, tex, variant)
+            try:
+                got, rate = _timed_match(h, data, steps=2)
+                assert_same(got, want, f"all-match / {mode_name} / {vname}")
+                rates[f"{mode_name}/{vname}"] = round(rate, 1)
+            finally:
+                h.destroy()
+    # PFACX_KERNEL_AUTO: after one filter launch on this input the handle switches to the simple kernel
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    try:
+        got, rate = _timed_match(h, data, steps=6)
+        assert_same(got, want, "all-match / auto")
+        rates["auto (density-driven)"] = round(rate, 1)
+    finally:
+        h.destroy()
+    with capsys.disabled():
+        print("\n[every position matches, 256 MiB] input GB/s:", rates)
+
+
+# ------------------------------------------------------------------------------------- pattern ingest
+
+def test_patterns_from_memory_and_compiled_files_on_the_gpu(workloads, oracle_results, tmp_path):
+    """PFACX_readPatternFromMemory and PFACX_saveCompiled / PFACX_loadCompiled feed the same
+    kernels: results equal the oracle in both perf modes; a set saved by a host-only handle loads on the GPU."""
+    for name in ("c3", "c5", "dense_hits"):
+        w = workloads[name]
+        raw = open(w.pattern_file, "rb").read()
+        for perf, tex, mode_name in (MODES[1], MODES[2]):
+            h = api.PFAC.create()
+            h.setPerfMode(perf)
+            h.setTextureMode(tex)
+            h.setKernelVariant(api.PFACX_KERNEL_FILTER)
+            h.readPatternFromMemory(raw)
+            assert_same(device_match(h, w.data), oracle_results[name], f"{name}/{mode_name} patterns from memory")
+            f1 = str(tmp_path / f"{name}_{mode_name}.pfacx")
+            h.saveCompiled(f1)
+            h.destroy()
+            h2 = api.PFAC.create()
+            h2.setKernelVariant(api.PFACX_KERNEL_FILTER)
+            h2.setTextureMode(tex)
+            h2.loadCompiled(f1)
+            assert h2.info().perfMode == perf
+            assert_same(device_match(h2, w.data), oracle_results[name], f"{name}/{mode_name} loaded compiled set")
+            got = np.full(w.data.size, -7, dtype=np.int32)
+            h2.matchFromHost(w.data.ctypes.data, w.data.size, got.ctypes.data)
+            assert_same(got, oracle_results[name], f"{name}/{mode_name} loaded compiled set, matchFromHost")
+            h2.destroy()
+        # saved without a device, loaded with one
+        ho = api.PFAC.createHostOnly()
+        ho.setPerfMode(api.PFAC_SPACE_DRIVEN)
+        ho.readPatternFromFile(w.pattern_file)
+        f2 = str(tmp_path / f"{name}_hostonly.pfacx")
+        ho.saveCompiled(f2)
+        ho.destroy()
+        h3 = api.PFAC.create()
+        h3.setKernelVariant(api.PFACX_KERNEL_FILTER)
+        h3.loadCompiled(f2)
+        assert_same(device_match(h3, w.data), oracle_results[name], f"{name} host-only compiled set on the GPU")
+        h3.destroy()
+
+
+# ------------------------------------------------------------------------------------- several GPUs, several threads
+
+def test_multi_gpu_driver_on_one_device(workdir):
+    """PFACX_matchFromHostMultiGPU: the library shards a host stream over the listed devices,
+    one worker thread and one internal handle each (SimpleMultiGPU_pthread.cpp:50-174).  Listing device 0 several
+    times exercises the whole path on a one-GPU box; the result must equal the oracle, including matches across
+    the slice boundaries, for 1, 2 and 3 workers and on repeated calls (cached per-device handles)."""
+    from oracle import binding as ob
+    pats = wl.snort_patterns(3000)
+    pf = wl.write_pattern_file(os.path.join(workdir, "multigpu.pat"), pats)
+    n = (48 << 20) + 4321
+    data = wl.http_stream(n, wl.http_message_pool(pats, pool_size=256, embed_fraction=0.3)).copy()
+    longest = np.frombuffer(max(pats, key=len), dtype=np.uint8)
+    for workers in (2, 3):
+        for i in range(1, workers):
+            cut = (n * i // workers) // 1024 * 1024
+            data[cut - longest.size // 2: cut - longest.size // 2 + longest.size] = longest
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    want = o.match(data, hashed=True, omp=True)
+    o.close()
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON)
+    try:
+        for devices in ([0], [0, 0], [0, 0, 0], None, [0, 0]):
+            got = np.full(n, -7, dtype=np.int32)
+            h.matchFromHostMultiGPU(data.ctypes.data, n, got.ctypes.data, devices)
+            assert_same(got, want, f"multi-GPU driver, devices {devices}")
+        if torch.cuda.device_count() <= 7:
+            assert h.matchFromHostMultiGPU(data.ctypes.data, n, got.ctypes.data, [7], check=False) == api.STATUS.INVALID_PARAMETER
+        assert_same(device_match(h, data[: 1 << 20]), o_prefix(pf, data[: 1 << 20]), "the handle itself still works")
+    finally:
+        h.destroy()
+
+
+def o_prefix(pf, data):
+    from oracle import binding as ob
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    try:
+        return o.match(data, hashed=True, omp=True)
+    finally:
+        o.close()
+
+
+def test_two_host_threads_share_one_handle(workloads, oracle_results):
+    """The reference serialises threads that share a handle with its texture mutex (PFAC.cpp:37-56).  Here two
+    host threads call matchFromDevice, matchFromDeviceReduce and matchFromHost on ONE handle at the same time:
+    every call must return its own complete, correct result (chunk counters, match counter, sort scratch and
+    staging buffers are per-handle state)."""
+    w = workloads["c3"]
+    want = oracle_results["c3"]
+    nz = np.flatnonzero(want)
+    h = make_handle(w.pattern_file, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON)
+    n = int(w.data.size)
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            d_in = torch.from_numpy(w.data).to("cuda:0")
+            for it in range(12):
+                d_out = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                if (it + k) % 3 == 0:
+                    h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+                    torch.cuda.synchronize()
+                    assert_same(d_out.cpu().numpy(), want, f"thread {k} call {it} matchFromDevice")
+                elif (it + k) % 3 == 1:
+                    _, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_out.data_ptr(), d_pos.data_ptr())
+                    assert count == nz.size and np.array_equal(d_pos[:count].cpu().numpy(), nz) and \
+                        np.array_equal(d_out[:count].cpu().numpy(), want[nz]), f"thread {k} call {it} reduce"
+                else:
+                    got = np.full(n, -7, dtype=np.int32)
+                    h.matchFromHost(w.data.ctypes.data, n, got.ctypes.data)
+                    assert_same(got, want, f"thread {k} call {it} matchFromHost")
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    h.destroy()
+    assert not errors, errors[0]
+
+
+def test_cpp_multi_gpu_example(workdir):
+    """examples/multi_gpu.cpp: PFACX_matchFromHostMultiGPU from C++ with three workers, self-checked against a
+    single-device scan the way PFAC/test/omp_PFAC.cpp:396-439 checks its sliced run."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-B"], stdout=subprocess.DEVNULL)
+    pats = wl.snort_patterns(1500)
+    pf = wl.write_pattern_file(os.path.join(workdir, "cpp_multi.pat"), pats)
+    data = wl.http_stream((9 << 20) + 77, wl.http_message_pool(pats, pool_size=128, embed_fraction=0.3))
+    inp = os.path.join(workdir, "cpp_multi.in")
+    data.tofile(inp)
+    out = subprocess.run([os.path.join(ROOT, "examples", "multi_gpu"), pf, inp, "3"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 differences" in out.stdout and "3 worker(s)" in out.stdout

@@ -123,3 +123,31 @@ def test_two_rank_gloo_scan_equals_single_scan(tmp_path):
         sel = (pos >= r * n) & (pos < (r + 1) * n)
         per_rank.append([int(sel.sum()), sharding.position_checksum(pos[sel], res[pos[sel]]) & 0x7FFFFFFFFFFFFFFF])
     assert facts == per_rank
+
+
+def test_bench_spawns_the_ranks_itself_and_checks_the_reference_digests():
+    """`python bench.py --gpus 2` must start two rank processes on its own (the driver's command shape) and fold
+    their results against the committed digests of the reference's CPU/OMP output (omp_PFAC.cpp:396-439).  Here on
+    the library's CPU_OMP platform over gloo (no GPU in this container): slices 0 and 1 of the 8 MiB c3 stream."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--platform", "cpu_omp", "--dist-backend", "gloo",
+                        "--size-mib", "8", "--steps", "1", "--warmup", "0", "--workload", "c3"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == [0, 1]
+    assert out["config"]["bit_exact"] is True and "digest" in out["config"]["bit_exact_method"]
+    assert out["config"]["folded_reference"]["equal"] is True
+    assert out["config"]["folded_result"]["match_count"] == 4579 + 4590      # tests/golden/full_digests.json, slices 0 and 1
+    # a rank count that does not match --gpus is refused, not silently reported
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--platform", "cpu_omp", "--dist-backend", "gloo",
+                        "--size-mib", "8", "--steps", "1", "--warmup", "0"], cwd=root, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 2 and b"refusing" in p.stderr

@@ -8,7 +8,8 @@ def cp(a, b):
 for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json", "bench_c2.json"),
              ("bench_c5_dense.json", "bench_c5_dense.json"), ("bench_c5_hashed.json", "bench_c5_hashed.json"),
              ("bench_c3_naive.json", "bench_c3_naive_kernel.json"), ("bench_c2_naive.json", "bench_c2_naive_kernel.json"),
-             ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json")):
+             ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json"),
+             ("bench_c3_2ranks_one_gpu_gloo.json", "bench_c3_2ranks_one_gpu_gloo.json")):
     cp(a, b)
 for w in ("c3", "c2"):
     rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
@@ -16,8 +17,10 @@ for w in ("c3", "c2"):
     csv.writer(open(os.path.join("profiles", f"{tag}_{w}_rocprofv3_kernel_stats.csv"), "w")).writerows(keep)
     cp(os.path.join(f"traffic_{w}", "summary.json"), f"hbm_traffic_{w}.json")
     d = json.load(open(os.path.join("profiles", f"{tag}_hbm_traffic_{w}.json")))
-    f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if "pfac_scan_filter" in k and not k.rstrip(">( ").endswith("true")][0]
-    wr = [v for k, v in d["WRITE_SIZE"]["scan"].items() if "pfac_scan_filter" in k and not k.rstrip(">( ").endswith("true")][0]
-    filt = [r for r in keep[1:] if "pfac_scan_filter" in r[0] and "false>(" in r[0].replace(" ", "").replace("false,false>", "false>")][:1]
+    def full_result(k):   # pfac_scan_filter<TEX, HAS_SHORT, REDUCE, WALKS>: REDUCE = false
+        targs = [a.strip() for a in k.split("<", 1)[-1].split(">", 1)[0].split(",")]
+        return "pfac_scan_filter" in k and len(targs) >= 3 and targs[2] == "false"
+    f = [v for k, v in d["FETCH_SIZE"]["scan"].items() if full_result(k)][0]
+    wr = [v for k, v in d["WRITE_SIZE"]["scan"].items() if full_result(k)][0]
     print(w, "filter kernel rocprof avg ns:", [(r[0][28:64], r[1], r[3]) for r in keep[1:] if "pfac_scan_filter" in r[0]],
           "| traffic GB: 2xFETCH %.3f + WRITE %.3f = %.3f" % (2 * f * 1024 / 1e9, wr * 1024 / 1e9, (2 * f + wr) * 1024 / 1e9))

@@ -44,8 +44,9 @@ import time
 # OpenMP workers of the rank processes (numpy/torch pools, the oracle's window checks before the timed
 # region) must sleep, not spin, once their parallel region is over: spinning host threads delay the
 # launches of the timed steps.  The CPU-baseline worker replaces these (cpu_worker_env).
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-os.environ.setdefault("GOMP_SPINCOUNT", "0")
+if "cpu" not in sys.argv[1:]:          # not the --worker cpu process: it runs with the OpenMP runtime's own wait policy
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 import numpy as np
 
@@ -617,6 +618,23 @@ def rank_main(args):
                 all_ok = False
                 out["config"]["bit_exact"] = False
             del d_pos
+            # The same launch with the input and the result vector in other allocations: on this hardware the time
+            # of a launch depends on WHERE the two buffers were placed (two classes ~8 % apart that follow the pair
+            # of allocations, not offsets inside them: DESIGN.md 3.3).  The headline above is the first pair this
+            # process allocated; nothing is picked.
+            if not args.no_other_configs:
+                alt_in = torch.from_numpy(run.host_in).to(device)
+                alt_out = torch.full_like(run.d_out, -1)
+                spread = {}
+                for name_in, b_in in (("first", run.d_in), ("second", alt_in)):
+                    for name_out, b_out in (("first", run.d_out), ("second", alt_out)):
+                        saved = (run.d_in, run.d_out)
+                        run.d_in, run.d_out = b_in, b_out
+                        ms, _ = run.timed(10, 2, 8)
+                        run.d_in, run.d_out = saved
+                        spread[f"input {name_in} / result {name_out} allocation"] = round(float(np.mean(ms)), 4)
+                out["roofline"]["placement_spread_kernel_ms"] = spread
+                del alt_in, alt_out
             if not args.no_other_configs:
                 buffers = (run.d_in, run.d_out)
                 out["other_configs"] = other_configs(args, device, buffers)

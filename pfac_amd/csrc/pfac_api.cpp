@@ -283,7 +283,7 @@ PFAC_status_t PFAC_destroy(PFAC_handle_t handle)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     freeResources(handle);
-    /* the module stays mapped: other handles may share it (dlopen refcounts) */
+    /* drops this handle's reference; the module stays mapped while other handles hold theirs (dlopen refcounts) */
     if (handle->module) dlclose(handle->module);
     delete handle;
     return PFAC_STATUS_SUCCESS;

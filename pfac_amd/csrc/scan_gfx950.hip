@@ -14,29 +14,46 @@
  *   The path is HBM-bound integer work: 1 B read + 4 B written per input byte.
  *   The reference walks the automaton from every byte; on MI355X that makes the
  *   CU's address/L1 pipeline (one gathered table line per lane per step), not
- *   HBM, the limit.  pfac_scan_filter splits the walk:
+ *   HBM, the limit.  pfac_scan_filter is one persistent 1024-thread block per CU
+ *   with two kinds of waves:
  *
- *   1. STREAM.  Persistent 1024-thread blocks; a wave owns 2 KiB chunks, grid-
- *      strided.  16 B per lane per load (1 KiB contiguous per instruction), the
- *      next chunk is prefetched; the chunk's 8 KiB of results are written as
- *      non-temporal 16 B/lane zero stores that do not depend on the input.
- *   2. FILTER, level 1 (every position, LDS only): a 3-gram Bloom bitmap, plus
- *      an exact 2-gram bitmap when patterns shorter than 3 bytes exist.  A miss
- *      proves the result is 0.
- *   3. QUEUE.  Hits (with their first four bytes) are compacted into a per-wave
- *      LDS ring with ballot/mbcnt; 64 at a time they are re-tested against a
- *      4-gram bitmap (level 2).
- *   4. WALK.  Each lane runs 2 or 3 split-phase walkers over the survivors:
- *      the loads of a step are issued at the top of an iteration and consumed at
- *      the top of the next one, so a table round trip hides behind a whole chunk
- *      of filter work.  Dense mode: one 4-byte gather per byte.  Hashed mode: a
- *      device-only "chained" copy of the reference's hash table (tables.cpp),
- *      16 bytes per slot, one gather per edge byte + up to 7 single-successor
- *      bytes; slots are looked up in a per-wave LDS cache first and the input
- *      window stays in registers, because gathered loads are what costs time
- *      here.  "Texture" mode = buffer-resource loads.
- *   5. PATCH.  Non-zero results overwrite the zero; the in-order vmcnt counter
- *      of the wave orders the two stores.
+ *   WRITER waves (2 of 16) only zero-fill: they claim 8 KiB spans of the input in
+ *   order (one moving front over the whole grid), write the 32 KiB of zeros of the
+ *   span with non-temporal 16 B/lane stores, wait until those are in L2 and publish
+ *   the span in an LDS ring.  The result stream is 80 % of the traffic and does not
+ *   depend on the input; kept out of the scanning waves it neither stalls them nor
+ *   is stalled by them.
+ *
+ *   SCANNING waves take 2 KiB chunks of published spans from an LDS ticket counter:
+ *   1. FILTER, level 1 (every position, LDS only): lane l tests its 16 positions of
+ *      each tile against a 3-gram Bloom bitmap (aligned dword read + shift), plus an
+ *      exact 2-gram bitmap when patterns shorter than 3 bytes exist.  A miss proves
+ *      the result is 0.  The chunk is staged in LDS on the way; the next chunk is
+ *      prefetched into the same registers.
+ *   2. LIST.  The lanes' hits become one list of 16-bit codes (prefix sum of the hit
+ *      counts, one divergent loop).
+ *   3. FILTER, level 2, one hit per lane: 20 bytes cut out of the stage, tested
+ *      against a two-hash 4-gram bitmap (+ length-3 bitmap); survivors go to the
+ *      wave's walk queue {position, 20 input bytes}.
+ *   4. WALK.  Each lane runs 2 split-phase walkers over a device-only "chained"
+ *      copy of the reference's hash table (tables.cpp; used for BOTH perf modes),
+ *      16 bytes per slot: one gathered load per edge byte + up to 7 single-
+ *      successor bytes; the loads of a step are issued in one trip of the loop and
+ *      consumed in the next.  The input window stays in registers: the entry's 20
+ *      bytes end 99.9 % of the walks without an input load.  "Texture" mode = buffer-
+ *      resource loads.
+ *   5. PATCH.  A non-zero result overwrites its zero, which the writer wave had in
+ *      L2 before the chunk was handed out (same CU, same L2: ordered).
+ *   The loop has ONE copy of every stage: a trip starts with a walker round, stages
+ *   a new chunk only when the previous one is listed and tested, and tests list
+ *   entries only while the queue has room -- otherwise the trip just walks.
+ *
+ *   The compacted-output variant (REDUCE) has no zeros to write and no writer waves;
+ *   its scanning waves claim chunks from the device counters themselves.  So do the
+ *   scanning waves of a -DPFAC_WRITERS=0 build, which then issue the zero stores of
+ *   their own chunks: there the patch relies on the single in-order vmcnt counter of
+ *   gfx9-family hardware (zero store acknowledged before a later load of the same
+ *   wave returns).
  *
  *   The kernel never checks a bound: the launcher gives it whole chunks that end
  *   at least maxPatternLen + 32 bytes before the end of the input.  The rest --
@@ -45,6 +62,9 @@
  *   also the independent second implementation the tests cross-check against.
  *   No MFMA: nothing here is a contraction.
  */
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "scan_gfx950.hip is written for gfx950 (CDNA4): wave64, gfx9 waitcnt semantics, 160 KiB LDS"
+#endif
 #include <hip/hip_runtime.h>
 
 #include <cstring>

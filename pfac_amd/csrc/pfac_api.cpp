@@ -79,6 +79,8 @@ void freeResources(PFAC_context *c)
     devFree(c->d_workCounters);
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
+    devFree(c->d_hostReduce);
+    c->hostReduceBytes = 0;
     freeHostStage(c);
     devFree(c->d_final3);
     if (c->h_statsPinned) { (void)hipHostFree(c->h_statsPinned); c->h_statsPinned = nullptr; }
@@ -628,29 +630,26 @@ PFAC_status_t PFAC_matchFromHostReduce(PFAC_handle_t handle, char *h_inputString
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
     std::lock_guard<std::mutex> guard(handle->lock);
 
-    char *d_in = nullptr;
-    int *d_out = nullptr, *d_pos = nullptr;
-    const size_t inBytes = (size + 3) & ~size_t(3);
-    hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&d_in), inBytes);
-    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&d_out), size * sizeof(int));
-    hipError_t e3 = hipMalloc(reinterpret_cast<void **>(&d_pos), size * sizeof(int));
-    PFAC_status_t st = PFAC_STATUS_SUCCESS;
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        (void)hipGetLastError();
-        st = PFAC_STATUS_CUDA_ALLOC_FAILED;
+    /* one handle-owned block: input (padded to 16 bytes) | ids | positions */
+    const size_t inBytes = (size + 15) & ~size_t(15);
+    const size_t need = inBytes + 2 * size * sizeof(int);
+    if (handle->hostReduceBytes < need) {
+        devFree(handle->d_hostReduce);
+        handle->hostReduceBytes = 0;
+        if (hipMalloc(&handle->d_hostReduce, need) != hipSuccess) {
+            (void)hipGetLastError();
+            handle->d_hostReduce = nullptr;
+            return PFAC_STATUS_CUDA_ALLOC_FAILED;
+        }
+        handle->hostReduceBytes = need;
     }
-    if (st == PFAC_STATUS_SUCCESS && hipMemcpy(d_in, h_inputString, size, hipMemcpyHostToDevice) != hipSuccess)
-        st = PFAC_STATUS_INTERNAL_ERROR;
-    if (st == PFAC_STATUS_SUCCESS) {
-        correctTextureMode(handle);
-        PFAC_reduce_kernel_protoType fn =
-            handle->perfMode == PFAC_TIME_DRIVEN ? handle->reduce_kernel_ptr : handle->reduce_inplace_kernel_ptr;
-        st = fn(handle, reinterpret_cast<int *>(d_in), (int)size, d_out, d_pos, h_num_matched, h_matched_result, h_pos);
-    }
-    if (e1 == hipSuccess) (void)hipFree(d_in);
-    if (e2 == hipSuccess) (void)hipFree(d_out);
-    if (e3 == hipSuccess) (void)hipFree(d_pos);
-    return st;
+    char *d_in = static_cast<char *>(handle->d_hostReduce);
+    int *d_out = reinterpret_cast<int *>(d_in + inBytes), *d_pos = d_out + size;
+    if (hipMemcpy(d_in, h_inputString, size, hipMemcpyHostToDevice) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    correctTextureMode(handle);
+    PFAC_reduce_kernel_protoType fn =
+        handle->perfMode == PFAC_TIME_DRIVEN ? handle->reduce_kernel_ptr : handle->reduce_inplace_kernel_ptr;
+    return fn(handle, reinterpret_cast<int *>(d_in), (int)size, d_out, d_pos, h_num_matched, h_matched_result, h_pos);
 }
 
 /* ------------------------------------------------------------- extensions */

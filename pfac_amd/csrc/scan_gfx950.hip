@@ -380,7 +380,8 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one group take another pass */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
-constexpr int kReduceScanners = kWavesPerBlock - 4;   /* ... whose LDS comes from leaving four waves of the block without work */
+constexpr int kReduceScanners = kWavesPerBlock;       /* ... and no writer waves: every wave scans, with half the walk queue each (LDS) */
+constexpr uint32_t kReduceQueueCap = kQueueCap > 64 ? kQueueCap / 2 : kQueueCap;
 /* In-order hand-out of the input: -1 = the input is cut into kWorkParts contiguous parts, one
  * counter each; G >= 0 = one moving front: granules of 2^G pieces are dealt round-robin to the parts, so
  * all parts work inside one window of parts << G pieces that sweeps the input once. */
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     constexpr int kScanners = REDUCE ? kReduceScanners : kWavesPerBlock - kWriters;
     Control *ctl = reinterpret_cast<Control *>(sFirst + pfac::kCharSet * 4);
     uint32_t *sQueueAll = reinterpret_cast<uint32_t *>(ctl) + kControlWords;           /* 16-byte aligned */
-    constexpr uint32_t kQCap = kQueueCap;
+    constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
     uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * 4;            /* ... second part of the entries: input bytes 12..19 */
     uint32_t *sStageAll = sQueueBAll + kScanners * kQCap * 2;            /* per scanning wave: the chunk being filtered + the 32 bytes behind it */
     uint32_t *sListAll = sStageAll + kScanners * kStageWords;            /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
@@ -645,9 +646,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     };
     unsigned int *const counter = a.work + part * 32;
 
-    if (!kWriters && wave >= kScanners) {
-        /* no per-wave LDS for this wave (REDUCE) */
-    } else if (kWriters && wave >= kScanners) {
+    if (kWriters && wave >= kScanners) {
         /* ---- writer wave: claim, zero-fill, publish */
         const i32x4 zero = {0, 0, 0, 0};
         for (uint32_t k = (uint32_t)(wave - kScanners);; k += kWriters) {
@@ -817,8 +816,14 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         }
         /* ---- 5. one listed hit per lane: cut its 12 bytes out of the stage, filter level 2 (the walk survives
          * four transitions, or a pattern of length <= 3 can match here), survivors -> walk queue */
-        while (listAt != listEnd && qv - qh + 64 <= kQCap) {
-            const bool act = listAt + (uint32_t)lane < listEnd;
+        /* a pass takes up to 64 entries while the queue has room for 64; with the short queue of the compacted-output
+         * variant it takes what fits, as long as that is half a wave */
+        for (;;) {
+            const uint32_t left = listEnd - listAt, room = kQCap - (qv - qh);
+            const uint32_t want = left < 64u ? left : 64u, take = (REDUCE && room < want) ? room : want;
+            if (left == 0 || (REDUCE ? (take != want && take < 32u) : room < 64u)) break;
+            const uint32_t passEnd = listAt + take;
+            const bool act = listAt + (uint32_t)lane < passEnd;
             const uint32_t code = act ? (uint32_t)list[listAt + lane] : 0u;
             const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
             const uint32_t at = o >> 2, sh = o & 3u;
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                 queueB[qi] = entryB;
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
-            listAt = uni(listAt + 64 < listEnd ? listAt + 64 : listEnd);
+            listAt = uni(passEnd);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #if PFAC_ABLATE == 2
@@ -909,7 +914,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     bytes += pfac::kCharSet * sizeof(pfac::ChainSlot);
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
-    bytes += scanners * (kQueueCap * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
+    bytes += scanners * ((reduce ? kReduceQueueCap : kQueueCap) * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
     if (reduce) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }
@@ -1103,6 +1108,21 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
  * (PFAC_reduce_kernel.cu:417-457) because it has no prefilter: every thread owns a result.
  * Synchronous, like the reference (the count goes back to the host).
  */
+/* grow-only device scratch of the compacted-output path, owned by the handle (the caller holds its lock) */
+PFAC_status_t reduceScratch(PFAC_context *mc, size_t need, char **base)
+{
+    if (mc->reduceScratchBytes < need) {
+        if (mc->d_reduceScratch) (void)hipFree(mc->d_reduceScratch);
+        mc->d_reduceScratch = nullptr;
+        mc->reduceScratchBytes = 0;
+        const size_t grow = need + need / 2;
+        if (hipMalloc(&mc->d_reduceScratch, grow) != hipSuccess) { (void)hipGetLastError(); mc->d_reduceScratch = nullptr; return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+        mc->reduceScratchBytes = grow;
+    }
+    *base = static_cast<char *>(mc->d_reduceScratch);
+    return PFAC_STATUS_SUCCESS;
+}
+
 PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_size, int *d_match_result, int *d_pos,
                          int *h_num_matched, int *h_match_result, int *h_pos, bool hashed)
 {
@@ -1140,16 +1160,9 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             /* scratch = sorted keys | sorted values | rocPRIM workspace, each 256-byte aligned */
             const size_t arrayBytes = ((size_t)count * sizeof(int) + 255) / 256 * 256;
             const size_t need = 2 * arrayBytes + (tempBytes ? tempBytes : 4);
-            PFAC_context *mc = handle;
-            if (mc->reduceScratchBytes < need) {
-                if (mc->d_reduceScratch) (void)hipFree(mc->d_reduceScratch);
-                mc->d_reduceScratch = nullptr;
-                mc->reduceScratchBytes = 0;
-                const size_t grow = need + need / 2;
-                if (hipMalloc(&mc->d_reduceScratch, grow) != hipSuccess) { (void)hipGetLastError(); mc->d_reduceScratch = nullptr; return PFAC_STATUS_CUDA_ALLOC_FAILED; }
-                mc->reduceScratchBytes = grow;
-            }
-            char *base = static_cast<char *>(mc->d_reduceScratch);
+            char *base = nullptr;
+            st = reduceScratch(handle, need, &base);
+            if (st != PFAC_STATUS_SUCCESS) return st;
             unsigned int *keysOut = reinterpret_cast<unsigned int *>(base);
             int *valuesOut = reinterpret_cast<int *>(base + arrayBytes);
             void *temp = base + 2 * arrayBytes;
@@ -1163,8 +1176,10 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     if (mainLen < n) {
         /* the rest: full results into a scratch vector, compacted on the host */
         const size_t rest = n - mainLen;
-        int *d_full = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&d_full), rest * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+        char *scratch = nullptr;
+        st = reduceScratch(handle, rest * sizeof(int), &scratch);        /* the sort above is finished: same scratch */
+        if (st != PFAC_STATUS_SUCCESS) return st;
+        int *d_full = reinterpret_cast<int *>(scratch);
         ScanArgs part = a;
         part.in = a.in + mainLen;
         part.out = d_full;
@@ -1176,7 +1191,6 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         st = e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
         if (st == PFAC_STATUS_SUCCESS && hipMemcpy(full.data(), d_full, rest * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
             st = PFAC_STATUS_INTERNAL_ERROR;
-        (void)hipFree(d_full);
         if (st != PFAC_STATUS_SUCCESS) return st;
         for (size_t i = 0; i < rest; i++)
             if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)(mainLen + i)); }

@@ -635,6 +635,27 @@ def rank_main(args):
                         spread[f"input {name_in} / result {name_out} allocation"] = round(float(np.mean(ms)), 4)
                 out["roofline"]["placement_spread_kernel_ms"] = spread
                 del alt_in, alt_out
+            # PCIe-inclusive rate of PFAC_matchFromHost (never the metric): 256 MiB of the same stream
+            # from pageable and from pinned host buffers, 5 B per input byte cross the link
+            if not args.no_other_configs:
+                hn = min(run.n, 256 << 20)
+                host_path = {"bytes": hn}
+                for kind in ("pageable", "pinned"):
+                    h_in = torch.from_numpy(run.host_in[:hn].copy())
+                    h_out = torch.empty(hn, dtype=torch.int32)
+                    if kind == "pinned":
+                        h_in, h_out = h_in.pin_memory(), h_out.pin_memory()
+                    run.handle.matchFromHost(h_in.data_ptr(), hn, h_out.data_ptr())
+                    t0h = time.perf_counter()
+                    for _ in range(3):
+                        run.handle.matchFromHost(h_in.data_ptr(), hn, h_out.data_ptr())
+                    th = (time.perf_counter() - t0h) / 3
+                    keep = pos < hn - info.maxPatternLen
+                    hp = np.flatnonzero(h_out.numpy()[: hn - info.maxPatternLen])
+                    host_path[kind] = {"input_GBps": round(hn / th / 1e9, 2), "ms_per_call": round(th * 1e3, 3),
+                                       "same_result": bool(np.array_equal(hp, pos[keep]))}
+                    del h_in, h_out
+                out["host_path_pcie_inclusive"] = host_path
             if not args.no_other_configs:
                 buffers = (run.d_in, run.d_out)
                 out["other_configs"] = other_configs(args, device, buffers)

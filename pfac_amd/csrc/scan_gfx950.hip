@@ -721,6 +721,12 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
      * a new chunk is staged only when the previous one is completely listed and tested, and list entries are
      * tested only while the walk queue has room for a full pass -- otherwise the trip just walks. */
     uint32_t hits = 0;                          /* bit 16 * tt + i: position i of this lane in tile tt of the staged chunk */
+    /* the two constants of the level-1 test in VECTOR registers: an instruction with a scalar or literal operand
+     * issues at ~0.6 of the rate of the same instruction on vector registers (tools/valu_probe2.hip: v_lshrrev
+     * 1.10 vs 1.78 ns, v_mul_u32_u24 1.76 vs 2.03 ns per wave and SIMD), and these two run 2048 times per chunk */
+    uint32_t vShift3, vGram3Mul;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(lds.shift3));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     for (;;) {
         /* ---- 1. finish the transitions issued one trip ago, hand idle walker lanes new positions (first
@@ -770,8 +776,8 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
                                 const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
                                 /* bytes pos..pos+2 in the low 24 bits (the multiply ignores the rest) */
                                 const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
-                                const uint32_t product = (uint32_t)__umul24(x, pfac::kGram3Mul);   /* __umul24 returns int: shifts must be logical */
-                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> lds.shift3) & ~3u);
+                                const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
+                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
                                 if (HAS_SHORT) word[q] |= sShort[(x & 0xFFFFu) >> 5] >> 0;      /* same bit number: (x & 0xFFFF) & 31 == x & 31 */
                                 xs[q] = x;
                             }

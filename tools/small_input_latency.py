@@ -5,11 +5,13 @@ import numpy as np, torch, time, tempfile
 from pfac_amd import api, workloads as wl
 cfg = wl.make_config("c3"); f = tempfile.mktemp(); wl.write_pattern_file(f, cfg.patterns)
 h = api.PFAC.create(); h.setPerfMode(cfg.perf_mode); h.readPatternFromFile(f)
-for n in (4096, 65536, 1 << 20, 16 << 20):
-    d_in = torch.from_numpy(cfg.input_slice(n, 0).copy()).to("cuda:0"); d_out = torch.empty(n, dtype=torch.int32, device="cuda:0")
-    for _ in range(5): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(200): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
-    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print("n=%9d: %.1f us per call (host-side enqueue %.1f us), %.2f GB/s" % (n, (t2 - t0) / 200 * 1e6, (t1 - t0) / 200 * 1e6, n * 200 / (t2 - t0) / 1e9))
+for variant, vname in ((api.PFACX_KERNEL_AUTO, "auto"), (api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")):
+  h.setKernelVariant(variant)
+  for n in (4096, 65536, 1 << 20, 4 << 20, 16 << 20):
+      d_in = torch.from_numpy(cfg.input_slice(n, 0).copy()).to("cuda:0"); d_out = torch.empty(n, dtype=torch.int32, device="cuda:0")
+      for _ in range(5): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(200): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+      t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+      print(vname, "n=%9d: %.1f us per call (host-side enqueue %.1f us), %.2f GB/s" % (n, (t2 - t0) / 200 * 1e6, (t1 - t0) / 200 * 1e6, n * 200 / (t2 - t0) / 1e9))

@@ -20,8 +20,9 @@
  * Inputs the reference leaves undefined are rejected with a status instead:
  *   - a blank line followed by another pattern (reference: assert at
  *     PFAC_reorder_Table.cpp:291)            -> PFAC_STATUS_INVALID_PARAMETER
- *   - duplicate patterns (reference: comparator is not a strict weak order;
- *     hashed build fails, PFAC.cpp:543-551)  -> PFAC_STATUS_INTERNAL_ERROR
+ * Duplicate patterns (reference: the comparator returns true for equal patterns, which std::sort does
+ * not allow; two edges for one byte; hashed build fails, PFAC.cpp:543-551) are accepted as ONE pattern
+ * that is reported under the highest of its IDs.
  */
 #include <algorithm>
 #include <cstdio>
@@ -59,6 +60,13 @@ public:
     {
         for (int e = head_[state]; e >= 0; e = link_[e])
             if (ch_[e] == ch) return to_[e];
+        return kTrapState;
+    }
+    /* redirect the existing transition (state, ch); returns its previous target */
+    int retarget(int state, int ch, int to)
+    {
+        for (int e = head_[state]; e >= 0; e = link_[e])
+            if (ch_[e] == ch) { const int old = to_[e]; to_[e] = to; return old; }
         return kTrapState;
     }
     void append(int state, int ch, int to)
@@ -161,9 +169,15 @@ PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &f
         for (int j = 0; j < p.len; j++) {
             const int ch = buf[p.off + j];
             if (j == p.len - 1) {
-                /* an existing edge here can only come from an identical pattern */
-                if (trie.find(state, ch) != kTrapState) return PFAC_STATUS_INTERNAL_ERROR;
-                trie.append(state, ch, p.id);
+                /* An existing edge here can only come from an identical pattern (they are adjacent in the sorted
+                 * order, nothing hangs below the first one yet).  Rule sets do repeat lines: the copies are one
+                 * pattern, reported under the HIGHEST of their IDs; the other IDs are never reported.  (The
+                 * reference pushes a second edge for the same byte: its dense table then reports the ID the
+                 * unstable sort happened to place last and loses every longer pattern that extends the first
+                 * copy, and its hashed build fails, PFAC.cpp:376-381, 506-551.) */
+                const int prev = trie.find(state, ch);
+                if (prev == kTrapState) trie.append(state, ch, p.id);
+                else if (prev < p.id) trie.retarget(state, ch, p.id);
             } else {
                 int nx = trie.find(state, ch);
                 if (nx == kTrapState) {

@@ -385,3 +385,22 @@ def test_cpp_multi_gpu_example(workdir):
     out = subprocess.run([os.path.join(ROOT, "examples", "multi_gpu"), pf, inp, "3"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 differences" in out.stdout and "3 worker(s)" in out.stdout
+
+
+def test_duplicate_patterns_on_the_gpu(tmp_path):
+    """Duplicate lines in the pattern file (tests/test_host_api.py::test_duplicate_patterns...) through the kernels."""
+    from oracle import binding as ob
+    pats = [b"AB", b"CD", b"AB", b"ABX", b"CD", b"Q", b"CDE", b"Q", b"AB"]
+    unique = [b"\x01\x02", b"\x01\x03", b"\x01\x04", b"ABX", b"CD", b"\x01\x05", b"CDE", b"Q", b"AB"]
+    data = np.frombuffer(b"xxABXyCDEzQABABXCDCDQ" * 3000 + b"AB", dtype=np.uint8)
+    fa, fb = tmp_path / "dup.pat", tmp_path / "uniq.pat"
+    fa.write_bytes(b"".join(p + b"\n" for p in pats))
+    fb.write_bytes(b"".join(p + b"\n" for p in unique))
+    want = ob.Oracle(str(fb)).match(data)
+    for perf, tex, mode_name in MODES:
+        for variant in (api.PFACX_KERNEL_FILTER, api.PFACX_KERNEL_NAIVE):
+            h = make_handle(str(fa), perf, tex, variant)
+            try:
+                assert_same(device_match(h, data), want, f"duplicates / {mode_name} / variant {variant}")
+            finally:
+                h.destroy()

@@ -365,20 +365,16 @@ template <bool TEX> struct ChainLane {
 #ifndef PFAC_STATS
 #define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
 #endif
-/* Two loop shapes, tuned on MI355X (tools/ab.sh).  SHAPE_LIGHT = 2 KiB chunks, 3 walks per lane: best
- * when few positions are walked (the stream is what costs).  SHAPE_HEAVY = 4 KiB chunks, 2 walks per
- * lane: half as many walker rounds, prefetches and counter grabs per KiB; 4 % faster on the 30 k-pattern
- * set, 4 % slower on the 1 k-pattern set.  The launcher picks by the size of the level-1 key set. */
-/* Level-1 survivors are handled per GROUP of two tiles: the group is staged in LDS (+ the 16 bytes behind
- * it), every lane's hits go to a per-wave list of 16-bit codes, and 64 list entries at a time are cut out
- * of the stage, tested against level 2 and appended to the walk queue -- one entry per lane. */
+/* A scanning wave works on one CHUNK of two 1 KiB tiles at a time: the chunk is staged in LDS (+ the 32 bytes
+ * behind it), every lane's level-1 hits go to a per-wave list of 16-bit codes, and 64 list entries at a time
+ * are cut out of the stage, tested against level 2 and appended to the walk queue -- one entry per lane. */
 constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
 constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
 #ifndef PFAC_LIST_CAP
 #define PFAC_LIST_CAP 96
 #endif
-constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one group take another pass */
+constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
 constexpr int kReduceScanners = kWavesPerBlock;       /* ... and no writer waves: every wave scans, with half the walk queue each (LDS) */
 constexpr uint32_t kReduceQueueCap = kQueueCap > 64 ? kQueueCap / 2 : kQueueCap;

@@ -404,3 +404,46 @@ def test_duplicate_patterns_on_the_gpu(tmp_path):
                 assert_same(device_match(h, data), want, f"duplicates / {mode_name} / variant {variant}")
             finally:
                 h.destroy()
+
+
+def test_unified_address_space_buffers_outside_device_memory(workloads, oracle_results):
+    """PFAC/test/UVA.cpp: the context lives on GPU 0 while d_input_string / d_matched_result are allocated somewhere
+    else in the unified virtual address space (there: a peer GPU).  On a one-GPU box the "somewhere else" is pinned
+    host memory: PFAC_matchFromDevice on host-resident buffers must still give the oracle's result -- input streamed
+    over the link, zero-fill by the writer waves and patches by the scanning waves ordered on memory they do not own."""
+    w = workloads["c3"]
+    n = int(w.data.size)
+    h_in = torch.from_numpy(w.data.copy()).pin_memory()
+    for variant in (api.PFACX_KERNEL_FILTER, api.PFACX_KERNEL_NAIVE):
+        for perf, tex, mode_name in (MODES[1], MODES[3]):
+            h = make_handle(w.pattern_file, perf, tex, variant)
+            try:
+                h_out = torch.full((n,), -5, dtype=torch.int32).pin_memory()
+                h.matchFromDevice(h_in.data_ptr(), n, h_out.data_ptr())
+                torch.cuda.synchronize()
+                assert_same(h_out.numpy(), oracle_results["c3"], f"pinned host buffers / {mode_name} / variant {variant}")
+                # mixed: input in device memory, result in host memory, and the other way round
+                d_in = torch.from_numpy(w.data).to("cuda:0")
+                h_out.fill_(-5)
+                h.matchFromDevice(d_in.data_ptr(), n, h_out.data_ptr())
+                torch.cuda.synchronize()
+                assert_same(h_out.numpy(), oracle_results["c3"], f"device input, host result / {mode_name} / variant {variant}")
+                d_out = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                h.matchFromDevice(h_in.data_ptr(), n, d_out.data_ptr())
+                torch.cuda.synchronize()
+                assert_same(d_out.cpu().numpy(), oracle_results["c3"], f"host input, device result / {mode_name} / variant {variant}")
+            finally:
+                h.destroy()
+
+
+def test_cpp_reduce_example_prints_the_user_guide_answer():
+    """examples/reduce_example.cpp (re-authored PFAC/test/simple_example_reduce.cpp): user guide r1.2 p.29 --
+    h_num_matched = 5, positions {0,1,2,4,6}, patterns {1,3,4,4,2} -- from matchFromHostReduce in both perf modes
+    and from matchFromDeviceReduce."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-B"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "examples", "reduce_example")], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.splitlines() == ["number of matched = 5", "At position    0, match pattern 1", "At position    1, match pattern 3",
+                                       "At position    2, match pattern 4", "At position    4, match pattern 4",
+                                       "At position    6, match pattern 2"]

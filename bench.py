@@ -538,7 +538,11 @@ def rank_main(args):
 
     # ---- correctness gate (outside the timed region) ------------------------------------------
     run.step()
+    if gpu:
+        torch.cuda.synchronize()
+    log(f"[bench r{rank}] first launch done {time.perf_counter() - t_setup:.1f}s")
     ok, method, pos, ids = run.verify(args, rank, world)
+    log(f"[bench r{rank}] verified ({ok}) {time.perf_counter() - t_setup:.1f}s")
     count = int(pos.size)
     checksum = sharding.position_checksum(pos, ids, base=rank * run.n)
     if rank == 0 and args.sparse_file:
@@ -548,6 +552,7 @@ def rank_main(args):
     # Host-side checks leave the GPU idle for ~1 s and its clocks drop; the first ~10 launches after
     # that run up to 15 % slower.  SETTLE_STEPS untimed launches precede the W warmup steps.
     kernel_ms, elapsed = run.timed(args.steps, args.warmup, SETTLE_STEPS if gpu else 0, barrier)
+    log(f"[bench r{rank}] timed region done {time.perf_counter() - t_setup:.1f}s")
 
     # ---- gather per-rank facts (RCCL: 5 x int64 per rank) ----------------------------------------
     allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],

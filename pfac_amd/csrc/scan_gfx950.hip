@@ -371,6 +371,11 @@ template <bool TEX> struct ChainLane {
 constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
 constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
+#ifndef PFAC_REFILL_MIN
+#define PFAC_REFILL_MIN 32                     /* queue entries are handed out only when at least this many lanes of a walk set are idle:
+                                                * a refill costs the whole wave ~40 instructions however few lanes it fills
+                                                * (C5 1.94 -> 1.82 ms, C3 -1 %; profiles/r02_ab_refill.txt) */
+#endif
 #ifndef PFAC_LIST_CAP
 #define PFAC_LIST_CAP 96
 #endif
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             const uint64_t idle = __ballot(!alive[s]);
-            if (idle && qh != qv) {
+            if ((uint32_t)__popcll(idle) >= (uint32_t)PFAC_REFILL_MIN && qh != qv) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);

@@ -82,6 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--spread", action="store_true", help="measure the placement spread (4 buffer pairs) even with --no-other-configs")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: measure HBM traffic of the scan kernel with two rocprofv3 --pmc passes (N = 1, orchestrated runs)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target duration of ONE CPU-baseline run (3 runs are timed)")
@@ -627,7 +628,7 @@ def rank_main(args):
             # of a launch depends on WHERE the two buffers were placed (two classes ~8 % apart that follow the pair
             # of allocations, not offsets inside them: DESIGN.md 3.3).  The headline above is the first pair this
             # process allocated; nothing is picked.
-            if not args.no_other_configs:
+            if not args.no_other_configs or args.spread:
                 alt_in = torch.from_numpy(run.host_in).to(device)
                 alt_out = torch.full_like(run.d_out, -1)
                 spread = {}

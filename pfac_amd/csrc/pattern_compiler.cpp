@@ -302,6 +302,13 @@ void buildFilter(const Automaton &fa, Filter &f)
             }
         }
     }
+    /* Level 1 tests ONE bitmap per position: a pattern of one or two bytes matches whatever follows it, so all
+     * 256 (or 65536) 3-grams that begin with it pass.  (The 2-byte bitmap is still tested at level 2, which
+     * sorts out the positions this lets through.) */
+    if (f.hasShort)
+        for (uint32_t key2 = 0; key2 < 65536; key2++)
+            if ((f.shortBits[key2 >> 5] >> (key2 & 31)) & 1u)
+                for (uint32_t c2 = 0; c2 < 256; c2++) setBit(f.gram3, gram3Hash(key2 | (c2 << 16), f.log2Bits));
     f.bitsSet = f.bitsSet4 = 0;
     for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
     for (uint32_t w : f.gram4) f.bitsSet4 += (size_t)__builtin_popcount(w);

@@ -719,7 +719,7 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 namespace {
 
 constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
-constexpr uint32_t kCompiledVersion = 1;
+constexpr uint32_t kCompiledVersion = 2;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap */
 /* what the stored tables depend on besides the patterns: hash constants and slot layout */
 constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kGram4Mul * 3u) ^ (pfac::kGram4Mul2 * 5u) ^ (pfac::kFinal3Mul * 7u) ^
                                         ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;

@@ -67,6 +67,7 @@
 #endif
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -124,6 +125,7 @@ struct ScanArgs {
     int *reducePos;
     unsigned int *reduceCount;
     unsigned int reduceBase;                           /* position of a.in[0] inside the caller's stream */
+    unsigned int deepWriters;                          /* writer waves keep two spans of zero stores in flight (launchFilter) */
 };
 
 /* ---------------------------------------------------------------- lookups */
@@ -274,10 +276,14 @@ template <bool TEX> struct ChainLane {
      * It starts as the queue entry's 20 bytes and is only re-fetched (16 bytes into W1..W4) when a MATCHING
      * slot needs bytes beyond it: the step that ends a walk -- a slot for some other byte -- needs none. */
     u32x4 t = {0, 0, 0, 0};
-    uint32_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, W4 = 0;
+    uint32_t W0 = 0;
+    u32x4 W = {0, 0, 0, 0};                    /* W1..W4 as one register quad: the destination of the window load itself */
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
     uint32_t refetches = 0;                    /* a walk that outran its window twice fetches one every step from then on */
+#ifdef PFAC_DUMMY_GATHER                       /* timing experiment: a second gathered load per step, PFAC_DUMMY_GATHER slots away */
+    uint32_t dummy = 0;
+#endif
 
     /* input bytes q .. q+7 out of the window (q - (wend - 20) in 0..19; bytes beyond the window are garbage:
      * callers only use bytes below wend).  A three-level binary shifter on the dword number: selects, no
@@ -286,6 +292,7 @@ template <bool TEX> struct ChainLane {
     {
         const uint32_t o = q - (wend - kEntryBytes);
         const bool b1 = (o & 4u) != 0, b2 = (o & 8u) != 0, b4 = (o & 16u) != 0;
+        const uint32_t W1 = W.x, W2 = W.y, W3 = W.z, W4 = W.w;
         const uint32_t T0 = b1 ? W1 : W0, T1 = b1 ? W2 : W1, T2 = b1 ? W3 : W2, T3 = b1 ? W4 : W3, T4 = b1 ? 0u : W4;
         const uint32_t U0 = b2 ? T2 : T0, U1 = b2 ? T3 : T1, U2 = b2 ? T4 : T2;
         const uint32_t lo = b4 ? W4 : U0;
@@ -321,7 +328,7 @@ template <bool TEX> struct ChainLane {
     __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1)
     {
         pos = ea.x; match = 0; depth = 0; b0 = ea.y & 0xFF;
-        W0 = ea.y; W1 = ea.z; W2 = ea.w; W3 = eb0; W4 = eb1;
+        W0 = ea.y; W.x = ea.z; W.y = ea.w; W.z = eb0; W.w = eb1;
         wend = pos + kEntryBytes;
         needWin = false; needSlot = true; refetches = 0;
         return advance(c.sRoot[b0], __builtin_amdgcn_alignbyte(ea.z, ea.y, 1), __builtin_amdgcn_alignbyte(ea.w, ea.z, 1));
@@ -332,15 +339,20 @@ template <bool TEX> struct ChainLane {
             const uint32_t idx = row + chainHashSlot(ks, b0);
             if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
             else t = c.slots[idx];
+#ifdef PFAC_DUMMY_GATHER
+            dummy = __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)((idx ^ (uint32_t)PFAC_DUMMY_GATHER) * 16u), 0, 0);
+#endif
         }
         if (needWin) {                                         /* rare: the walk is more than 20 bytes deep */
-            const u32x4 w = loadWindow16(c.in32, pos + depth + 1);     /* pos + depth = position of the edge byte b0 */
-            W1 = w.x; W2 = w.y; W3 = w.z; W4 = w.w;
+            W = loadWindow16(c.in32, pos + depth + 1);                 /* pos + depth = position of the edge byte b0 */
             wend = ((pos + depth + 1) & ~3u) + 16u;
         }
     }
     __device__ __forceinline__ bool consume(const Ctx &)
     {
+#ifdef PFAC_DUMMY_GATHER
+        refetches += dummy == 0x9E3779B9u ? 1u : 0u;
+#endif
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
         const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
@@ -376,6 +388,12 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
                                                 * a refill costs the whole wave ~40 instructions however few lanes it fills
                                                 * (C5 1.94 -> 1.82 ms, C3 -1 %; profiles/r02_ab_refill.txt) */
 #endif
+#ifndef PFAC_ROUND_MIN
+#define PFAC_ROUND_MIN 0
+#endif
+#ifndef PFAC_TIMING
+#define PFAC_TIMING 0
+#endif
 #ifndef PFAC_LIST_CAP
 #define PFAC_LIST_CAP 96
 #endif
@@ -403,6 +421,9 @@ constexpr uint32_t kReduceQueueCap = kQueueCap > 64 ? kQueueCap / 2 : kQueueCap;
 #endif
 #ifndef PFAC_SPAN_LOG2
 #define PFAC_SPAN_LOG2 2
+#endif
+#ifndef PFAC_WRITER_PIPE
+#define PFAC_WRITER_PIPE 2                     /* a writer wave keeps two spans of stores in flight: 0 never, 1 always, 2 = ScanArgs::deepWriters */
 #endif
 constexpr int kSpanLog2 = PFAC_SPAN_LOG2;
 constexpr uint32_t kSpanChunks = 1u << kSpanLog2;      /* chunks per span (4 chunks = 8 KiB of input, 32 KiB of results) */
@@ -436,9 +457,15 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
     return v;
 }
 
+/* vector registers the compiler may use in the filter kernel, HALVED (on gfx90a and later the attribute counts a
+ * unified VGPR + AGPR budget of twice its value; the kernel uses no AGPRs): v0..v117.  v119..v127 hold the chunk
+ * in flight (prefetchChunk). */
+constexpr int kCompilerVgprs = 59;
+
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
 template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets>
-__global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_scan_filter(ScanArgs a)
+__global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(kCompilerVgprs)))
+void pfac_scan_filter(ScanArgs a)
 {
     constexpr int kTilesPerIter = kGroupTiles;
     constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
@@ -474,7 +501,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
-        if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == 3) ? kEnd : 0u;      /* endSpan = none yet */
+        if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
 
@@ -488,7 +515,6 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     u32x2 *queueB = reinterpret_cast<u32x2 *>(sQueueBAll) + wave * kQCap;
     uint32_t *stage = sStageAll + wave * kStageWords;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
-    const u32x4 *in128 = reinterpret_cast<const u32x4 *>(a.in);
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort,
                   35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
@@ -648,13 +674,36 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     unsigned int *const counter = a.work + part * 32;
 
     if (kWriters && wave >= kScanners) {
-        /* ---- writer wave: claim, zero-fill, publish */
+        /* ---- writer wave: claim, zero-fill, publish.  With a.deepWriters a writer keeps TWO spans in flight: the
+         * stores of span k are only waited for (the in-order counter: all but the youngest span's) after span k + 1
+         * has been claimed and issued, so the ~1.5 us of the claim's device atomic and the acknowledgement of the
+         * stores overlap.  That pays when the scanning waves are the slower side and the writers only have to keep
+         * out of their way (Snort-style patterns over HTTP text: -2..4 %); when the launch is bound by the result
+         * stream itself (random patterns over random bytes) every block already pushes as hard as the memory system
+         * takes and the same change costs 5 %.  The launcher decides from the walk density of the handle's
+         * previous launch (launchFilter). */
         const i32x4 zero = {0, 0, 0, 0};
+        constexpr uint32_t kSpanStores = kSpanChunks * (kChunkBytes * 4 / 1024);       /* 1 KiB per instruction */
+        static_assert(kSpanStores <= 32, "two spans of stores fit the 6-bit wait counter");
+        bool havePrev = false;
+        uint32_t prevK = 0, prevSpan = 0;
+        auto publishPrev = [&]() {                           /* its zeros are in L2 */
+            while (ldsLoad(&ctl->pubCount) != prevK) __builtin_amdgcn_s_sleep(2);        /* publish in order */
+            ldsStore(&ctl->ring[prevK & (kRing - 1)], prevSpan);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ldsStore(&ctl->pubCount, prevK + 1);
+            havePrev = false;
+        };
         for (uint32_t k = (uint32_t)(wave - kScanners);; k += kWriters) {
             for (;;) {                                      /* my turn to claim, and a ring slot nobody still reads */
                 const uint32_t turn = ldsLoad(&ctl->claimTurn), pops = ldsLoad(&ctl->popCount);
                 if (turn == k && k < (pops >> kSpanLog2) + kRunAhead) break;
-                __builtin_amdgcn_s_sleep(8);
+                if (havePrev) {                             /* nothing to issue: finish the span in flight */
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    publishPrev();
+                } else {
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
             unsigned int v = 0;
             if (lane == 0) v = atomicAdd(counter, 1u);
@@ -667,13 +716,29 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             const uint32_t c0 = span << kSpanLog2;
             const uint32_t cN = c0 + kSpanChunks < numChunks ? c0 + kSpanChunks : numChunks;
             i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)c0 * kChunkBytes);
-            const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);                 /* 1 KiB per instruction */
+            const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);
             for (uint32_t i = 0; i < stores; i++) __builtin_nontemporal_store(zero, &o4[i * 64 + lane]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              /* the zeros are in L2 */
-            while (ldsLoad(&ctl->pubCount) != k) __builtin_amdgcn_s_sleep(2);             /* publish in order */
-            ldsStore(&ctl->ring[k & (kRing - 1)], span);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            ldsStore(&ctl->pubCount, k + 1);
+            if (havePrev) {                                 /* the previous span's zeros are in L2 */
+                if (stores == kSpanStores) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSpanStores) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publishPrev();
+            }
+            havePrev = true; prevK = k; prevSpan = span;
+#if PFAC_WRITER_PIPE == 0
+            const bool deep = false;
+#elif PFAC_WRITER_PIPE == 1
+            const bool deep = true;
+#else
+            const bool deep = a.deepWriters != 0;
+#endif
+            if (!deep) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publishPrev();
+            }
+        }
+        if (havePrev) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publishPrev();
         }
     } else {
     /* ---- scanning wave */
@@ -700,12 +765,34 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
         const uint32_t c = (uni(ldsLoad(&ctl->ring[slot & (kRing - 1)])) << kSpanLog2) | (ticket & (kSpanChunks - 1u));
         return c < numChunks ? c : kEnd;                   /* the last span of the input may be partial */
     };
-    /* the chunk's tiles, 1 KiB per instruction, and the 16 bytes behind it */
-    auto loadChunk = [&](uint32_t c, u32x4 (&d)[kTilesPerIter], u32x4 &halo) {
-        const uint32_t q = c * (kChunkBytes / 16);
-#pragma unroll
-        for (int t = 0; t < kTilesPerIter; t++) d[t] = in128[q + t * 64 + lane];
-        halo = in128[(c + 1) * (kChunkBytes / 16) + (lane & 1)];       /* lane 0: bytes 0..15 behind the chunk, lane 1: 16..31 */
+    /* The chunk in flight lives in nine vector registers that the COMPILER DOES NOT KNOW ABOUT (v119..v127: the
+     * kernel is compiled for fewer registers, kCompilerVgprs): two tiles, 1 KiB per load instruction, and the 32
+     * bytes behind the chunk, one dword in each of the lanes 0..7.  Left to the register allocator they were
+     * copied between two register sets on every trip of the loop that did not stage a chunk, and a copy of the
+     * destination of a load in flight waits for it -- and, the wait counter being in-order, for the walkers'
+     * loads just issued: a third of a scanning wave's time (PFAC_TIMING build).  Issued and read through inline
+     * assembly, they are waited for in one place: the top of the scan loop. */
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"        /* "clobber list contains reserved registers": that is the point */
+    auto prefetchChunk = [&](uint32_t c) {
+        const uint32_t off = c * (uint32_t)kChunkBytes + (uint32_t)lane * 16u;
+        const uint32_t offHalo = (c + 1u) * (uint32_t)kChunkBytes + (uint32_t)(lane & 7) * 4u;
+        static_assert(kTilesPerIter == 2, "two tile registers are reserved");
+        asm volatile("global_load_dwordx4 v[120:123], %0, %2\n\t"
+                     "global_load_dwordx4 v[124:127], %0, %2 offset:1024\n\t"
+                     "global_load_dword v119, %1, %2"
+                     :: "v"(off), "v"(offHalo), "s"(a.in)
+                     : "memory", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    };
+#pragma clang diagnostic pop
+    /* the prefetched chunk -> ordinary registers, a tile at a time (the copies only live while level 1 runs) */
+    auto takeTile0 = [&](u32x4 &d0, uint32_t &d1x) {
+        asm volatile("v_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v122\n\tv_mov_b32 %3, v123\n\tv_mov_b32 %4, v124"
+                     : "=v"(d0.x), "=v"(d0.y), "=v"(d0.z), "=v"(d0.w), "=v"(d1x) :: "memory");
+    };
+    auto takeTile1 = [&](u32x4 &d1, uint32_t &halo) {
+        asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127\n\tv_mov_b32 %4, v119"
+                     : "=v"(d1.x), "=v"(d1.y), "=v"(d1.z), "=v"(d1.w), "=v"(halo) :: "memory");
     };
 
 #if PFAC_ABLATE == 1
@@ -713,9 +800,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
 #endif
     uint32_t chunk = resolve(uni(pop()));
     uint32_t nextTicket = uni(pop());
-    u32x4 d[kTilesPerIter];
-    u32x4 halo = {0, 0, 0, 0};
-    if (chunk != kEnd) loadChunk(chunk, d, halo);
+    if (chunk != kEnd) prefetchChunk(chunk);
 
     /* The staged chunk: level-1 hits not yet listed (per lane), listed codes not yet tested [listAt, listEnd),
      * and its position in the input.  One loop, one copy of every stage: each trip starts with a walker round;
@@ -729,99 +814,127 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(lds.shift3));
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
-    for (;;) {
-        /* ---- 1. finish the transitions issued one trip ago, hand idle walker lanes new positions (first
-         *         transition from LDS), start the next transition of every live walk */
-        walkConsume();
-        walkRefill();
-        walkIssue();
-
-        if (listAt == listEnd) {
-            if (__ballot(hits != 0) == 0) {
-                if (chunk == kEnd) {
-                    if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
-                } else {
-                    /* ---- 2. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
-                     *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
-                     *         this chunk) */
-                    const unsigned int afterNext = pop();
-                    if (!REDUCE && !kWriters) {
-                        i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
-                        const i32x4 zero = {0, 0, 0, 0};
-#pragma unroll
-                        for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
-                    }
-                    /* ---- 3. filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position.
-                     * The chunk also goes to LDS (lane l -> bytes 16l.. of its tile, lane 0 also the 16 bytes behind
-                     * it): an entry of the walk queue needs 12 bytes from an arbitrary offset. */
-#pragma unroll
-                    for (int tt = 0; tt < kTilesPerIter; tt++) {
-                        reinterpret_cast<u32x4 *>(stage)[tt * 64 + lane] = d[tt];
-                        const uint32_t dw[4] = {d[tt].x, d[tt].y, d[tt].z, d[tt].w};
-                        uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
-                        const u32x4 &follow = (tt + 1 < kTilesPerIter) ? d[(tt + 1) % kTilesPerIter] : halo;   /* lane 0's copy is the right one */
-                        const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow.x);
-                        if (lane == 63) nxtLane = wrap;
-                        /* kBatch positions at a time (that many LDS reads in flight); the scheduling barrier keeps the
-                         * batches apart, or their temporaries pile up past the register budget.  Per position: the gram
-                         * (a shift or v_alignbyte), v_mul_u32_u24, shift + AND = dword address, ds_read_b32, a shift by the
-                         * gram (mod 32: the bit), v_alignbit to push the bit into the mask.  Plain VOP2 instructions
-                         * wherever possible: they issue twice as fast as VOP3 ones here (tools/valu_probe.hip). */
-                        constexpr int kBatch = HAS_SHORT ? 4 : 8;
-#pragma unroll
-                        for (int b0 = 0; b0 < 16; b0 += kBatch) {
-                            uint32_t word[kBatch], xs[kBatch];
-#pragma unroll
-                            for (int q = 0; q < kBatch; q++) {
-                                const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
-                                const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
-                                /* bytes pos..pos+2 in the low 24 bits (the multiply ignores the rest) */
-                                const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
-                                const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
-                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
-                                if (HAS_SHORT) word[q] |= sShort[(x & 0xFFFFu) >> 5] >> 0;      /* same bit number: (x & 0xFFFF) & 31 == x & 31 */
-                                xs[q] = x;
-                            }
-#pragma unroll
-                            for (int q = 0; q < kBatch; q++)
-                                hits = __builtin_amdgcn_alignbit(word[q] >> (xs[q] & 31u), hits, 1);   /* bit 0 of the shifted word enters at the top */
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    if (lane < 2) reinterpret_cast<u32x4 *>(stage)[kTilesPerIter * 64 + lane] = halo;
-                    stagedBase = chunk * kChunkBytes;
-                    /* the registers are free: prefetch the next chunk into them (a whole chunk ahead of its use; the
-                     * loads stay younger than this trip's walker loads, so consuming those does not wait for HBM).
-                     * Past the end the previous address is loaded again, not nothing: every path issues the same
-                     * vector-memory instructions, which keeps the wait counts exact. */
-                    const uint32_t next = resolve(nextTicket);
-                    loadChunk(next != kEnd ? next : chunk, d, halo);
-                    chunk = next;
-                    nextTicket = uni(afterNext);
-#if PFAC_ABLATE == 1
-                    ablateSink |= hits;
-                    hits = 0;
+#if PFAC_TIMING     /* profile build: shader-clock cycles this wave spends in each stage (s_memtime at the stage boundaries) */
+    uint32_t tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tLast = __builtin_readcyclecounter();
+#define PFAC_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const uint64_t tNow = __builtin_readcyclecounter(); tm[k] += (uint32_t)(tNow - tLast); tLast = tNow; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PFAC_TICK(k) do { } while (0)
 #endif
+    /* One loop, one copy of every stage.  A trip: (1) finish the walkers' transitions issued one trip ago; (2) if
+     * the staged chunk is completely listed and tested: level 1 over the next chunk (prefetched one chunk ago) and
+     * the prefetch of the one after it; (3) refill idle walker lanes and issue the next transitions; (4) the next
+     * <= kListCap hits -> list; (5) passes while the walk queue has room.  The order matters: the wait counter for
+     * vector memory is in-order, so whoever waits for the walkers' loads in (1) also waits for everything issued
+     * before them.  The prefetch is issued right after (1) and before the walkers' loads of the same trip: it
+     * has the rest of the trip to land, and a later trip's (1) covers it. */
+    for (;;) {
+        PFAC_TICK(7);
+        /* every load of the previous trip: the walkers' slots, which (1) is about to use, and -- older -- the
+         * prefetched chunk.  Written out (the compiler's own waits sit inside `if (alive)` blocks and it would
+         * add more further down for loads it cannot prove finished), and it is all this loop ever waits for:
+         * s_waitcnt vmcnt(0), expcnt and lgkmcnt untouched */
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        PFAC_TICK(8);
+        walkConsume();
+        PFAC_TICK(0);
+        if (listAt == listEnd && __ballot(hits != 0) == 0) {
+            if (chunk == kEnd) {
+                if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
+            } else {
+                /* ---- 2. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
+                 *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
+                 *         this chunk) */
+                const unsigned int afterNext = pop();
+                if (!REDUCE && !kWriters) {
+                    i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
+                    const i32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
                 }
+                /* filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position.
+                 * The chunk also goes to LDS (lane l -> bytes 16l.. of its tile, lanes 0..7 also the 32 bytes behind
+                 * it): an entry of the walk queue needs 20 bytes from an arbitrary offset. */
+#pragma unroll
+                for (int tt = 0; tt < kTilesPerIter; tt++) {
+                    u32x4 dt;
+                    uint32_t follow;                   /* lane 0: the dword behind this tile */
+                    if (tt == 0) takeTile0(dt, follow);
+                    else takeTile1(dt, follow);
+                    reinterpret_cast<u32x4 *>(stage)[tt * 64 + lane] = dt;
+                    if (tt == kTilesPerIter - 1 && lane < 8) stage[kTilesPerIter * 256 + lane] = follow;
+                    const uint32_t dw[4] = {dt.x, dt.y, dt.z, dt.w};
+                    uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
+                    const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow);
+                    if (lane == 63) nxtLane = wrap;
+                    /* kBatch positions at a time (that many LDS reads in flight); the scheduling barrier keeps the
+                     * batches apart, or their temporaries pile up past the register budget.  Per position: the gram
+                     * (a shift or v_alignbyte), v_mul_u32_u24, shift + AND = dword address, ds_read_b32, a shift by the
+                     * gram (mod 32: the bit), v_alignbit to push the bit into the mask.  Plain VOP2 instructions
+                     * wherever possible: they issue twice as fast as VOP3 ones here (tools/valu_probe.hip). */
+                    constexpr int kBatch = 8;
+#pragma unroll
+                    for (int b0 = 0; b0 < 16; b0 += kBatch) {
+                        uint32_t word[kBatch], xs[kBatch];
+#pragma unroll
+                        for (int q = 0; q < kBatch; q++) {
+                            const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
+                            const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+                            /* bytes pos..pos+2 in the low 24 bits (the multiply ignores the rest) */
+                            const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
+                            const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
+                            word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
+                            xs[q] = x;
+                        }
+#pragma unroll
+                        for (int q = 0; q < kBatch; q++)
+                            hits = __builtin_amdgcn_alignbit(word[q] >> (xs[q] & 31u), hits, 1);   /* bit 0 of the shifted word enters at the top */
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                stagedBase = chunk * kChunkBytes;
+                PFAC_TICK(3);
+                /* the chunk registers are free again: prefetch the next chunk.  Past the end the last chunk is
+                 * loaded again, not nothing (it is never taken) */
+                const uint32_t next = resolve(nextTicket);
+                PFAC_TICK(6);
+                prefetchChunk(next != kEnd ? next : chunk);
+                chunk = next;
+                nextTicket = uni(afterNext);
+#if PFAC_ABLATE == 1
+                ablateSink |= hits;
+                hits = 0;
+#endif
             }
-            /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
-             *         counts; hits beyond the list's capacity stay in `hits` for the next round */
+        }
+        /* ---- 3. hand idle walker lanes new positions (first transition from LDS), start the next transition of
+         *         every live walk */
+        walkRefill();
+        PFAC_TICK(1);
+        walkIssue();
+        PFAC_TICK(2);
+        /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
+         *         counts; hits beyond the list's capacity stay in `hits` for the next trip */
+        if (listAt == listEnd && __ballot(hits != 0) != 0) {
             const uint32_t cnt = (uint32_t)__builtin_popcount(hits);
             const uint32_t incl = waveInclusiveScan(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t idx = incl - cnt;
+            PFAC_TICK(9);
             while (hits != 0 && idx < kListCap) {       /* divergent: as many rounds as the busiest lane has hits */
                 list[idx] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)__builtin_ctz(hits));
                 idx++;
                 hits &= hits - 1;
             }
+            PFAC_TICK(10);
             listAt = 0;
             listEnd = total < kListCap ? total : kListCap;
             stHits += listEnd;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            PFAC_TICK(4);
         }
-        /* ---- 5. one listed hit per lane: cut its 12 bytes out of the stage, filter level 2 (the walk survives
+        /* ---- 5. one listed hit per lane: cut its 20 bytes out of the stage, filter level 2 (the walk survives
          * four transitions, or a pattern of length <= 3 can match here), survivors -> walk queue */
         /* a pass takes up to 64 entries while the queue has room for 64; with the short queue of the compacted-output
          * variant it takes what fits, as long as that is half a wave */
@@ -855,6 +968,7 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
             listAt = uni(passEnd);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        PFAC_TICK(5);
 #if PFAC_ABLATE == 2
         qh = qv;                                        /* timing experiment: drop the verified entries unwalked */
 #endif
@@ -863,6 +977,10 @@ __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) void pfac_s
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
     if (REDUCE) flushStaged();
+#if PFAC_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 12; k++) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 8 + k, (unsigned long long)tm[k]);
+#endif
     }   /* scanning wave */
 
     /* counters of this launch (PFACX_getScanStats): per-wave scalars -> LDS -> one atomic per counter and block */
@@ -961,11 +1079,33 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     if (blocks > resident) blocks = resident;
     hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
+    /* The counters of the previous launch on this handle (they follow every launch into pinned host memory, nobody
+     * waits for them): walks started per position tell which side of the kernel is the slower one, and with that how
+     * the writer waves should behave.  No history: assume pattern-dense input. */
+    ScanArgs b = a;
+    b.deepWriters = 1;
+    if (c->h_statsPinned) {
+        const volatile unsigned long long *st = c->h_statsPinned;
+        const unsigned long long walks = st[2], positions = st[4];
+        if (positions) b.deepWriters = walks * pfac::kDeepWritersPerWalk >= positions;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, b);
     e = hipGetLastError();
-    /* PFACX_KERNEL_AUTO looks at the level-1 hit density of recent launches: their counters follow the kernel
-     * into pinned host memory, nobody waits for them */
-    if (e == hipSuccess && c->kernelVariant == PFACX_KERNEL_AUTO && c->h_statsPinned)
+#if PFAC_TIMING
+    {
+        unsigned long long t[12];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(t, c->d_workCounters + pfac::kStatsWord + 16, sizeof(t), hipMemcpyDeviceToHost);
+        double sum = 0;
+        for (int k = 0; k < 12; k++) sum += (double)t[k];
+        static const char *names[12] = {"consume", "refill", "issue", "level1+stage", "list-fences", "passes", "resolve(wait for writers)+prefetch issue", "loop/pop/other",
+                                        "wait for loads (top of trip)", "popcount+scan", "emit-loop", "-"};
+        fprintf(stderr, "PFAC_TIMING blocks %zu scanners %zu:", blocks, scanners);
+        for (int k = 0; k < 11; k++) fprintf(stderr, "  %s %.1f%% (%.0f cyc/wave)", names[k], 100.0 * t[k] / sum, (double)t[k] / (blocks * scanners));
+        fprintf(stderr, "\n");
+    }
+#endif
+    if (e == hipSuccess && c->h_statsPinned)
         e = hipMemcpyAsync(c->h_statsPinned, c->d_workCounters + pfac::kStatsWord, pfac::kStatsCount * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, 0);
     return e;

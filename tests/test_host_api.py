@@ -204,7 +204,7 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     h4b = ((x * 0x85EBCA77) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
     hf = (((x & 0xFFFFFF) * 0x85EBCB) & 0xFFFFFFFF) >> (32 - info.filterLog2BitsFinal3)
     short = bit(sb, x & 0xFFFF)
-    level1 = bit(g3, h3) | short
+    level1 = bit(g3, h3)                               # patterns of 1-2 bytes are folded into the 3-gram bitmap
     level2 = (bit(g4, h4) & bit(g4, h4b)) | bit(f3, hf) | short
     hit = oracle_results[name] != 0
     assert np.all(level1[hit] == 1) and np.all(level2[hit] == 1)

@@ -13,10 +13,11 @@ for r in $(seq $REPEAT); do
     for w in $WL; do
       extra=""; ww=$w
       case $w in c5h) ww=c5; extra="--perf-mode hash";; esac
-      python bench.py --steps ${STEPS:-20} --warmup 3 --workload $ww $extra --no-cpu-baseline --no-other-configs --pmc off $EXTRA 2>/dev/null | python -c "
+      python bench.py --steps ${STEPS:-20} --warmup 3 --workload $ww $extra --no-cpu-baseline --no-other-configs --spread --pmc off $EXTRA 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$name', '$w', r['kernel_ms_avg'], d['config']['bit_exact'], (d.get('reduce_api') or {}).get('ms_per_call'))" >> /tmp/ab_raw.txt
+sp=list((r.get('placement_spread_kernel_ms') or {'x':r['kernel_ms_avg']}).values())
+print('$name', '$w', r['kernel_ms_avg'], d['config']['bit_exact'], (d.get('reduce_api') or {}).get('ms_per_call'), min(sp), max(sp))" >> /tmp/ab_raw.txt
     done
   done
 done
@@ -24,11 +25,12 @@ python - <<'PY'
 import collections, statistics
 rows = collections.OrderedDict()
 for l in open('/tmp/ab_raw.txt'):
-    n, w, ms, ok, red = l.split()
-    rows.setdefault((n, w), []).append((float(ms), ok, None if red == 'None' else float(red)))
+    n, w, ms, ok, red, lo, hi = l.split()
+    rows.setdefault((n, w), []).append((float(ms), ok, None if red == 'None' else float(red), float(lo), float(hi)))
 for (n, w), v in rows.items():
     ms = [x[0] for x in v]; red = [x[2] for x in v if x[2] is not None]
-    print('%-14s %-4s kernel ms min %.4f median %.4f max %.4f  (n=%d) exact %s  reduce ms min %s' % (
-        n, w, min(ms), statistics.median(ms), max(ms), len(ms), all(x[1] == 'True' for x in v), ('%.3f' % min(red)) if red else '-'))
+    print('%-14s %-4s kernel ms min %.4f median %.4f max %.4f  (n=%d) exact %s  reduce ms min %s  | 4 buffer pairs: fastest %.4f slowest %.4f' % (
+        n, w, min(ms), statistics.median(ms), max(ms), len(ms), all(x[1] == 'True' for x in v), ('%.3f' % min(red)) if red else '-',
+        min(x[3] for x in v), max(x[4] for x in v)))
 PY
 rm -f /tmp/ab_raw.txt

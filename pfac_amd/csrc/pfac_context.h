@@ -32,11 +32,11 @@ constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 *
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
 #ifndef PFAC_WORK_PARTS
-#define PFAC_WORK_PARTS 32
+#define PFAC_WORK_PARTS 16
 #endif
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
-constexpr int kWorkCounterWords = 64 * 32;   /* one counter per 128-byte line */
-constexpr int kStatsWord = 1536;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
+constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */
+constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 5;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned */
 constexpr unsigned long long kDeepWritersPerWalk = 200;   /* writer waves go two spans deep when the previous launch started a walk at >= 1 in 200 positions */
 constexpr double kAutoDenseHitRate = 0.6;     /* PFACX_KERNEL_AUTO: above this level-1 hit rate the simple kernel is the faster one */

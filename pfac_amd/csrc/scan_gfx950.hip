@@ -429,7 +429,10 @@ constexpr int kSpanLog2 = PFAC_SPAN_LOG2;
 constexpr uint32_t kSpanChunks = 1u << kSpanLog2;      /* chunks per span (4 chunks = 8 KiB of input, 32 KiB of results) */
 /* writers run up to kRunAhead spans (>= 128 KiB of input) ahead of the tickets handed out; a scanner holds at
  * most 2 tickets it has not resolved yet, so a ring slot is reused only kRing - kRunAhead >= 32 tickets later */
-constexpr uint32_t kRunAhead = (64u >> kSpanLog2) > 4u ? (64u >> kSpanLog2) : 4u;
+#ifndef PFAC_RUN_AHEAD
+#define PFAC_RUN_AHEAD ((64u >> kSpanLog2) > 4u ? (64u >> kSpanLog2) : 4u)
+#endif
+constexpr uint32_t kRunAhead = PFAC_RUN_AHEAD;
 constexpr uint32_t kRing = 2 * kRunAhead;
 static_assert((kRing - kRunAhead) * kSpanChunks >= 2 * 16 + kSpanChunks, "ring slack covers the unresolved tickets of 16 waves");
 constexpr uint32_t kEnd = 0xFFFFFFFFu;
@@ -661,7 +664,11 @@ void pfac_scan_filter(ScanArgs a)
      * by the scanning wave itself (kWriters == 0). */
     const uint32_t numChunks = n / kChunkBytes;
     const uint32_t numPieces = kWriters ? (numChunks + kSpanChunks - 1) >> kSpanLog2 : numChunks;
-    const uint32_t parts = gridDim.x < (uint32_t)pfac::kWorkParts ? gridDim.x : (uint32_t)pfac::kWorkParts;
+    /* parts: few for the full-result kernel (a narrow front: 16 parts ran 1 % (Snort-style) to 4 % (random patterns)
+     * faster than 32, 64 were 2..4 % slower), more for the compacted-output kernel, whose waves claim single chunks
+     * and would queue up at the counters */
+    constexpr uint32_t kParts = REDUCE ? 32u : (uint32_t)pfac::kWorkParts;
+    const uint32_t parts = gridDim.x < kParts ? gridDim.x : kParts;
     const uint32_t part = blockIdx.x % parts;
     constexpr bool kFrontOn = PFAC_FRONT_LOG2 >= 0;
     constexpr uint32_t kFront = kFrontOn ? PFAC_FRONT_LOG2 : 0;

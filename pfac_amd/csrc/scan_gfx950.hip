@@ -384,7 +384,7 @@ constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
 constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
 #ifndef PFAC_REFILL_MIN
-#define PFAC_REFILL_MIN 32                     /* queue entries are handed out only when at least this many lanes of a walk set are idle:
+#define PFAC_REFILL_MIN 16                     /* queue entries are handed out only when at least this many lanes of a walk set are idle:
                                                 * a refill costs the whole wave ~40 instructions however few lanes it fills
                                                 * (C5 1.94 -> 1.82 ms, C3 -1 %; profiles/r02_ab_refill.txt) */
 #endif
@@ -394,8 +394,11 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #ifndef PFAC_TIMING
 #define PFAC_TIMING 0
 #endif
+#ifndef PFAC_GATHERS_FIRST
+#define PFAC_GATHERS_FIRST 1                   /* the walkers' loads are issued before level 1, not after it: their latency hides behind it (C3 slow class -1.5 %, C5 -4 %) */
+#endif
 #ifndef PFAC_LIST_CAP
-#define PFAC_LIST_CAP 96
+#define PFAC_LIST_CAP 120
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
@@ -845,6 +848,12 @@ void pfac_scan_filter(ScanArgs a)
         PFAC_TICK(8);
         walkConsume();
         PFAC_TICK(0);
+#if PFAC_GATHERS_FIRST
+        walkRefill();
+        PFAC_TICK(1);
+        walkIssue();
+        PFAC_TICK(2);
+#endif
         if (listAt == listEnd && __ballot(hits != 0) == 0) {
             if (chunk == kEnd) {
                 if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
@@ -916,10 +925,12 @@ void pfac_scan_filter(ScanArgs a)
         }
         /* ---- 3. hand idle walker lanes new positions (first transition from LDS), start the next transition of
          *         every live walk */
+#if !PFAC_GATHERS_FIRST
         walkRefill();
         PFAC_TICK(1);
         walkIssue();
         PFAC_TICK(2);
+#endif
         /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
          *         counts; hits beyond the list's capacity stay in `hits` for the next trip */
         if (listAt == listEnd && __ballot(hits != 0) != 0) {

@@ -38,7 +38,6 @@ constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel ha
 constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 5;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned */
-constexpr unsigned long long kDeepWritersPerWalk = 200;   /* writer waves go two spans deep when the previous launch started a walk at >= 1 in 200 positions */
 constexpr double kAutoDenseHitRate = 0.6;     /* PFACX_KERNEL_AUTO: above this level-1 hit rate the simple kernel is the faster one */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS

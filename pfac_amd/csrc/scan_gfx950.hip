@@ -125,7 +125,6 @@ struct ScanArgs {
     int *reducePos;
     unsigned int *reduceCount;
     unsigned int reduceBase;                           /* position of a.in[0] inside the caller's stream */
-    unsigned int deepWriters;                          /* writer waves keep two spans of zero stores in flight (launchFilter) */
 };
 
 /* ---------------------------------------------------------------- lookups */
@@ -281,9 +280,6 @@ template <bool TEX> struct ChainLane {
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
     uint32_t refetches = 0;                    /* a walk that outran its window twice fetches one every step from then on */
-#ifdef PFAC_DUMMY_GATHER                       /* timing experiment: a second gathered load per step, PFAC_DUMMY_GATHER slots away */
-    uint32_t dummy = 0;
-#endif
 
     /* input bytes q .. q+7 out of the window (q - (wend - 20) in 0..19; bytes beyond the window are garbage:
      * callers only use bytes below wend).  A three-level binary shifter on the dword number: selects, no
@@ -339,9 +335,6 @@ template <bool TEX> struct ChainLane {
             const uint32_t idx = row + chainHashSlot(ks, b0);
             if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
             else t = c.slots[idx];
-#ifdef PFAC_DUMMY_GATHER
-            dummy = __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)((idx ^ (uint32_t)PFAC_DUMMY_GATHER) * 16u), 0, 0);
-#endif
         }
         if (needWin) {                                         /* rare: the walk is more than 20 bytes deep */
             W = loadWindow16(c.in32, pos + depth + 1);                 /* pos + depth = position of the edge byte b0 */
@@ -350,9 +343,6 @@ template <bool TEX> struct ChainLane {
     }
     __device__ __forceinline__ bool consume(const Ctx &)
     {
-#ifdef PFAC_DUMMY_GATHER
-        refetches += dummy == 0x9E3779B9u ? 1u : 0u;
-#endif
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
         const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
@@ -388,14 +378,8 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
                                                 * a refill costs the whole wave ~40 instructions however few lanes it fills
                                                 * (C5 1.94 -> 1.82 ms, C3 -1 %; profiles/r02_ab_refill.txt) */
 #endif
-#ifndef PFAC_ROUND_MIN
-#define PFAC_ROUND_MIN 0
-#endif
 #ifndef PFAC_TIMING
 #define PFAC_TIMING 0
-#endif
-#ifndef PFAC_GATHERS_FIRST
-#define PFAC_GATHERS_FIRST 1                   /* the walkers' loads are issued before level 1, not after it: their latency hides behind it (C3 slow class -1.5 %, C5 -4 %) */
 #endif
 #ifndef PFAC_LIST_CAP
 #define PFAC_LIST_CAP 120
@@ -424,9 +408,6 @@ constexpr uint32_t kReduceQueueCap = kQueueCap > 64 ? kQueueCap / 2 : kQueueCap;
 #endif
 #ifndef PFAC_SPAN_LOG2
 #define PFAC_SPAN_LOG2 2
-#endif
-#ifndef PFAC_WRITER_PIPE
-#define PFAC_WRITER_PIPE 2                     /* a writer wave keeps two spans of stores in flight: 0 never, 1 always, 2 = ScanArgs::deepWriters */
 #endif
 constexpr int kSpanLog2 = PFAC_SPAN_LOG2;
 constexpr uint32_t kSpanChunks = 1u << kSpanLog2;      /* chunks per span (4 chunks = 8 KiB of input, 32 KiB of results) */
@@ -684,36 +665,16 @@ void pfac_scan_filter(ScanArgs a)
     unsigned int *const counter = a.work + part * 32;
 
     if (kWriters && wave >= kScanners) {
-        /* ---- writer wave: claim, zero-fill, publish.  With a.deepWriters a writer keeps TWO spans in flight: the
-         * stores of span k are only waited for (the in-order counter: all but the youngest span's) after span k + 1
-         * has been claimed and issued, so the ~1.5 us of the claim's device atomic and the acknowledgement of the
-         * stores overlap.  That pays when the scanning waves are the slower side and the writers only have to keep
-         * out of their way (Snort-style patterns over HTTP text: -2..4 %); when the launch is bound by the result
-         * stream itself (random patterns over random bytes) every block already pushes as hard as the memory system
-         * takes and the same change costs 5 %.  The launcher decides from the walk density of the handle's
-         * previous launch (launchFilter). */
+        /* ---- writer wave: claim, zero-fill, publish.  One span in flight per writer: keeping two in flight (the
+         * next span claimed and issued before the previous one is waited for) was worth 2..4 % while the scanning
+         * waves stalled on their own loads, is worth nothing since they do not, and costs 4 % when the launch is bound
+         * by the result stream (profiles/r02_ab_prefetch_registers_and_writers.txt, r02_ab_list_refill_order.txt) */
         const i32x4 zero = {0, 0, 0, 0};
-        constexpr uint32_t kSpanStores = kSpanChunks * (kChunkBytes * 4 / 1024);       /* 1 KiB per instruction */
-        static_assert(kSpanStores <= 32, "two spans of stores fit the 6-bit wait counter");
-        bool havePrev = false;
-        uint32_t prevK = 0, prevSpan = 0;
-        auto publishPrev = [&]() {                           /* its zeros are in L2 */
-            while (ldsLoad(&ctl->pubCount) != prevK) __builtin_amdgcn_s_sleep(2);        /* publish in order */
-            ldsStore(&ctl->ring[prevK & (kRing - 1)], prevSpan);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            ldsStore(&ctl->pubCount, prevK + 1);
-            havePrev = false;
-        };
         for (uint32_t k = (uint32_t)(wave - kScanners);; k += kWriters) {
             for (;;) {                                      /* my turn to claim, and a ring slot nobody still reads */
                 const uint32_t turn = ldsLoad(&ctl->claimTurn), pops = ldsLoad(&ctl->popCount);
                 if (turn == k && k < (pops >> kSpanLog2) + kRunAhead) break;
-                if (havePrev) {                             /* nothing to issue: finish the span in flight */
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    publishPrev();
-                } else {
-                    __builtin_amdgcn_s_sleep(8);
-                }
+                __builtin_amdgcn_s_sleep(8);
             }
             unsigned int v = 0;
             if (lane == 0) v = atomicAdd(counter, 1u);
@@ -726,29 +687,13 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t c0 = span << kSpanLog2;
             const uint32_t cN = c0 + kSpanChunks < numChunks ? c0 + kSpanChunks : numChunks;
             i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)c0 * kChunkBytes);
-            const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);
+            const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);                 /* 1 KiB per instruction */
             for (uint32_t i = 0; i < stores; i++) __builtin_nontemporal_store(zero, &o4[i * 64 + lane]);
-            if (havePrev) {                                 /* the previous span's zeros are in L2 */
-                if (stores == kSpanStores) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSpanStores) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                publishPrev();
-            }
-            havePrev = true; prevK = k; prevSpan = span;
-#if PFAC_WRITER_PIPE == 0
-            const bool deep = false;
-#elif PFAC_WRITER_PIPE == 1
-            const bool deep = true;
-#else
-            const bool deep = a.deepWriters != 0;
-#endif
-            if (!deep) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                publishPrev();
-            }
-        }
-        if (havePrev) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            publishPrev();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              /* the zeros are in L2 */
+            while (ldsLoad(&ctl->pubCount) != k) __builtin_amdgcn_s_sleep(2);             /* publish in order */
+            ldsStore(&ctl->ring[k & (kRing - 1)], span);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ldsStore(&ctl->pubCount, k + 1);
         }
     } else {
     /* ---- scanning wave */
@@ -831,13 +776,13 @@ void pfac_scan_filter(ScanArgs a)
 #else
 #define PFAC_TICK(k) do { } while (0)
 #endif
-    /* One loop, one copy of every stage.  A trip: (1) finish the walkers' transitions issued one trip ago; (2) if
-     * the staged chunk is completely listed and tested: level 1 over the next chunk (prefetched one chunk ago) and
-     * the prefetch of the one after it; (3) refill idle walker lanes and issue the next transitions; (4) the next
-     * <= kListCap hits -> list; (5) passes while the walk queue has room.  The order matters: the wait counter for
-     * vector memory is in-order, so whoever waits for the walkers' loads in (1) also waits for everything issued
-     * before them.  The prefetch is issued right after (1) and before the walkers' loads of the same trip: it
-     * has the rest of the trip to land, and a later trip's (1) covers it. */
+    /* One loop, one copy of every stage.  A trip: (1) finish the walkers' transitions issued one trip ago; (2) refill
+     * idle walker lanes and issue the next transitions; (3) if the staged chunk is completely listed and tested: level
+     * 1 over the next chunk (prefetched one chunk ago), then the prefetch of the one after it; (4) the next <= kListCap
+     * hits -> list; (5) passes while the walk queue has room.  The order matters.  The wait counter for vector memory
+     * is in-order, so the one wait at the top of a trip is for everything issued in the trip before; the walkers'
+     * loads are what it mostly waits for (gathered, from L2 or beyond), so they are issued first and have (3)-(5) to
+     * land: issued after level 1 they cost C3 1.5 % and C5 4 % (profiles/r02_ab_list_refill_order.txt). */
     for (;;) {
         PFAC_TICK(7);
         /* every load of the previous trip: the walkers' slots, which (1) is about to use, and -- older -- the
@@ -848,17 +793,17 @@ void pfac_scan_filter(ScanArgs a)
         PFAC_TICK(8);
         walkConsume();
         PFAC_TICK(0);
-#if PFAC_GATHERS_FIRST
+        /* ---- 2. hand idle walker lanes new positions (first transition from LDS), start the next transition of
+         *         every live walk */
         walkRefill();
         PFAC_TICK(1);
         walkIssue();
         PFAC_TICK(2);
-#endif
         if (listAt == listEnd && __ballot(hits != 0) == 0) {
             if (chunk == kEnd) {
                 if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
             } else {
-                /* ---- 2. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
+                /* ---- 3. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
                  *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
                  *         this chunk) */
                 const unsigned int afterNext = pop();
@@ -923,14 +868,6 @@ void pfac_scan_filter(ScanArgs a)
 #endif
             }
         }
-        /* ---- 3. hand idle walker lanes new positions (first transition from LDS), start the next transition of
-         *         every live walk */
-#if !PFAC_GATHERS_FIRST
-        walkRefill();
-        PFAC_TICK(1);
-        walkIssue();
-        PFAC_TICK(2);
-#endif
         /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
          *         counts; hits beyond the list's capacity stay in `hits` for the next trip */
         if (listAt == listEnd && __ballot(hits != 0) != 0) {
@@ -1097,17 +1034,7 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     if (blocks > resident) blocks = resident;
     hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
-    /* The counters of the previous launch on this handle (they follow every launch into pinned host memory, nobody
-     * waits for them): walks started per position tell which side of the kernel is the slower one, and with that how
-     * the writer waves should behave.  No history: assume pattern-dense input. */
-    ScanArgs b = a;
-    b.deepWriters = 1;
-    if (c->h_statsPinned) {
-        const volatile unsigned long long *st = c->h_statsPinned;
-        const unsigned long long walks = st[2], positions = st[4];
-        if (positions) b.deepWriters = walks * pfac::kDeepWritersPerWalk >= positions;
-    }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, b);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     e = hipGetLastError();
 #if PFAC_TIMING
     {
@@ -1123,7 +1050,9 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
         fprintf(stderr, "\n");
     }
 #endif
-    if (e == hipSuccess && c->h_statsPinned)
+    /* PFACX_KERNEL_AUTO looks at the level-1 hit density of recent launches: their counters follow the kernel
+     * into pinned host memory, nobody waits for them */
+    if (e == hipSuccess && c->kernelVariant == PFACX_KERNEL_AUTO && c->h_statsPinned)
         e = hipMemcpyAsync(c->h_statsPinned, c->d_workCounters + pfac::kStatsWord, pfac::kStatsCount * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, 0);
     return e;

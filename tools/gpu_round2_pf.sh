@@ -2,6 +2,6 @@
 O=gpurun_out/r02pf; mkdir -p $O; export TMPDIR=/tmp
 cp pfac_amd/lib/libpfac_gfx950.so /tmp/keep.so
 V=tools/bin/variants
-REPEAT=2 WL="c3 c5" timeout 2400 tools/ab.sh $V/n0.so $V/n1.so > $O/ab15.txt 2>&1
+REPEAT=2 WL="c3 c2 c5" timeout 2400 tools/ab.sh $V/e0.so $V/e1.so $V/e2.so > $O/ab16.txt 2>&1
 cp /tmp/keep.so pfac_amd/lib/libpfac_gfx950.so
-cat $O/ab15.txt
+cat $O/ab16.txt

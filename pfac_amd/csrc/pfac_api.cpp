@@ -47,6 +47,7 @@ void freeTables(PFAC_context *c)
     std::vector<pfac::ChainSlot>().swap(c->h_chainSlots);
     std::vector<pfac::ChainSlot>().swap(c->h_rootSlots);
     c->numChainSlots = 0;
+    c->chainJumpLog2 = 0;
     c->numOfTableEntry = c->sizeOfTableEntry = c->sizeOfTableInBytes = 0;
 }
 
@@ -117,11 +118,11 @@ PFAC_status_t uploadChainedHashTable(PFAC_context *c)
     PFAC_status_t st = PFAC_STATUS_SUCCESS;
     if (c->h_chainSlots.empty() || c->h_rootSlots.size() != (size_t)pfac::kCharSet) {
         if (c->perfMode == PFAC_SPACE_DRIVEN) {
-            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->h_rootSlots);
+            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->h_rootSlots, c->chainJumpLog2);
         } else {
             std::vector<Int2> rowPtr, valPtr;
             st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
-            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->h_rootSlots);
+            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->h_rootSlots, c->chainJumpLog2);
         }
         if (st != PFAC_STATUS_SUCCESS) return st;
     }
@@ -719,13 +720,13 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 namespace {
 
 constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
-constexpr uint32_t kCompiledVersion = 2;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap */
+constexpr uint32_t kCompiledVersion = 3;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots */
 /* what the stored tables depend on besides the patterns: hash constants and slot layout */
 constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kGram4Mul * 3u) ^ (pfac::kGram4Mul2 * 5u) ^ (pfac::kFinal3Mul * 7u) ^
                                         ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;
 struct CompiledHeader {
     char magic[8];
-    uint32_t version, fingerprint, perfMode, reserved;
+    uint32_t version, fingerprint, perfMode, jumpLog2;   /* jumpLog2: log2 of the jump-table slots at the end of the chained table */
     uint64_t payloadBytes, payloadFnv1a;
 };
 enum Section : uint32_t { kSecFile = 1, kSecScalars, kSecPatOff, kSecPatLen, kSecSorted, kSecEdgeBegin, kSecEdgeCh, kSecEdgeNext,
@@ -806,6 +807,7 @@ PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
         std::memset(&h, 0, sizeof(h));
         std::memcpy(h.magic, kCompiledMagic, 8);
         h.version = kCompiledVersion; h.fingerprint = kLayoutFingerprint; h.perfMode = (uint32_t)c->perfMode;
+        h.jumpLog2 = (uint32_t)c->chainJumpLog2;
         h.payloadBytes = payload.size(); h.payloadFnv1a = fnv1a64(payload.data(), payload.size());
         FILE *fp = std::fopen(filename, "wb");
         if (!fp) return PFAC_STATUS_FILE_OPEN_ERROR;
@@ -889,7 +891,11 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
                  f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.gram4.size() == (size_t(1) << f.log2Bits4) / 32 &&
                  f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
                  c->h_initialRow.size() == (size_t)pfac::kCharSet && c->h_rootSlots.size() == (size_t)pfac::kCharSet &&
-                 (h.perfMode == PFAC_TIME_DRIVEN || (c->h_hashRow.size() == S && c->h_hashVal.size() == c->h_chainSlots.size()));
+                 h.jumpLog2 >= (uint32_t)pfac::kJumpLog2Min && h.jumpLog2 <= (uint32_t)pfac::kJumpLog2Max &&
+                 c->h_chainSlots.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
+                 (h.perfMode == PFAC_TIME_DRIVEN ||
+                  (c->h_hashRow.size() == S && c->h_hashVal.size() + pfac::kCharSet + (size_t(1) << h.jumpLog2) == c->h_chainSlots.size()));
+            if (ok) c->chainJumpLog2 = (int)h.jumpLog2;
             for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0;
             for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S;
             /* a slot's bucket must lie inside the slot array: the walker indexes it without a bound on the global path */

@@ -108,6 +108,9 @@ inline uint32_t gram3Hash(uint32_t key24, int log2Bits)
     return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits)) << 5 | (key24 & 31u);
 }
 constexpr uint32_t kGram4Mul = 0x9E3779B1u;   /* 32-bit odd multiplier of the 4-gram hash */
+constexpr uint32_t kJumpMul = 0x9E3779B1u;    /* jump table of the chained walker (tables.cpp): slot of a 4-byte prefix */
+constexpr int kJumpLog2Min = 10, kJumpLog2Max = 20;
+inline uint32_t jumpHash(uint32_t key32, int log2Slots) { return (uint32_t)(key32 * kJumpMul) >> (32 - log2Slots); }
 constexpr uint32_t kFinal3Mul = 0x85EBCBu;    /* 24-bit odd multiplier of the length-3 hash */
 inline uint32_t gram4Hash(uint32_t key32, int log2Bits) { return (uint32_t)(key32 * kGram4Mul) >> (32 - log2Bits); }
 /* level 2 is a two-hash Bloom filter: it runs for a few positions per hundred, 64 at a time, so the
@@ -143,6 +146,8 @@ struct PFAC_context {
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
     pfac::ChainSlot *d_rootSlots = nullptr;   /* the 256 transitions of the initial state, same encoding           */
     size_t numChainSlots = 0;
+    int chainJumpLog2 = 0;                    /* the last 2^J slots of the chained table are the jump table, the 256 before them the
+                                                 initial state's bucket (tables.cpp: buildChainedHashTable)                        */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_gram4 = nullptr;

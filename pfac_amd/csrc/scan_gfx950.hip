@@ -110,7 +110,8 @@ struct ScanArgs {
     const Int2 *hashRow;
     const Int2 *hashVal;
     const u32x4 *chainSlots;                           /* pfac::ChainSlot[], 16 bytes each               */
-    const u32x4 *rootSlots;                            /* pfac::ChainSlot[256] of the initial state      */
+    uint32_t rootRow, jumpBase, jumpShift;             /* inside chainSlots: the initial state's bucket (256 slots, indexed by the byte)
+                                                          and the jump table (2^(32 - jumpShift) slots): tables.cpp */
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
     const int *initialRow;
     const uint32_t *gram3;
@@ -246,13 +247,14 @@ __device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos
 template <bool TEX> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
-    const u32x4 *sRoot;
     const uint32_t *in32;
-    __device__ ChainCtx(const ScanArgs &a, const u32x4 *rootInLds)
+    uint32_t rootRow, jumpBase, jumpShift;
+    __device__ ChainCtx(const ScanArgs &a)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          sRoot(rootInLds), in32(reinterpret_cast<const uint32_t *>(a.in)) {}
+          in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift) {}
 };
+constexpr uint32_t kRootKs = 1u | (255u << 9);         /* the initial state's bucket: k = 1, S = 256 -- the slot of byte b is b */
 
 /* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
  * ((k*ch) mod 257) & (S-1), ref PFAC_kernel_spaceDriven.cu:76-124.  256 == -1 (mod 257), k*ch <= 65280. */
@@ -279,7 +281,8 @@ template <bool TEX> struct ChainLane {
     u32x4 W = {0, 0, 0, 0};                    /* W1..W4 as one register quad: the destination of the window load itself */
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
-    uint32_t refetches = 0;                    /* a walk that outran its window twice fetches one every step from then on */
+    bool first = false;                        /* the slot in flight comes from the jump table */
+    bool longWalk = false;                     /* a walk that outran its window once fetches a new one with every step from then on */
 
     /* input bytes q .. q+7 out of the window (q - (wend - 20) in 0..19; bytes beyond the window are garbage:
      * callers only use bytes below wend).  A three-level binary shifter on the dword number: selects, no
@@ -300,14 +303,14 @@ template <bool TEX> struct ChainLane {
      * bytes x0:x1 behind the edge byte: compares the chain, lands in the slot's end state and picks
      * the next edge byte.  Straight-line: the walker's fields are garbage afterwards unless the result
      * is true; `match` is always valid.  False = the walk is over (trap, or no successor). */
-    __device__ __forceinline__ bool advance(const u32x4 &s, uint32_t x0, uint32_t x1)
+    __device__ __forceinline__ bool advance(const u32x4 &s, uint32_t x0, uint32_t x1, bool &ok)
     {
         const uint32_t meta = s.x;
         const uint32_t len = (meta >> 8) & 0xFu;               /* <= kChainMax = 7 */
         const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
         /* the slot is this byte's (not empty, not another byte's), and the first len chain bytes equal the
          * input: two shifts by less than 64 each, so that len == 0 shifts everything out */
-        const bool ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & (((diff << 8) << (56u - 8u * len)) == 0);
+        ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & (((diff << 8) << (56u - 8u * len)) == 0);
         const bool leaf = (meta & pfac::kSlotLeaf) != 0;
         const int id = (int)(leaf ? s.y : s.w);                /* kSlotFinal: see pfac::ChainSlot */
         match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
@@ -318,16 +321,19 @@ template <bool TEX> struct ChainLane {
         return ok & !leaf;
     }
 
-    /* The slots of the initial state live in LDS and the queue entry {position, 20 input bytes} is the walk's
-     * first window, so the first transition is taken right here without touching memory.  Returns false if the
-     * walk is already over. */
-    __device__ __forceinline__ bool start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1)
+    /* A walk starts in the JUMP table (tables.cpp): the queue entry {position, 20 input bytes} is its first window,
+     * and the prefilter has just found its first four bytes to be -- probably -- a pattern prefix, so the slot at
+     * hash(those four bytes) takes it four or more bytes deep with its first gathered load (ks = 0: the bucket is
+     * the slot itself).  If the slot is somebody else's, consume() restarts the walk in the initial state's bucket. */
+    __device__ __forceinline__ void start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1)
     {
         pos = ea.x; match = 0; depth = 0; b0 = ea.y & 0xFF;
         W0 = ea.y; W.x = ea.z; W.y = ea.w; W.z = eb0; W.w = eb1;
         wend = pos + kEntryBytes;
-        needWin = false; needSlot = true; refetches = 0;
-        return advance(c.sRoot[b0], __builtin_amdgcn_alignbyte(ea.z, ea.y, 1), __builtin_amdgcn_alignbyte(ea.w, ea.z, 1));
+        needWin = false; needSlot = true; longWalk = false;
+        first = true;
+        row = c.jumpBase + ((ea.y * pfac::kJumpMul) >> c.jumpShift);
+        ks = 0;
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
@@ -341,7 +347,7 @@ template <bool TEX> struct ChainLane {
             wend = ((pos + depth + 1) & ~3u) + 16u;
         }
     }
-    __device__ __forceinline__ bool consume(const Ctx &)
+    __device__ __forceinline__ bool consume(const Ctx &c)
     {
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
         const uint32_t len = (t.x >> 8) & 0xFu;
@@ -349,12 +355,21 @@ template <bool TEX> struct ChainLane {
         const bool covered = q + len + 1u <= wend;
         needWin = mine & !covered;                             /* matching slot, bytes missing: fetch them and come back */
         needSlot = !needWin;
-        refetches += needWin ? 1u : 0u;
+        longWalk |= needWin;
         uint32_t x0, x1;
         windowBytes(q, x0, x1);
-        bool cont = true;
-        if (!needWin) cont = advance(t, x0, x1);
-        needWin |= refetches >= 2u;                            /* long walks (adversarial input): no more retry rounds */
+        bool cont = true, ok = true;
+        if (!needWin) cont = advance(t, x0, x1, ok);
+        /* the jump table does not know these four bytes (a collision, a final state on the way, a false positive
+         * of the prefilter): the walk starts over in the initial state's bucket, one byte at a time */
+        const bool restart = first & !ok;
+        row = restart ? c.rootRow : row;
+        ks = restart ? kRootKs : ks;
+        depth = restart ? 0u : depth;
+        b0 = restart ? (W0 & 0xFFu) : b0;
+        cont |= restart;
+        first = false;
+        needWin |= longWalk;                                   /* long walks (adversarial input): no more retry rounds */
         return cont;
     }
 };
@@ -464,10 +479,9 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t *sGram4 = sGram3 + words3;
     uint32_t *sFinal3 = sGram4 + words4;
     uint32_t *sShort = sFinal3 + wordsF3;
-    uint32_t *sFirst = sShort + (HAS_SHORT ? 2048 : 0);          /* ChainSlot[256] of the initial state */
     constexpr int kWriters = REDUCE ? 0 : PFAC_WRITERS;             /* the compacted-output variant has no zeros to write */
     constexpr int kScanners = REDUCE ? kReduceScanners : kWavesPerBlock - kWriters;
-    Control *ctl = reinterpret_cast<Control *>(sFirst + pfac::kCharSet * 4);
+    Control *ctl = reinterpret_cast<Control *>(sShort + (HAS_SHORT ? 2048 : 0));
     uint32_t *sQueueAll = reinterpret_cast<uint32_t *>(ctl) + kControlWords;           /* 16-byte aligned */
     constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
     uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * 4;            /* ... second part of the entries: input bytes 12..19 */
@@ -487,7 +501,6 @@ void pfac_scan_filter(ScanArgs a)
         copy16(sGram4, a.gram4, words4);
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
-        copy16(sFirst, a.rootSlots, pfac::kCharSet * 4);
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
@@ -505,7 +518,7 @@ void pfac_scan_filter(ScanArgs a)
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sGram4, sFinal3, sShort,
                   35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
-    const WCtx wctx(a, reinterpret_cast<const u32x4 *>(sFirst));
+    const WCtx wctx(a);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
 #pragma unroll
@@ -601,7 +614,7 @@ void pfac_scan_filter(ScanArgs a)
         }
         stagePending();
     };
-    /* hand verified queue entries to idle walker lanes; the first transition happens here (LDS) */
+    /* hand verified queue entries to idle walker lanes */
     auto walkRefill = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
@@ -610,24 +623,18 @@ void pfac_scan_filter(ScanArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);
-                bool cont = false;
                 if (take) {
                     const uint32_t qi = (qh + rank) & kMask;
                     const u32x2 eb = queueB[qi];
-                    cont = walk[s].start(wctx, queue[qi], eb.x, eb.y);
+                    walk[s].start(wctx, queue[qi], eb.x, eb.y);
                 }
-                report(take & !cont, walk[s], s, false);
-                alive[s] = alive[s] | cont;
+                alive[s] = alive[s] | take;
                 const uint32_t idleLanes = (uint32_t)__popcll(idle);
                 const uint32_t taken = idleLanes < qv - qh ? idleLanes : qv - qh;
                 stStarts += taken;
-#if PFAC_STATS
-                stStartDead += (uint32_t)__popcll(__ballot(take & !cont));
-#endif
                 qh = uni(qh + taken);
             }
         }
-        stagePending();
     };
     auto anyAlive = [&]() {
         bool any = false;
@@ -823,7 +830,14 @@ void pfac_scan_filter(ScanArgs a)
                     if (tt == 0) takeTile0(dt, follow);
                     else takeTile1(dt, follow);
                     reinterpret_cast<u32x4 *>(stage)[tt * 64 + lane] = dt;
-                    if (tt == kTilesPerIter - 1 && lane < 8) stage[kTilesPerIter * 256 + lane] = follow;
+                    if (tt == kTilesPerIter - 1 && lane < 8) {
+                        /* the address is computed on the spot (volatile: not hoisted out of the loop into a register
+                         * that lives -- or is spilled -- across it) */
+                        uint32_t at;
+                        const uint32_t haloBase = (uint32_t)(reinterpret_cast<unsigned char *>(stage + kTilesPerIter * 256) - smem);   /* smem is LDS address 0 */
+                        asm volatile("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(at) : "v"(lane), "s"(haloBase));
+                        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(at) = follow;
+                    }
                     const uint32_t dw[4] = {dt.x, dt.y, dt.z, dt.w};
                     uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
                     const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow);
@@ -991,7 +1005,6 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
-    bytes += pfac::kCharSet * sizeof(pfac::ChainSlot);
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
     bytes += scanners * ((reduce ? kReduceQueueCap : kQueueCap) * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
@@ -1088,7 +1101,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
                        int *d_matched_result, ScanArgs &a)
 {
     if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
-    if (!c->d_chainSlots || !c->d_rootSlots || (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense))
+    if (!c->d_chainSlots || c->chainJumpLog2 <= 0 || (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense))
         return PFAC_STATUS_INTERNAL_ERROR;
     a = ScanArgs{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
@@ -1101,7 +1114,9 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.hashRowBytes = clampExtent(c->h_hashRow.size() * sizeof(Int2));
     a.hashValBytes = clampExtent(c->h_hashVal.size() * sizeof(Int2));
     a.chainSlots = reinterpret_cast<const u32x4 *>(c->d_chainSlots);
-    a.rootSlots = reinterpret_cast<const u32x4 *>(c->d_rootSlots);
+    a.jumpShift = 32u - (uint32_t)c->chainJumpLog2;
+    a.jumpBase = (uint32_t)(c->numChainSlots - (size_t(1) << c->chainJumpLog2));
+    a.rootRow = a.jumpBase - (uint32_t)pfac::kCharSet;
     a.chainBytes = clampExtent(c->numChainSlots * sizeof(pfac::ChainSlot));
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;

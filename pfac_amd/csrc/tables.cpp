@@ -124,8 +124,11 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * lands on a non-final chain state; the next slot carries on from there).
  * rootSlots is the same encoding for the 256 transitions of the initial state (kept in LDS).
  */
-static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next)
+static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next,
+                               const unsigned char *forced = nullptr, int numForced = 0)
 {
+    /* forced: the first chain bytes are given (a path through non-final states that may branch: the jump slots
+     * below) and `next` is the state behind them; the single-successor chain carries on from there */
     ChainSlot s;
     std::memset(&s, 0, sizeof(s));
     s.meta = kSlotEmpty;
@@ -133,6 +136,7 @@ static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &row
     if (next < 0) return s;
     auto follow = [&](int limit, int &end) {
         int k = 0;
+        for (; k < numForced; k++) s.chain[k] = forced[k];
         end = next;
         while (k < limit && end > fa.numPatterns && fa.edgeBegin[end + 1] - fa.edgeBegin[end] == 1) {
             s.chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
@@ -157,21 +161,64 @@ static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &row
     return s;
 }
 
+/*
+ * Behind the slots of the reference layout the array carries two more regions (device-only, like the rest):
+ *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 1, S = 256);
+ *   [jumpBase, jumpBase + 2^J) the JUMP table: one slot per 4-byte pattern prefix whose first three states are not
+ *                              final, at hash(prefix), encoded as a transition on the first byte with the other
+ *                              three as the head of its chain.  A walk starts there -- the prefilter has just
+ *                              established that the four bytes are (probably) a prefix -- and lands four or
+ *                              more bytes deep with its first gathered load.  The table is an accelerator, not
+ *                              an index: prefixes that collide (first come, first served), that pass a final
+ *                              state, or that the prefilter let through wrongly simply are not there, and the
+ *                              walker falls back to the initial state's bucket.
+ */
 PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2> &rowPtr,
                                     const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots,
-                                    std::vector<ChainSlot> &rootSlots)
+                                    std::vector<ChainSlot> &rootSlots, int &jumpLog2)
 {
-    try {
-        slots.resize(valPtr.size());
-        rootSlots.resize(kCharSet);
-    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     for (const Int2 &r : rowPtr)
         if (r.x >= 0 && (((uint32_t)r.y >> 16) > 256u || ((uint32_t)r.y & 0xFFFFu) > 255u)) return PFAC_STATUS_INTERNAL_ERROR;
-    for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
-    for (int c = 0; c < kCharSet; c++) rootSlots[c] = makeChainSlot(fa, rowPtr, c, kTrapState);
-    const int init = fa.initialState;
-    for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
-        rootSlots[fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
+    const int F = fa.numPatterns, init = fa.initialState;
+    /* 4-byte prefixes: {key, state at depth 4} */
+    struct Prefix { uint32_t key; int state; };
+    std::vector<Prefix> prefixes;
+    try {
+        for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
+            const int s1 = fa.edgeNext[e1];
+            if (s1 <= F) continue;
+            for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
+                const int s2 = fa.edgeNext[e2];
+                if (s2 <= F) continue;
+                for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
+                    const int s3 = fa.edgeNext[e3];
+                    if (s3 <= F) continue;
+                    for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++)
+                        prefixes.push_back({(uint32_t)fa.edgeCh[e1] | ((uint32_t)fa.edgeCh[e2] << 8) | ((uint32_t)fa.edgeCh[e3] << 16) |
+                                                ((uint32_t)fa.edgeCh[e4] << 24),
+                                            fa.edgeNext[e4]});
+                }
+            }
+        }
+        jumpLog2 = kJumpLog2Min;
+        while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < 8 * prefixes.size()) jumpLog2++;
+        const size_t rootRow = valPtr.size(), jumpBase = rootRow + kCharSet;
+        slots.resize(jumpBase + (size_t(1) << jumpLog2));
+        rootSlots.resize(kCharSet);
+        for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
+        for (int c = 0; c < kCharSet; c++) rootSlots[c] = makeChainSlot(fa, rowPtr, c, kTrapState);
+        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
+            rootSlots[fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
+        for (int c = 0; c < kCharSet; c++) slots[rootRow + c] = rootSlots[c];
+        const ChainSlot empty = makeChainSlot(fa, rowPtr, 0, kTrapState);
+        for (size_t i = jumpBase; i < slots.size(); i++) slots[i] = empty;
+        for (const Prefix &p : prefixes) {
+            ChainSlot &dst = slots[jumpBase + jumpHash(p.key, jumpLog2)];
+            if (!(dst.meta & kSlotEmpty)) continue;            /* taken: this prefix walks from the initial state */
+            const unsigned char rest[3] = {(unsigned char)(p.key >> 8), (unsigned char)(p.key >> 16), (unsigned char)(p.key >> 24)};
+            dst = makeChainSlot(fa, rowPtr, (int)(p.key & 0xFFu), p.state, rest, 3);
+        }
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     return PFAC_STATUS_SUCCESS;
 }
 

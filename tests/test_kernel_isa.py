@@ -83,7 +83,9 @@ def test_scan_loop_waits_once_per_trip(isa):
         # the scan loop: from the first copy out of a reserved register back to the enclosing loop header
         first_copy = next(i for i, l in enumerate(lines) if re.search(r"v_mov_b32 v\d+, v120\b", l))
         header = max(i for i, l in enumerate(lines[:first_copy]) if "Loop Header: Depth=1" in l)
-        end = next(i for i, l in enumerate(lines) if i > first_copy and "Loop Header: Depth=1" in l)
+        label = re.match(r"\.L(BB\d+_\d+):", lines[header]).group(1)
+        last_block = max(i for i, l in enumerate(lines) if f"Header={label} " in l)      # last block annotated as part of the loop
+        end = next(i for i, l in enumerate(lines) if i > last_block and re.match(r"\.LBB\d+_\d+:", l))
         loop = lines[header:end]
         waits = [i for i, l in enumerate(loop) if "s_waitcnt" in l and "vmcnt" in l]
         # the compacted-output instances flush their staged pairs with a returning atomic now and then and wait for it

@@ -53,6 +53,8 @@ typedef struct {
     int filterLog2Bits4;      /* 4-gram bitmap has 2^filterLog2Bits4 bits        */
     int filterLog2BitsFinal3; /* length-3-pattern bitmap                         */
     size_t filterBitsSet4;
+    int chainJumpLog2;        /* PFACX_TABLE_CHAIN: log2 of its jump-table slots (0 until the table exists) */
+    size_t chainSlots;        /* PFACX_TABLE_CHAIN: slots in total                                          */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -67,7 +69,11 @@ typedef enum {
     PFACX_TABLE_FILTER_GRAM3 = 4,  /* uint32[2^filterLog2Bits / 32]                 */
     PFACX_TABLE_FILTER_SHORT = 5,  /* uint32[2048] (65536 bits)                     */
     PFACX_TABLE_FILTER_GRAM4 = 6,  /* uint32[2^filterLog2Bits4 / 32]                */
-    PFACX_TABLE_FILTER_FINAL3 = 7  /* uint32[2^filterLog2BitsFinal3 / 32]           */
+    PFACX_TABLE_FILTER_FINAL3 = 7, /* uint32[2^filterLog2BitsFinal3 / 32]           */
+    PFACX_TABLE_CHAIN        = 8   /* uint32[4] per slot: the device-only chained form of the hashed table that the
+                                      filter kernel walks in both perf modes (slot i = reference hashValPtr[i]; then
+                                      the 256 slots of the initial state; the last 2^chainJumpLog2 slots are the
+                                      jump table of 4-byte prefixes).  Built on first use on a host-only handle.  */
 } PFACX_table_t;
 
 PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const void **ptr,

@@ -26,7 +26,8 @@ PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO = 0, 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
- PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_GRAM4, PFACX_TABLE_FILTER_FINAL3) = range(8)
+ PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_GRAM4, PFACX_TABLE_FILTER_FINAL3,
+ PFACX_TABLE_CHAIN) = range(9)
 
 
 class STATUS:
@@ -59,6 +60,7 @@ class PFACX_info(C.Structure):
         ("filterLog2Bits", C.c_int), ("filterHasShort", C.c_int), ("filterBitsSet", C.c_size_t),
         ("kernelVariant", C.c_int), ("multiProcessorCount", C.c_int),
         ("filterLog2Bits4", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSet4", C.c_size_t),
+        ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
     ]
 
 

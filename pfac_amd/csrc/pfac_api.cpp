@@ -680,6 +680,8 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
     info->filterLog2Bits4 = handle->filter.log2Bits4;
     info->filterLog2BitsFinal3 = handle->filter.log2BitsF3;
     info->filterBitsSet4 = handle->filter.bitsSet4;
+    info->chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
+    info->chainSlots = handle->h_chainSlots.size();
     info->multiProcessorCount = handle->multiProcessorCount;
     return PFAC_STATUS_SUCCESS;
 }
@@ -707,6 +709,14 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.gram4.data(); *bytes = handle->filter.gram4.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_FINAL3:
         *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_CHAIN: {
+        if (handle->h_chainSlots.empty()) {
+            std::lock_guard<std::mutex> g(handle->lock);
+            const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */
+            if (st != PFAC_STATUS_SUCCESS) return st;
+        }
+        *ptr = handle->h_chainSlots.data(); *bytes = handle->h_chainSlots.size() * sizeof(pfac::ChainSlot); break;
+    }
     default: return PFAC_STATUS_INVALID_PARAMETER;
     }
     return PFAC_STATUS_SUCCESS;

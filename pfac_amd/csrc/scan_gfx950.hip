@@ -397,7 +397,7 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #define PFAC_TIMING 0
 #endif
 #ifndef PFAC_LIST_CAP
-#define PFAC_LIST_CAP 120
+#define PFAC_LIST_CAP 128
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
 constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */

@@ -320,3 +320,67 @@ def test_duplicate_patterns_are_one_pattern_with_the_highest_id(tmp_path, perf):
         h.setPlatform(platform)
         assert np.array_equal(h.match_host_array(data), want)
     h.destroy()
+
+
+@pytest.mark.parametrize("name,perf", [("c1", "dense"), ("ex2", "hash"), ("c3", "hash"), ("c3", "dense"), ("c5", "hash"), ("binary", "hash")])
+def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf):
+    """The device-only chained table (PFACX_TABLE_CHAIN), walked the way the filter kernel's walkers do -- first
+    slot from the jump table at hash(first four bytes), restart in the initial state's bucket if that slot is somebody
+    else's, then one slot per transition with its chain -- gives the reference's result at every position.  No
+    prefilter here: the tables alone must be exact."""
+    w = workloads[name]
+    h = api.PFAC.createHostOnly()
+    h.setPerfMode(api.PFAC_TIME_DRIVEN if perf == "dense" else api.PFAC_SPACE_DRIVEN)
+    h.readPatternFromFile(w.pattern_file)
+    slots = h.table(api.PFACX_TABLE_CHAIN).reshape(-1, 4)
+    info = h.info()
+    h.destroy()
+    J = info.chainJumpLog2
+    assert 10 <= J <= 20 and info.chainSlots == len(slots)
+    jump_base = len(slots) - (1 << J)
+    root_row = jump_base - 256
+    EMPTY, LEAF, FINAL = 1 << 14, 1 << 13, 1 << 12
+    n = min(len(w.data), 30000)
+    data = bytes(w.data[:n]) + bytes(80)
+    limit = n - info.maxPatternLen               # beyond it a walk would read the padding
+    expect = oracle_results[name]
+
+    def step(slot, b0, p):
+        """transition on edge byte b0 with the input behind it at p: (ok, leaf, match id or 0, end row, ks, bytes consumed)"""
+        meta = int(slot[0])
+        ln = (meta >> 8) & 0xF
+        chain = int(slot[2]).to_bytes(4, "little") + int(slot[3]).to_bytes(4, "little")
+        ok = (meta & (EMPTY | 0xFF)) == b0 and chain[:ln] == data[p:p + ln]
+        leaf = bool(meta & LEAF)
+        ident = 0
+        if ok and meta & FINAL:
+            ident = int(slot[1]) if leaf else int(slot[3])
+        return ok, leaf, ident, int(slot[1]), meta >> 15, 1 + ln
+
+    used_jump = fell_back = 0
+    for i in range(0, max(limit, 0)):
+        x = int.from_bytes(data[i:i + 4], "little")
+        match = 0
+        ok, leaf, ident, row, ks, used = step(slots[jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J))], data[i], i + 1)
+        if ok:
+            used_jump += 1
+        else:                                      # restart in the initial state's bucket (k = 1, S = 256)
+            fell_back += 1
+            ok, leaf, ident, row, ks, used = step(slots[root_row + data[i]], data[i], i + 1)
+        depth = 0
+        while ok:
+            if ident:
+                match = ident
+            depth += used
+            if leaf:
+                break
+            b0 = data[i + depth]
+            prod = (ks & 0x1FF) * b0
+            r = (prod & 0xFF) - (prod >> 8)
+            if r < 0:
+                r += 257
+            ok, leaf, ident, row, ks, used = step(slots[row + (r & (ks >> 9))], b0, i + depth + 1)
+        assert match == int(expect[i]), (name, perf, i, match, int(expect[i]))
+    assert used_jump + fell_back == max(limit, 0)
+    if name == "c3":
+        assert used_jump > 0                       # the Snort-style stream does contain 4-byte pattern prefixes

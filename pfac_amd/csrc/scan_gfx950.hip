@@ -26,27 +26,33 @@
  *
  *   SCANNING waves take 2 KiB chunks of published spans from an LDS ticket counter:
  *   1. FILTER, level 1 (every position, LDS only): lane l tests its 16 positions of
- *      each tile against a 3-gram Bloom bitmap (aligned dword read + shift), plus an
- *      exact 2-gram bitmap when patterns shorter than 3 bytes exist.  A miss proves
- *      the result is 0.  The chunk is staged in LDS on the way; the next chunk is
- *      prefetched into the same registers.
+ *      each tile against a 3-gram Bloom bitmap (aligned dword read + shift; patterns
+ *      of 1-2 bytes are folded into it when the set is compiled).  A miss proves the
+ *      result is 0.  The chunk is staged in LDS on the way; the next chunk is
+ *      prefetched into nine registers the compiler is told not to use (v119..v127,
+ *      inline assembly), so that no register copy ever waits for it.
  *   2. LIST.  The lanes' hits become one list of 16-bit codes (prefix sum of the hit
  *      counts, one divergent loop).
  *   3. FILTER, level 2, one hit per lane: 20 bytes cut out of the stage, tested
- *      against a two-hash 4-gram bitmap (+ length-3 bitmap); survivors go to the
- *      wave's walk queue {position, 20 input bytes}.
+ *      against a two-hash 4-gram bitmap (+ length-3 bitmap, + exact 2-byte bitmap);
+ *      survivors go to the wave's walk queue {position, 20 input bytes}.
  *   4. WALK.  Each lane runs 2 split-phase walkers over a device-only "chained"
  *      copy of the reference's hash table (tables.cpp; used for BOTH perf modes),
  *      16 bytes per slot: one gathered load per edge byte + up to 7 single-
  *      successor bytes; the loads of a step are issued in one trip of the loop and
- *      consumed in the next.  The input window stays in registers: the entry's 20
- *      bytes end 99.9 % of the walks without an input load.  "Texture" mode = buffer-
- *      resource loads.
+ *      consumed in the next.  A walk starts in a JUMP table keyed by its first four
+ *      bytes (which level 2 has just found to be a probable pattern prefix) and
+ *      restarts in the initial state's bucket if its prefix is not there.  The input
+ *      window stays in registers: the entry's 20 bytes end 99.9 % of the walks
+ *      without an input load.  "Texture" mode = buffer-resource loads.
  *   5. PATCH.  A non-zero result overwrites its zero, which the writer wave had in
  *      L2 before the chunk was handed out (same CU, same L2: ordered).
- *   The loop has ONE copy of every stage: a trip starts with a walker round, stages
- *   a new chunk only when the previous one is listed and tested, and tests list
- *   entries only while the queue has room -- otherwise the trip just walks.
+ *   The loop has ONE copy of every stage and ONE wait for vector memory: a trip is
+ *   wait -> consume the walkers' slots -> refill -> issue the next slots -> (if the
+ *   staged chunk is listed and tested) level 1 of the next chunk + prefetch of the
+ *   one after it -> list -> passes while the queue has room.  The wait counter is
+ *   in-order; the walkers' gathered loads are what the wait is mostly for, so they
+ *   go first and have the rest of the trip to land.
  *
  *   The compacted-output variant (REDUCE) has no zeros to write and no writer waves;
  *   its scanning waves claim chunks from the device counters themselves.  So do the

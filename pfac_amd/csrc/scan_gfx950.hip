@@ -711,10 +711,23 @@ void pfac_scan_filter(ScanArgs a)
     } else {
     /* ---- scanning wave */
     /* ticket for the next chunk (lane 0 holds the answer): cheap, asked for one chunk ahead ... */
-    auto pop = [&]() {
+    /* Without writer waves the tickets come from the part's device counter, a granule of the front (adjacent chunks)
+     * per atomic: the wave waits for the atomic's answer -- and, the counter being in-order, for its own loads in
+     * flight -- so it asks once per granule, not once per chunk. */
+    constexpr uint32_t kTicketBatch = kWriters ? 1u : (kFrontOn ? (1u << kFront) : 1u);
+    uint32_t ticketNext = 0, ticketEnd = 0;
+    auto pop = [&]() -> unsigned int {
         unsigned int v = 0;
-        if (lane == 0) v = kWriters ? atomicAdd(&ctl->popCount, 1u) : atomicAdd(counter, 1u);
-        return v;
+        if (kWriters) {
+            if (lane == 0) v = atomicAdd(&ctl->popCount, 1u);
+            return v;
+        }
+        if (ticketNext == ticketEnd) {
+            if (lane == 0) v = atomicAdd(counter, kTicketBatch);
+            ticketNext = uni(v);
+            ticketEnd = ticketNext + kTicketBatch;
+        }
+        return ticketNext++;
     };
     /* ... and turned into a chunk number when its data is to be prefetched: waits for the writers if they are
      * behind (then the launch is bound by the result stream, as it should be).  kEnd = the part is finished. */

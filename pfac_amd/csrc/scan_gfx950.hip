@@ -701,6 +701,8 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t cN = c0 + kSpanChunks < numChunks ? c0 + kSpanChunks : numChunks;
             i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)c0 * kChunkBytes);
             const uint32_t stores = (cN - c0) * (kChunkBytes * 4 / 1024);                 /* 1 KiB per instruction */
+            /* non-temporal: plain stores run the launch 10 % slower, stores with a wider scope (sc0 / sc1) 2-3 times
+             * (profiles/r02_ab_zero_store_policy.txt) */
             for (uint32_t i = 0; i < stores; i++) __builtin_nontemporal_store(zero, &o4[i * 64 + lane]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              /* the zeros are in L2 */
             while (ldsLoad(&ctl->pubCount) != k) __builtin_amdgcn_s_sleep(2);             /* publish in order */

@@ -662,6 +662,24 @@ def rank_main(args):
                                        "same_result": bool(np.array_equal(hp, pos[keep]))}
                     del h_in, h_out
                 out["host_path_pcie_inclusive"] = host_path
+            # What this part sustains for the traffic shape of the path with nothing else in it ("also
+            # measure a 1R:4W streaming kernel as the achievable ceiling and report both"): pfac_stream_1r4w of the
+            # kernel module, on the very buffers just timed.  It zeroes d_out: everything above has been checked.
+            try:
+                import ctypes as C
+                from pfac_amd import api as _api
+                mod = C.CDLL(_api.library_paths()[1])
+                mod.PFACX_streamProbe.restype = C.c_double
+                mod.PFACX_streamProbe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                n4k = run.n_read // 4096 * 4096
+                sms = float(mod.PFACX_streamProbe(run.d_in.data_ptr(), run.d_out.data_ptr(), n4k, 10))
+                if sms > 0:
+                    out["roofline"]["bare_stream_1r4w"] = {
+                        "ms": round(sms, 4), "frac": round(5.0 * n4k / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "scan_over_stream": round(out["roofline"]["kernel_ms_avg"] * n4k / run.n_read / sms, 3),
+                        "note": "every wave reads 1 KiB and writes 4 KiB of zeros, same buffers, 10 launches"}
+            except (OSError, AttributeError) as e:
+                log(f"[bench] stream probe skipped: {e}")
             if not args.no_other_configs:
                 buffers = (run.d_in, run.d_out)
                 out["other_configs"] = other_configs(args, device, buffers)

@@ -48,6 +48,12 @@ PFAC_status_t PFAC_reduce_inplace_kernel(PFAC_handle_t handle, int *d_input_stri
                                          int *d_match_result, int *d_pos, int *h_num_matched,
                                          int *h_match_result, int *h_pos);
 
+/* Measurement only (no reference counterpart): the traffic shape of the match path with nothing else in it -- every
+ * wave reads 1 KiB of d_in and writes 4 KiB of zeros to d_out, non-temporal.  Returns the average milliseconds of
+ * `launches` launches over the first n bytes (a multiple of 4096) of d_in, or a negative value on a HIP error.
+ * bench.py reports it next to the scan as "what this part sustains for 1 B read : 4 B written" (SURVEY 8d). */
+double PFACX_streamProbe(const void *d_in, void *d_out, size_t n, int launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = (
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
-    "PFAC_reduce_kernel", "PFAC_reduce_inplace_kernel",
+    "PFAC_reduce_kernel", "PFAC_reduce_inplace_kernel", "PFACX_streamProbe",
 )
 
 

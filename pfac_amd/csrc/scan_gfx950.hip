@@ -1337,9 +1337,51 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     return PFAC_STATUS_SUCCESS;
 }
 
+/* ---------------------------------------------------------- stream probe (measurement only) */
+
+/* The traffic shape of the match path with nothing else in it: every wave reads 1 KiB of the input and writes 4 KiB
+ * of zeros (non-temporal), small blocks in dispatch order.  bench.py runs it on the very buffers it has just timed
+ * the scan on and reports it next to the scan ("what this part sustains for 1 B read : 4 B written"). */
+__global__ __launch_bounds__(256) void pfac_stream_1r4w(const u32x4 *in, i32x4 *out, unsigned int *sink)
+{
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const u32x4 v = in[tile * 64 + lane];
+    const i32x4 z = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) __builtin_nontemporal_store(z, &out[tile * 256 + k * 64 + lane]);
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345678u) *sink = v.x;      /* keeps the load */
+}
+
 } // namespace
 
 extern "C" {
+
+/* average milliseconds of `launches` back-to-back launches of pfac_stream_1r4w over the first n (a multiple of 4096)
+ * bytes of d_in, 4 n bytes of d_out are overwritten with zeros; < 0: a HIP error */
+double PFACX_streamProbe(const void *d_in, void *d_out, size_t n, int launches)
+{
+    if (!d_in || !d_out || n < 4096 || launches < 1) return -1.0;
+    unsigned int *sink = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    double ms = -1.0;
+    if (hipMalloc(reinterpret_cast<void **>(&sink), sizeof(unsigned int)) == hipSuccess && hipEventCreate(&a) == hipSuccess &&
+        hipEventCreate(&b) == hipSuccess) {
+        const unsigned blocks = (unsigned)(n / 4096);
+        for (int r = 0; r < 3; r++)
+            hipLaunchKernelGGL(pfac_stream_1r4w, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const u32x4 *>(d_in), reinterpret_cast<i32x4 *>(d_out), sink);
+        (void)hipEventRecord(a, 0);
+        for (int r = 0; r < launches; r++)
+            hipLaunchKernelGGL(pfac_stream_1r4w, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const u32x4 *>(d_in), reinterpret_cast<i32x4 *>(d_out), sink);
+        (void)hipEventRecord(b, 0);
+        float t = 0;
+        if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&t, a, b) == hipSuccess && hipGetLastError() == hipSuccess) ms = (double)t / launches;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (sink) (void)hipFree(sink);
+    return ms;
+}
 
 PFAC_status_t PFAC_kernel_timeDriven_warpper(PFAC_handle_t handle, char *d_input_string, size_t input_size,
                                              int *d_matched_result)

@@ -331,15 +331,19 @@ template <bool TEX> struct ChainLane {
      * and the prefilter has just found its first four bytes to be -- probably -- a pattern prefix, so the slot at
      * hash(those four bytes) takes it four or more bytes deep with its first gathered load (ks = 0: the bucket is
      * the slot itself).  If the slot is somebody else's, consume() restarts the walk in the initial state's bucket. */
-    __device__ __forceinline__ void start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1)
+    __device__ __forceinline__ void start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1, const uint32_t *shortBits)
     {
         pos = ea.x; match = 0; depth = 0; b0 = ea.y & 0xFF;
         W0 = ea.y; W.x = ea.z; W.y = ea.w; W.z = eb0; W.w = eb1;
         wend = pos + kEntryBytes;
         needWin = false; needSlot = true; longWalk = false;
-        first = true;
-        row = c.jumpBase + ((ea.y * pfac::kJumpMul) >> c.jumpShift);
-        ks = 0;
+        /* a pattern of one or two bytes matches here (shortBits: the exact 2-byte bitmap, only given when the set has
+         * such patterns): the prefix passes a final state, so it has no jump slot -- straight to the initial state's
+         * bucket instead of finding that out a round later */
+        const bool viaRoot = shortBits != nullptr && testBit(shortBits, ea.y & 0xFFFFu) != 0;
+        first = !viaRoot;
+        row = viaRoot ? c.rootRow : c.jumpBase + ((ea.y * pfac::kJumpMul) >> c.jumpShift);
+        ks = viaRoot ? kRootKs : 0u;
     }
     __device__ __forceinline__ void issue(const Ctx &c)
     {
@@ -632,7 +636,7 @@ void pfac_scan_filter(ScanArgs a)
                 if (take) {
                     const uint32_t qi = (qh + rank) & kMask;
                     const u32x2 eb = queueB[qi];
-                    walk[s].start(wctx, queue[qi], eb.x, eb.y);
+                    walk[s].start(wctx, queue[qi], eb.x, eb.y, HAS_SHORT ? sShort : nullptr);
                 }
                 alive[s] = alive[s] | take;
                 const uint32_t idleLanes = (uint32_t)__popcll(idle);

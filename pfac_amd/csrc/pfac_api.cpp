@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
+#include <vector>
 
 #include "pfac_host.h"
 
@@ -56,6 +58,7 @@ void freeHostStage(PFAC_context *c)
     for (int b = 0; b < 2; b++) {
         devFree(c->d_stageIn[b]);
         devFree(c->d_stageOut[b]);
+        devFree(c->d_stagePos[b]);
         if (c->evUp[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evUp[b]));
         if (c->evScan[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evScan[b]));
         if (c->evDown[b]) (void)hipEventDestroy(static_cast<hipEvent_t>(c->evDown[b]));
@@ -434,31 +437,36 @@ PFAC_status_t matchDeviceLocked(PFAC_context *c, char *d_inputString, size_t siz
  * and only its own results go back.  The staging buffers, two copy streams and their events belong to the
  * handle and are created on first use; the scan itself stays on the default stream.
  */
-PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
+static PFAC_status_t ensureHostStage(PFAC_context *c, size_t need)
 {
-    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
+    if (c->hostStagePositions >= need) return PFAC_STATUS_SUCCESS;
+    freeHostStage(c);
+    bool ok = true;
+    for (int b = 0; b < 2 && ok; b++) {
+        ok = hipMalloc(reinterpret_cast<void **>(&c->d_stageIn[b]), (need + 3) & ~size_t(3)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&c->d_stageOut[b]), need * sizeof(int)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&c->d_stagePos[b]), need * sizeof(int)) == hipSuccess;
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&e[k], hipEventDisableTiming) == hipSuccess;
+        c->evUp[b] = e[0]; c->evScan[b] = e[1]; c->evDown[b] = e[2];
+    }
+    hipStream_t up = nullptr, down = nullptr;
+    ok = ok && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&down, hipStreamNonBlocking) == hipSuccess;
+    c->stageUp = up; c->stageDown = down;
+    if (!ok) { (void)hipGetLastError(); freeHostStage(c); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
+    c->hostStagePositions = need;
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* every result crosses the link: pieces with many matches */
+static PFAC_status_t matchHostFullVector(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
+{
     const size_t overlap = (size_t)c->fa.maxPatternLen;
     const size_t piece = owned < kHostPiece ? owned : kHostPiece;
-    const size_t need = piece + overlap;
-    if (c->hostStagePositions < need) {
-        freeHostStage(c);
-        bool ok = true;
-        for (int b = 0; b < 2 && ok; b++) {
-            ok = hipMalloc(reinterpret_cast<void **>(&c->d_stageIn[b]), (need + 3) & ~size_t(3)) == hipSuccess &&
-                 hipMalloc(reinterpret_cast<void **>(&c->d_stageOut[b]), need * sizeof(int)) == hipSuccess;
-            hipEvent_t e[3] = {nullptr, nullptr, nullptr};
-            for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&e[k], hipEventDisableTiming) == hipSuccess;
-            c->evUp[b] = e[0]; c->evScan[b] = e[1]; c->evDown[b] = e[2];
-        }
-        hipStream_t up = nullptr, down = nullptr;
-        ok = ok && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess &&
-             hipStreamCreateWithFlags(&down, hipStreamNonBlocking) == hipSuccess;
-        c->stageUp = up; c->stageDown = down;
-        if (!ok) { (void)hipGetLastError(); freeHostStage(c); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
-        c->hostStagePositions = need;
-    }
+    PFAC_status_t st = ensureHostStage(c, piece + overlap);
+    if (st != PFAC_STATUS_SUCCESS) return st;
     hipStream_t up = static_cast<hipStream_t>(c->stageUp), down = static_cast<hipStream_t>(c->stageDown);
-    PFAC_status_t st = PFAC_STATUS_SUCCESS;
     bool used[2] = {false, false};
     size_t i = 0;
     for (size_t off = 0; off < owned && st == PFAC_STATUS_SUCCESS; off += piece, i++) {
@@ -485,6 +493,100 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
                          hipStreamSynchronize(down) == hipSuccess;
     if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     return st;
+}
+
+/*
+ * PFAC_matchFromHost on the GPU.  Four of the five bytes per position that the reference moves over the host link
+ * (PFAC.cpp:916-960) are results, and nearly all of them are zero.  So the pieces are scanned with the compacted-
+ * output kernel and only the (position, id) pairs come back; the zeros are written where they are needed -- by a few
+ * helper threads of this call straight into the caller's result vector, while the pieces are uploaded and scanned --
+ * and the pairs are scattered on top at the end.  A piece in which more than one position in eight matches takes the
+ * full-vector route above instead (after the zero fill, so the two never write the same words at the same time).
+ */
+PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
+{
+    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
+    const size_t overlap = (size_t)c->fa.maxPatternLen;
+    const size_t piece = owned < kHostPiece ? owned : kHostPiece;
+    PFAC_status_t st = ensureHostStage(c, piece + overlap);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    correctTextureMode(c);
+    PFAC_reduce_kernel_protoType reduce = c->perfMode == PFAC_TIME_DRIVEN ? c->reduce_kernel_ptr : c->reduce_inplace_kernel_ptr;
+    hipStream_t up = static_cast<hipStream_t>(c->stageUp);
+
+    /* zero fill of the caller's vector, in parallel with everything below */
+    unsigned helpers = 0;
+    if (owned >= (size_t(4) << 20)) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        helpers = hw >= 64 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
+    }
+    std::vector<std::thread> fillers;
+    try {
+        for (unsigned t = 0; t < helpers; t++) {
+            const size_t lo = owned * t / helpers, hi = owned * (t + 1) / helpers;
+            fillers.emplace_back([=]() { std::memset(h_matched_result + lo, 0, (hi - lo) * sizeof(int)); });
+        }
+    } catch (const std::system_error &) { /* fewer helpers than planned: the rest is filled below */ }
+    const size_t filledByHelpers = fillers.empty() ? 0 : owned * fillers.size() / helpers;
+    auto joinAll = [&]() { for (std::thread &t : fillers) if (t.joinable()) t.join(); };
+
+    struct Found { size_t off; std::vector<int> pos, id; };
+    std::vector<Found> found;
+    std::vector<size_t> densePieces;
+    const size_t numPieces = (owned + piece - 1) / piece;
+    auto uploadPiece = [&](size_t i) -> bool {               /* into buffer i & 1, on the upload stream */
+        const size_t off = i * piece;
+        const size_t mine = owned - off < piece ? owned - off : piece;
+        const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
+        return hipMemcpyAsync(c->d_stageIn[i & 1], h_inputString + off, scanned, hipMemcpyHostToDevice, up) == hipSuccess &&
+               hipEventRecord(static_cast<hipEvent_t>(c->evUp[i & 1]), up) == hipSuccess;
+    };
+    try {
+        found.reserve(numPieces);
+        bool ok = uploadPiece(0);
+        for (size_t i = 0; i < numPieces && ok && st == PFAC_STATUS_SUCCESS; i++) {
+            const int b = (int)(i & 1);
+            const size_t off = i * piece;
+            const size_t mine = owned - off < piece ? owned - off : piece;
+            const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
+            /* the scan of piece i - 1 (synchronous, below) is over: its input buffer may take piece i + 1 */
+            if (i + 1 < numPieces) ok = uploadPiece(i + 1);
+            ok = ok && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
+            if (!ok) break;
+            int count = 0;
+            st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)scanned, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
+            if (st != PFAC_STATUS_SUCCESS) break;
+            if ((size_t)count > mine / 8) { densePieces.push_back(i); continue; }
+            Found f;
+            f.off = off;
+            f.pos.resize((size_t)count);
+            f.id.resize((size_t)count);
+            if (count && (hipMemcpy(f.pos.data(), c->d_stagePos[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(f.id.data(), c->d_stageOut[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)) {
+                ok = false;
+                break;
+            }
+            found.push_back(std::move(f));
+        }
+        if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
+    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+    if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
+    if (filledByHelpers < owned) std::memset(h_matched_result + filledByHelpers, 0, (owned - filledByHelpers) * sizeof(int));
+    joinAll();
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    for (const Found &f : found) {
+        const size_t mine = owned - f.off < piece ? owned - f.off : piece;
+        for (size_t k = 0; k < f.pos.size(); k++)
+            if ((size_t)f.pos[k] < mine) h_matched_result[f.off + (size_t)f.pos[k]] = f.id[k];   /* beyond: the next piece's (or nobody's) */
+    }
+    for (size_t i : densePieces) {
+        const size_t off = i * piece;
+        const size_t mine = owned - off < piece ? owned - off : piece;
+        st = matchHostFullVector(c, h_inputString + off, mine, readable - off, h_matched_result + off);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+    }
+    return PFAC_STATUS_SUCCESS;
 }
 
 } // namespace

@@ -164,6 +164,7 @@ struct PFAC_context {
      * buffers of hostStageChunk (+ overlap) positions, two copy streams, events; created on first use */
     char *d_stageIn[2] = {nullptr, nullptr};
     int *d_stageOut[2] = {nullptr, nullptr};
+    int *d_stagePos[2] = {nullptr, nullptr};  /* positions of the compacted results of a piece (PFAC_matchFromHost) */
     size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
     void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */
     void *evUp[2] = {nullptr, nullptr}, *evScan[2] = {nullptr, nullptr}, *evDown[2] = {nullptr, nullptr};   /* hipEvent_t */

@@ -115,6 +115,34 @@ def test_match_from_host_pieces_equal_oracle(workdir):
         o.close()
 
 
+def test_match_from_host_sparse_and_dense_pieces(workdir):
+    """PFAC_matchFromHost brings back compacted (position, id) pairs and fills the zeros on the host; a piece in which
+    more than one position in eight matches takes the full-vector route.  A 42 MiB stream whose first piece is
+    sparse and whose second piece ends in 8 MiB where every position matches, against the ORACLE; the result vector
+    starts out as garbage (every element must be written)."""
+    from oracle import binding as ob
+    pats = [b"a", b"aa", b"aaa", b"aaaa", b"ab", b"b" * 7, b"abc" * 5] + wl.snort_patterns(500)
+    pf = wl.write_pattern_file(os.path.join(workdir, "hostsparse.pat"), pats)
+    n = (42 << 20) + 77
+    data = wl.http_stream(n, wl.http_message_pool(pats[7:], pool_size=128, embed_fraction=0.3)).copy()
+    data[data == ord("a")] = ord("e")                              # keeps the text part sparse: no 1-byte hits
+    data[(34 << 20):] = ord("a")                                   # ... and the end of the second piece as dense as it gets
+    data[(33 << 20):(33 << 20) + 15] = np.frombuffer(b"abc" * 5, dtype=np.uint8)
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC)
+    try:
+        want = o.match(data, hashed=True, omp=True)
+        first, second = want[:32 << 20], want[32 << 20:]
+        assert 0 < np.count_nonzero(first) < first.size // 8 and np.count_nonzero(second) > second.size // 8
+        for trial in range(2):                                     # the second call reuses the staging buffers
+            got = np.full(n, -7, dtype=np.int32)
+            h.matchFromHost(data.ctypes.data, n, got.ctypes.data)
+            assert_same(got, want, f"matchFromHost, sparse + dense pieces, call {trial}")
+    finally:
+        h.destroy()
+        o.close()
+
+
 # ------------------------------------------------------------------------------------- hostile pattern sets
 
 def _timed_match(h, data, steps=5):

@@ -554,7 +554,9 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
             ok = ok && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
             if (!ok) break;
             int count = 0;
+            c->reduceUnordered = true;
             st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)scanned, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
+            c->reduceUnordered = false;
             if (st != PFAC_STATUS_SUCCESS) break;
             if ((size_t)count > mine / 8) { densePieces.push_back(i); continue; }
             Found f;

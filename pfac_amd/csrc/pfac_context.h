@@ -164,6 +164,7 @@ struct PFAC_context {
      * buffers of hostStageChunk (+ overlap) positions, two copy streams, events; created on first use */
     char *d_stageIn[2] = {nullptr, nullptr};
     int *d_stageOut[2] = {nullptr, nullptr};
+    bool reduceUnordered = false;             /* the compacted-output scan may leave its pairs in any order (set around the calls of PFAC_matchFromHost) */
     int *d_stagePos[2] = {nullptr, nullptr};  /* positions of the compacted results of a piece (PFAC_matchFromHost) */
     size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
     void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */

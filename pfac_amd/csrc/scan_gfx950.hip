@@ -1284,7 +1284,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         e = launchChained<true>(c, part, tex);
         if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        if (count > 1) {                                   /* order by position */
+        if (count > 1 && !c->reduceUnordered) {            /* order by position (PFAC_matchFromHost scatters the pairs: any order) */
             size_t tempBytes = 0;
             unsigned int *keysIn = reinterpret_cast<unsigned int *>(d_pos);
             unsigned int *nullKeys = nullptr;

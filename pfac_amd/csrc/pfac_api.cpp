@@ -45,9 +45,7 @@ void freeTables(PFAC_context *c)
     devFree(c->d_hashRow);
     devFree(c->d_hashVal);
     devFree(c->d_chainSlots);
-    devFree(c->d_rootSlots);
     std::vector<pfac::ChainSlot>().swap(c->h_chainSlots);
-    std::vector<pfac::ChainSlot>().swap(c->h_rootSlots);
     c->numChainSlots = 0;
     c->chainJumpLog2 = 0;
     c->numOfTableEntry = c->sizeOfTableEntry = c->sizeOfTableInBytes = 0;
@@ -119,20 +117,19 @@ PFAC_status_t upload(T *&dst, const T *src, size_t count)
 PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 {
     PFAC_status_t st = PFAC_STATUS_SUCCESS;
-    if (c->h_chainSlots.empty() || c->h_rootSlots.size() != (size_t)pfac::kCharSet) {
+    if (c->h_chainSlots.empty()) {
         if (c->perfMode == PFAC_SPACE_DRIVEN) {
-            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->h_rootSlots, c->chainJumpLog2);
+            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->chainJumpLog2);
         } else {
             std::vector<Int2> rowPtr, valPtr;
             st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
-            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->h_rootSlots, c->chainJumpLog2);
+            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->chainJumpLog2);
         }
         if (st != PFAC_STATUS_SUCCESS) return st;
     }
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
     c->numChainSlots = c->h_chainSlots.size();
     st = upload(c->d_chainSlots, c->h_chainSlots.data(), c->h_chainSlots.size());
-    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_rootSlots, c->h_rootSlots.data(), c->h_rootSlots.size());
     return st;
 }
 
@@ -834,7 +831,7 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 namespace {
 
 constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
-constexpr uint32_t kCompiledVersion = 3;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots */
+constexpr uint32_t kCompiledVersion = 4;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots */
 /* what the stored tables depend on besides the patterns: hash constants and slot layout */
 constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kGram4Mul * 3u) ^ (pfac::kGram4Mul2 * 5u) ^ (pfac::kFinal3Mul * 7u) ^
                                         ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;
@@ -844,7 +841,7 @@ struct CompiledHeader {
     uint64_t payloadBytes, payloadFnv1a;
 };
 enum Section : uint32_t { kSecFile = 1, kSecScalars, kSecPatOff, kSecPatLen, kSecSorted, kSecEdgeBegin, kSecEdgeCh, kSecEdgeNext,
-                          kSecFilter, kSecGram3, kSecGram4, kSecFinal3, kSecShort, kSecHashRow, kSecHashVal, kSecChain, kSecRoot, kSecInitialRow };
+                          kSecFilter, kSecGram3, kSecGram4, kSecFinal3, kSecShort, kSecHashRow, kSecHashVal, kSecChain, kSecRootUnused, kSecInitialRow };
 
 uint64_t fnv1a64(const unsigned char *p, size_t n)
 {
@@ -915,7 +912,6 @@ PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
             putSection(payload, kSecHashVal, c->h_hashVal.data(), c->h_hashVal.size());
         }
         putSection(payload, kSecChain, c->h_chainSlots.data(), c->h_chainSlots.size());
-        putSection(payload, kSecRoot, c->h_rootSlots.data(), c->h_rootSlots.size());
         putSection(payload, kSecInitialRow, c->h_initialRow.data(), c->h_initialRow.size());
         CompiledHeader h;
         std::memset(&h, 0, sizeof(h));
@@ -984,7 +980,6 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
             case kSecHashRow: ok = takeSection(p, bytes, c->h_hashRow); break;
             case kSecHashVal: ok = takeSection(p, bytes, c->h_hashVal); break;
             case kSecChain: ok = takeSection(p, bytes, c->h_chainSlots); break;
-            case kSecRoot: ok = takeSection(p, bytes, c->h_rootSlots); break;
             case kSecInitialRow: ok = takeSection(p, bytes, c->h_initialRow); break;
             default: break;                                    /* unknown section of a later writer: skipped */
             }
@@ -1004,7 +999,7 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
                  f.log2Bits >= 5 && f.log2Bits <= 19 && f.log2Bits4 >= 5 && f.log2Bits4 <= 17 && f.log2BitsF3 >= 5 && f.log2BitsF3 <= 16 &&
                  f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.gram4.size() == (size_t(1) << f.log2Bits4) / 32 &&
                  f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
-                 c->h_initialRow.size() == (size_t)pfac::kCharSet && c->h_rootSlots.size() == (size_t)pfac::kCharSet &&
+                 c->h_initialRow.size() == (size_t)pfac::kCharSet &&
                  h.jumpLog2 >= (uint32_t)pfac::kJumpLog2Min && h.jumpLog2 <= (uint32_t)pfac::kJumpLog2Max &&
                  c->h_chainSlots.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
                  (h.perfMode == PFAC_TIME_DRIVEN ||
@@ -1020,7 +1015,6 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
                 return sl.endRow >= 0 && (size_t)sl.endRow + sizeMask < slots;
             };
             for (size_t i = 0; ok && i < slots; i++) ok = slotOk(c->h_chainSlots[i]);
-            for (size_t i = 0; ok && i < c->h_rootSlots.size(); i++) ok = slotOk(c->h_rootSlots[i]);
         }
     } catch (const std::bad_alloc &) { freeResources(c); return PFAC_STATUS_ALLOC_FAILED; }
     if (!ok) { freeResources(c); return PFAC_STATUS_INVALID_PARAMETER; }

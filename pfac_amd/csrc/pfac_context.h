@@ -142,9 +142,8 @@ struct PFAC_context {
     pfac::Int2 *d_hashRow = nullptr;
     pfac::Int2 *d_hashVal = nullptr;
     int *d_initialRow = nullptr;
-    std::vector<pfac::ChainSlot> h_chainSlots, h_rootSlots;   /* host copies of the chained table (PFACX_saveCompiled)    */
+    std::vector<pfac::ChainSlot> h_chainSlots;               /* host copy of the chained table (PFACX_saveCompiled)       */
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
-    pfac::ChainSlot *d_rootSlots = nullptr;   /* the 256 transitions of the initial state, same encoding           */
     size_t numChainSlots = 0;
     int chainJumpLog2 = 0;                    /* the last 2^J slots of the chained table are the jump table, the 256 before them the
                                                  initial state's bucket (tables.cpp: buildChainedHashTable)                        */

@@ -545,10 +545,10 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t stFullRounds = 0, stSlotGathers = 0, stWinLoads = 0, stStartDead = 0;
 #endif
 
-    /* Reporting a finished walk.  Zero stores and walker loads of one wave complete in issue order (a
-     * single in-order vmcnt counter on gfx9-family hardware), and a walk that ends in consume() has just
-     * consumed loads issued behind its chunk's zero stores, so its patch lands on top of the zero.  A walk
-     * that ends in start() (resolved from LDS alone) drains this wave's stores first.
+    /* Reporting a finished walk.  With writer waves the zeros of a chunk are in L2 before the chunk is handed out.
+     * Without them (-DPFAC_WRITERS=0) zero stores and walker loads of one wave complete in issue order (a single
+     * in-order vmcnt counter on gfx9-family hardware), and a walk ends in consume(), where it has just consumed
+     * loads issued behind its chunk's zero stores, so its patch lands on top of the zero.
      * REDUCE: results are staged per wave in LDS and flushed with one atomic per kReduceCap pairs
      * (a single device counter saturates at ~90 increments/us; pattern-dense input has 10^5..10^6 matches) */
     uint32_t *rPos = sReduceAll + wave * (2 * kReduceCap);
@@ -559,13 +559,12 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) { pendMatch[s] = 0; pendPos[s] = 0; }
 
-    auto report = [&](bool ended, const WLane &w, int s, bool afterLoad) {
+    auto report = [&](bool ended, const WLane &w, int s) {
         if (ended & (w.match != 0)) {
             if (REDUCE) {                                  /* parked; stagePending() picks it up in uniform control flow */
                 pendMatch[s] = w.match;
                 pendPos[s] = w.pos;
             } else {
-                if (!afterLoad && !kWriters) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 a.out[w.pos] = w.match;
             }
         }
@@ -619,7 +618,7 @@ void pfac_scan_filter(ScanArgs a)
         for (int s = 0; s < kWalkSets; s++) {
             bool cont = false;
             if (alive[s]) cont = walk[s].consume(wctx);
-            report(alive[s] & !cont, walk[s], s, true);
+            report(alive[s] & !cont, walk[s], s);
             alive[s] = cont;
         }
         stagePending();
@@ -825,7 +824,7 @@ void pfac_scan_filter(ScanArgs a)
         PFAC_TICK(8);
         walkConsume();
         PFAC_TICK(0);
-        /* ---- 2. hand idle walker lanes new positions (first transition from LDS), start the next transition of
+        /* ---- 2. hand idle walker lanes new positions, start the next transition of
          *         every live walk */
         walkRefill();
         PFAC_TICK(1);

@@ -122,7 +122,6 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * keeps it in endRow (a leaf has no bucket); a final state with successors (a pattern that is a
  * prefix of another) keeps it in chain[4..7], and such a slot's chain is cut to <= 3 bytes (the cut
  * lands on a non-final chain state; the next slot carries on from there).
- * rootSlots is the same encoding for the 256 transitions of the initial state (kept in LDS).
  */
 static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next,
                                const unsigned char *forced = nullptr, int numForced = 0)
@@ -174,8 +173,7 @@ static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &row
  *                              walker falls back to the initial state's bucket.
  */
 PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2> &rowPtr,
-                                    const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots,
-                                    std::vector<ChainSlot> &rootSlots, int &jumpLog2)
+                                    const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots, int &jumpLog2)
 {
     for (const Int2 &r : rowPtr)
         if (r.x >= 0 && (((uint32_t)r.y >> 16) > 256u || ((uint32_t)r.y & 0xFFFFu) > 255u)) return PFAC_STATUS_INTERNAL_ERROR;
@@ -204,13 +202,11 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2>
         while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < 8 * prefixes.size()) jumpLog2++;
         const size_t rootRow = valPtr.size(), jumpBase = rootRow + kCharSet;
         slots.resize(jumpBase + (size_t(1) << jumpLog2));
-        rootSlots.resize(kCharSet);
         for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
-        for (int c = 0; c < kCharSet; c++) rootSlots[c] = makeChainSlot(fa, rowPtr, c, kTrapState);
-        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
-            rootSlots[fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
-        for (int c = 0; c < kCharSet; c++) slots[rootRow + c] = rootSlots[c];
         const ChainSlot empty = makeChainSlot(fa, rowPtr, 0, kTrapState);
+        for (int c = 0; c < kCharSet; c++) slots[rootRow + c] = empty;
+        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
+            slots[rootRow + fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
         for (size_t i = jumpBase; i < slots.size(); i++) slots[i] = empty;
         for (const Prefix &p : prefixes) {
             ChainSlot &dst = slots[jumpBase + jumpHash(p.key, jumpLog2)];

@@ -45,16 +45,20 @@ typedef struct {
     size_t sizeOfTableEntry;
     size_t sizeOfTableInBytes;
     /* prefilter (this implementation only; see DESIGN.md "filter") */
-    int filterLog2Bits;       /* 3-gram bitmap has 2^filterLog2Bits bits        */
+    int filterLog2Bits;       /* 3-gram bitmap has 2^filterLog2Bits bits (two per 3-gram, in one dword) */
     int filterHasShort;       /* 1 if some pattern is shorter than 3 bytes      */
     size_t filterBitsSet;     /* population of the 3-gram bitmap                */
     int kernelVariant;        /* PFACX_KERNEL_*                                 */
     int multiProcessorCount;
-    int filterLog2Bits4;      /* 4-gram bitmap has 2^filterLog2Bits4 bits        */
+    int filterLog2BitsLadder; /* prefix-ladder bitmap has 2^filterLog2BitsLadder bits (level 2 of the prefilter) */
     int filterLog2BitsFinal3; /* length-3-pattern bitmap                         */
-    size_t filterBitsSet4;
+    size_t filterBitsSetLadder;
     int chainJumpLog2;        /* PFACX_TABLE_CHAIN: log2 of its jump-table slots (0 until the table exists) */
     size_t chainSlots;        /* PFACX_TABLE_CHAIN: slots in total                                          */
+    size_t ladderStops;       /* prefix ladder: trie nodes inserted as "stop: walk from here" ...            */
+    size_t ladderGoOns;       /* ... and as "go on: test the next prefix length"                             */
+    int ladderThin;           /* nodes with at most this many patterns below them are stops ...             */
+    int ladderExtend;         /* ... this many levels further down                                          */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -68,7 +72,7 @@ typedef enum {
     PFACX_TABLE_INITIAL_ROW  = 3,  /* int[256], both modes                          */
     PFACX_TABLE_FILTER_GRAM3 = 4,  /* uint32[2^filterLog2Bits / 32]                 */
     PFACX_TABLE_FILTER_SHORT = 5,  /* uint32[2048] (65536 bits)                     */
-    PFACX_TABLE_FILTER_GRAM4 = 6,  /* uint32[2^filterLog2Bits4 / 32]                */
+    PFACX_TABLE_FILTER_LADDER = 6, /* uint32[2^filterLog2BitsLadder / 32]           */
     PFACX_TABLE_FILTER_FINAL3 = 7, /* uint32[2^filterLog2BitsFinal3 / 32]           */
     PFACX_TABLE_CHAIN        = 8   /* uint32[4] per slot: the device-only chained form of the hashed table that the
                                       filter kernel walks in both perf modes (slot i = reference hashValPtr[i]; then
@@ -109,10 +113,12 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
 typedef struct {
     unsigned long long walkerRounds;      /* wave-wide walker rounds (one table step for every live walk)      */
     unsigned long long laneSteps;         /* table steps taken, summed over lanes                              */
-    unsigned long long walksStarted;      /* positions that passed both filter levels and were walked          */
+    unsigned long long walksStarted;      /* positions that passed level 1 and the prefix ladder and were walked */
     unsigned long long level1Hits;        /* positions that passed filter level 1                              */
     int tilesPerChunk;                    /* KiB per chunk                                                     */
     int walksPerLane;                     /* independent walks per lane                                        */
+    unsigned long long ladderCandidates;  /* level-1 hits whose first four bytes are a pattern prefix (or a short
+                                             pattern): what the prefix ladder was asked about                  */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);

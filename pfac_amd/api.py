@@ -26,7 +26,7 @@ PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO = 0, 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
- PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_GRAM4, PFACX_TABLE_FILTER_FINAL3,
+ PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
 
 
@@ -59,14 +59,16 @@ class PFACX_info(C.Structure):
         ("numOfTableEntry", C.c_size_t), ("sizeOfTableEntry", C.c_size_t), ("sizeOfTableInBytes", C.c_size_t),
         ("filterLog2Bits", C.c_int), ("filterHasShort", C.c_int), ("filterBitsSet", C.c_size_t),
         ("kernelVariant", C.c_int), ("multiProcessorCount", C.c_int),
-        ("filterLog2Bits4", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSet4", C.c_size_t),
+        ("filterLog2BitsLadder", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSetLadder", C.c_size_t),
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
+        ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
     ]
 
 
 class PFACX_scan_stats(C.Structure):
     _fields_ = [("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
-                ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int)]
+                ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
+                ("ladderCandidates", C.c_ulonglong)]
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")

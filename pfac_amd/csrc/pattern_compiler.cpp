@@ -209,26 +209,68 @@ void buildInitialRow(const Automaton &fa, std::vector<int> &row)
 }
 
 /*
- * Prefilter bitmaps (this implementation only).
+ * Prefilter bitmaps (this implementation only; struct Filter in pfac_context.h has the contract).
  *
  * A start position j can report a non-zero pattern only if
  *   (a) a pattern of length 1 or 2 matches at j                -> shortBits (exact over c0,c1;
  *       a 1-byte pattern sets all 256 c1 slots of its c0)
  *   (b) the walk from j survives three transitions             -> gram3
- * because every match of length >= 3 passes through a depth-3 state; and, one level deeper, only if
+ * because every match of length >= 3 passes through a depth-3 state; and, deeper, only if
  *   (c) (a), or a pattern of length exactly 3 matches at j     -> final3
- *   (d) or the walk survives four transitions                  -> gram4.
- * The kernel tests (a)/(b) from LDS for every position and (c)/(d) for the survivors; only positions
- * that pass both are walked through the real table, so false positives cost time, never
- * correctness.  gram3 / gram4 / final3 are one-hash Bloom filters sized for <= ~1/64 density
- * within the LDS budget (gram3 1..64 KiB, gram4 1..16 KiB).
+ *   (d) or the walk reaches an S node of the prefix ladder through G nodes -> ladder.
+ * The kernel tests (b) from LDS for every position and (a)/(c)/(d) for the survivors; only positions
+ * that pass are walked through the real table, so false positives cost time, never correctness.
  */
 static int sizeLog2(size_t keys, int lo, int hi)
 {
     int lg = lo;
-    while (lg < hi && (size_t(1) << lg) < keys * 64) lg++;
+    while (lg < hi && (size_t(1) << lg) < keys * 128) lg++;
     return lg;
 }
+
+namespace {
+
+/* The ladder of one pattern set for a given "thin" threshold: visits every ladder node that a candidate can reach
+ * through G nodes, as S or G, with the rolling hash of its prefix. */
+struct LadderWalk {
+    const Automaton &fa;
+    const std::vector<uint32_t> &below;        /* patterns in the subtree of each state (itself included) */
+    uint32_t thin;
+    int extend = 0;                            /* thin nodes go on for this many more levels before they stop */
+    template <class Visit> void run(Visit &&visit) const
+    {
+        struct Item { int state; int depth; uint32_t acc; int ext; };   /* acc: bytes so far (depth < 4: the bytes; depth >= 4: rolling hash) */
+        std::vector<Item> stack;
+        stack.push_back({fa.initialState, 0, 0u, extend});
+        const int F = fa.numPatterns;
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.depth < kLadderFirst) {                     /* below the first level: every path, finals on the way included */
+                for (int e = fa.edgeBegin[it.state]; e < fa.edgeBegin[it.state + 1]; e++) {
+                    const uint32_t acc = it.acc | ((uint32_t)fa.edgeCh[e] << (8 * it.depth));
+                    stack.push_back({fa.edgeNext[e], it.depth + 1, it.depth + 1 == kLadderFirst ? ladderStart(acc) : acc, it.ext});
+                }
+                continue;
+            }
+            /* a ladder node */
+            bool endsSoon = it.state <= F || it.depth >= kLadderLast;
+            for (int e = fa.edgeBegin[it.state]; e < fa.edgeBegin[it.state + 1] && !endsSoon; e++) endsSoon = fa.edgeNext[e] <= F;
+            const bool isThin = below[it.state] <= thin;
+            const bool stop = endsSoon || (isThin && it.ext == 0);
+            visit(it.acc, it.depth, stop);
+            if (stop) continue;
+            for (int e1 = fa.edgeBegin[it.state]; e1 < fa.edgeBegin[it.state + 1]; e1++) {
+                const int s1 = fa.edgeNext[e1];
+                for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++)
+                    stack.push_back({fa.edgeNext[e2], it.depth + kLadderStep,
+                                     ladderRoll(it.acc, (uint32_t)fa.edgeCh[e1] | ((uint32_t)fa.edgeCh[e2] << 8)), isThin ? it.ext - 1 : it.ext});
+            }
+        }
+    }
+};
+
+} // namespace
 
 void buildFilter(const Automaton &fa, Filter &f)
 {
@@ -238,7 +280,7 @@ void buildFilter(const Automaton &fa, Filter &f)
     const int init = fa.initialState;
     auto fanout = [&](int s) { return (size_t)(fa.edgeBegin[s + 1] - fa.edgeBegin[s]); };
 
-    size_t depth3 = 0, depth4 = 0, len3 = 0;
+    size_t depth3 = 0, len3 = 0;
     bool anyShort = false;
     for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
         const int s1 = fa.edgeNext[e1];
@@ -247,33 +289,75 @@ void buildFilter(const Automaton &fa, Filter &f)
             const int s2 = fa.edgeNext[e2];
             anyShort |= s2 <= F;
             depth3 += fanout(s2);
-            for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
-                const int s3 = fa.edgeNext[e3];
-                depth4 += fanout(s3);
-                if (s3 <= F) len3++;
+            for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++)
+                if (fa.edgeNext[e3] <= F) len3++;
+        }
+    }
+    /* patterns below every state (a trie: children are reached from exactly one parent; post-order over an explicit stack) */
+    std::vector<uint32_t> below((size_t)fa.numStates, 0u);
+    if (fa.numStates > init) {
+        std::vector<std::pair<int, int>> stack;                /* state, next edge */
+        stack.emplace_back(init, fa.edgeBegin[init]);
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second < fa.edgeBegin[top.first + 1]) {
+                const int child = fa.edgeNext[top.second++];
+                stack.emplace_back(child, fa.edgeBegin[child]);
+            } else {
+                const int s = top.first;
+                below[s] += s <= F ? 1u : 0u;
+                stack.pop_back();
+                if (!stack.empty()) below[stack.back().first] += below[s];
             }
         }
     }
-    /* Level 1 is tested for every position and each false positive costs queue work (the kernel is bound
-     * by instruction issue): up to 64 KiB, <= 1/64 density.  Level 2 has two hashes and only costs a
-     * short walk when it errs: up to 16 KiB.  Everything lives in LDS next to 78 KiB of queues and
-     * tables (scan_gfx950.hip: filterLdsBytes), so the bitmaps share kFilterLdsBudget. */
-    f.log2Bits = sizeLog2(depth3, 13, 19);
-    f.log2Bits4 = sizeLog2(depth4, 13, 17);
-    f.log2BitsF3 = sizeLog2(len3, 10, 16);
+
+    /* Level 1 is tested for every position and each false positive costs list and ladder work: up to 32 KiB, two bits
+     * per 3-gram.  The ladder gets up to 64 KiB.  Everything lives in LDS next to the scanning waves' queues and
+     * stages (scan_gfx950.hip: filterLdsBytes), so the bitmaps share kFilterLdsBudget. */
+    f.log2Bits = sizeLog2(depth3, 13, 18);
+    f.log2BitsF3 = sizeLog2(len3, 10, 13);
+    f.log2BitsLad = 19;
     auto total = [&]() {
-        return ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2Bits4) + (size_t(1) << f.log2BitsF3)) / 8 + (anyShort ? 65536 / 8 : 0);
+        return ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (anyShort ? 65536 / 8 : 0);
     };
     while (total() > kFilterLdsBudget) {
-        if (f.log2Bits > 16) f.log2Bits--;
-        else if (f.log2BitsF3 > 13) f.log2BitsF3--;
-        else if (f.log2Bits4 > 13) f.log2Bits4--;
+        if (f.log2BitsLad > 17) f.log2BitsLad--;
+        else if (f.log2Bits > 16) f.log2Bits--;
+        else if (f.log2BitsLad > 13) f.log2BitsLad--;
         else break;
     }
+    /* The ladder.  Wanted: thin = 1 (every pattern's own path is followed until it is alone on it) and one more level
+     * behind a thin node; the bitmap may be a fifth full (S nodes set two bits, G nodes one or two).  If that does not
+     * fit: no extra level; then a larger "thin" threshold, i.e. fewer, shallower nodes.  Then the smallest bitmap
+     * that is still that sparse. */
+    const int ladCap = f.log2BitsLad;
+    const size_t dens = 5;
+    size_t stops = 0, goOns = 0;
+    auto count = [&](uint32_t thin, int ext) {
+        stops = goOns = 0;
+        LadderWalk{fa, below, thin, ext}.run([&](uint32_t, int, bool stop) { (stop ? stops : goOns)++; });
+        return dens * (2 * stops + goOns) <= (size_t(1) << ladCap);
+    };
+    f.ladderThin = 1;
+    f.ladderExtend = 1;
+    if (!count(1, f.ladderExtend)) {
+        f.ladderExtend = 0;
+        for (uint32_t thin = 1;; thin *= 2) {
+            f.ladderThin = (int)thin;
+            if (count(thin, 0) || thin >= (1u << 30)) break;
+        }
+    }
+    f.log2BitsLad = 13;
+    while (f.log2BitsLad < ladCap && dens * (2 * stops + goOns) > (size_t(1) << f.log2BitsLad)) f.log2BitsLad++;
+    f.ladderStops = stops;
+    f.ladderGoOns = goOns;
+
     f.gram3.assign((size_t(1) << f.log2Bits) / 32, 0);
-    f.gram4.assign((size_t(1) << f.log2Bits4) / 32, 0);
+    f.ladder.assign((size_t(1) << f.log2BitsLad) / 32, 0);
     f.final3.assign((size_t(1) << f.log2BitsF3) / 32, 0);
     auto setBit = [](std::vector<uint32_t> &v, uint32_t h) { v[h >> 5] |= 1u << (h & 31); };
+    auto setGram3 = [&](uint32_t key3) { f.gram3[gram3Word(key3, f.log2Bits)] |= (1u << gram3Bit1(key3)) | (1u << gram3Bit2(key3)); };
 
     for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
         const uint32_t c0 = fa.edgeCh[e1];
@@ -291,27 +375,33 @@ void buildFilter(const Automaton &fa, Filter &f)
             }
             for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
                 const uint32_t key3 = c0 | (c1 << 8) | ((uint32_t)fa.edgeCh[e3] << 16);
-                const int s3 = fa.edgeNext[e3];
-                setBit(f.gram3, gram3Hash(key3, f.log2Bits));
-                if (s3 <= F) setBit(f.final3, final3Hash(key3, f.log2BitsF3));   /* 3-byte pattern */
-                for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++) {
-                    const uint32_t key4 = key3 | ((uint32_t)fa.edgeCh[e4] << 24);
-                    setBit(f.gram4, gram4Hash(key4, f.log2Bits4));
-                    setBit(f.gram4, gram4Hash2(key4, f.log2Bits4));
+                setGram3(key3);
+                if (fa.edgeNext[e3] <= F) {                                         /* 3-byte pattern */
+                    setBit(f.final3, final3Hash(key3, f.log2BitsF3));
+                    setBit(f.final3, final3Hash2(key3, f.log2BitsF3));
                 }
             }
         }
     }
+    LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend}.run([&](uint32_t h, int depth, bool stop) {
+        if (stop) {
+            setBit(f.ladder, ladderBitS1(h, f.log2BitsLad));
+            setBit(f.ladder, ladderBitS2(h, f.log2BitsLad));
+        } else {
+            setBit(f.ladder, ladderBitG(h, f.log2BitsLad));
+            if (depth == kLadderFirst) setBit(f.ladder, ladderBitG2(h, f.log2BitsLad));
+        }
+    });
     /* Level 1 tests ONE bitmap per position: a pattern of one or two bytes matches whatever follows it, so all
      * 256 (or 65536) 3-grams that begin with it pass.  (The 2-byte bitmap is still tested at level 2, which
      * sorts out the positions this lets through.) */
     if (f.hasShort)
         for (uint32_t key2 = 0; key2 < 65536; key2++)
             if ((f.shortBits[key2 >> 5] >> (key2 & 31)) & 1u)
-                for (uint32_t c2 = 0; c2 < 256; c2++) setBit(f.gram3, gram3Hash(key2 | (c2 << 16), f.log2Bits));
-    f.bitsSet = f.bitsSet4 = 0;
+                for (uint32_t c2 = 0; c2 < 256; c2++) setGram3(key2 | (c2 << 16));
+    f.bitsSet = f.bitsSetLad = 0;
     for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
-    for (uint32_t w : f.gram4) f.bitsSet4 += (size_t)__builtin_popcount(w);
+    for (uint32_t w : f.ladder) f.bitsSetLad += (size_t)__builtin_popcount(w);
 }
 
 } // namespace pfac

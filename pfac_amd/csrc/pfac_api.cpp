@@ -76,7 +76,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_initialRow);
     devFree(c->d_gram3);
     devFree(c->d_shortBits);
-    devFree(c->d_gram4);
+    devFree(c->d_ladder);
     devFree(c->d_reduceCount);
     devFree(c->d_workCounters);
     devFree(c->d_reduceScratch);
@@ -110,21 +110,14 @@ PFAC_status_t upload(T *&dst, const T *src, size_t count)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* Build (unless a compiled file brought it along) and upload the chained device form of the hashed table
- * (tables.cpp: buildChainedHashTable): what the scan kernel walks in BOTH perf modes.  In PFAC_TIME_DRIVEN mode
- * the hashed layout it derives from is built here and dropped again: the handle's reference-layout table
- * (PFACX_getTable, the dump, the simple kernel) stays dense. */
+/* Build (unless a compiled file brought it along) and upload the chained device table (tables.cpp:
+ * buildChainedHashTable): what the scan kernel walks in BOTH perf modes.  It is built from the trie; the handle's
+ * reference-layout table (PFACX_getTable, the dump, the simple kernel) is dense or hashed as the perf mode says. */
 PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 {
     PFAC_status_t st = PFAC_STATUS_SUCCESS;
     if (c->h_chainSlots.empty()) {
-        if (c->perfMode == PFAC_SPACE_DRIVEN) {
-            st = pfac::buildChainedHashTable(c->fa, c->h_hashRow, c->h_hashVal, c->h_chainSlots, c->chainJumpLog2);
-        } else {
-            std::vector<Int2> rowPtr, valPtr;
-            st = pfac::buildHashTable(c->fa, rowPtr, valPtr);
-            if (st == PFAC_STATUS_SUCCESS) st = pfac::buildChainedHashTable(c->fa, rowPtr, valPtr, c->h_chainSlots, c->chainJumpLog2);
-        }
+        st = pfac::buildChainedHashTable(c->fa, c->h_chainSlots, c->chainJumpLog2);
         if (st != PFAC_STATUS_SUCCESS) return st;
     }
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
@@ -189,7 +182,7 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
     PFAC_status_t st = upload(c->d_initialRow, c->h_initialRow.data(), c->h_initialRow.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram3, c->filter.gram3.data(), c->filter.gram3.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
-    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram4, c->filter.gram4.data(), c->filter.gram4.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_ladder, c->filter.ladder.data(), c->filter.ladder.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
     const unsigned int zero = 0;
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_reduceCount, &zero, 1);
@@ -778,9 +771,13 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
     info->filterHasShort = handle->filter.hasShort ? 1 : 0;
     info->filterBitsSet = handle->filter.bitsSet;
     info->kernelVariant = handle->kernelVariant;
-    info->filterLog2Bits4 = handle->filter.log2Bits4;
+    info->filterLog2BitsLadder = handle->filter.log2BitsLad;
     info->filterLog2BitsFinal3 = handle->filter.log2BitsF3;
-    info->filterBitsSet4 = handle->filter.bitsSet4;
+    info->filterBitsSetLadder = handle->filter.bitsSetLad;
+    info->ladderStops = handle->filter.ladderStops;
+    info->ladderGoOns = handle->filter.ladderGoOns;
+    info->ladderThin = handle->filter.ladderThin;
+    info->ladderExtend = handle->filter.ladderExtend;
     info->chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
     info->chainSlots = handle->h_chainSlots.size();
     info->multiProcessorCount = handle->multiProcessorCount;
@@ -806,8 +803,8 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.gram3.data(); *bytes = handle->filter.gram3.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_SHORT:
         *ptr = handle->filter.shortBits.data(); *bytes = handle->filter.shortBits.size() * sizeof(uint32_t); break;
-    case PFACX_TABLE_FILTER_GRAM4:
-        *ptr = handle->filter.gram4.data(); *bytes = handle->filter.gram4.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_LADDER:
+        *ptr = handle->filter.ladder.data(); *bytes = handle->filter.ladder.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_FINAL3:
         *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
@@ -831,9 +828,11 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 namespace {
 
 constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
-constexpr uint32_t kCompiledVersion = 4;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots */
+constexpr uint32_t kCompiledVersion = 6;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots;
+                                                     5: the prefix ladder replaces the 4-gram bitmap, the chained table has its own compact breadth-first layout */
 /* what the stored tables depend on besides the patterns: hash constants and slot layout */
-constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kGram4Mul * 3u) ^ (pfac::kGram4Mul2 * 5u) ^ (pfac::kFinal3Mul * 7u) ^
+constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kLadMul0 * 3u) ^ (pfac::kLadMul * 5u) ^ (pfac::kLadMulS * 11u) ^ (pfac::kLadMulG * 13u) ^ (pfac::kLadMulG2 * 17u) ^ (pfac::kFinal3Mul * 7u) ^ (pfac::kFinal3Mul2 * 19u) ^
+                                        ((uint32_t)pfac::kLadderLevels << 12) ^
                                         ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;
 struct CompiledHeader {
     char magic[8];
@@ -841,7 +840,7 @@ struct CompiledHeader {
     uint64_t payloadBytes, payloadFnv1a;
 };
 enum Section : uint32_t { kSecFile = 1, kSecScalars, kSecPatOff, kSecPatLen, kSecSorted, kSecEdgeBegin, kSecEdgeCh, kSecEdgeNext,
-                          kSecFilter, kSecGram3, kSecGram4, kSecFinal3, kSecShort, kSecHashRow, kSecHashVal, kSecChain, kSecRootUnused, kSecInitialRow };
+                          kSecFilter, kSecGram3, kSecLadder, kSecFinal3, kSecShort, kSecHashRow, kSecHashVal, kSecChain, kSecRootUnused, kSecInitialRow };
 
 uint64_t fnv1a64(const unsigned char *p, size_t n)
 {
@@ -901,10 +900,11 @@ PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
         putSection(payload, kSecEdgeBegin, fa.edgeBegin.data(), fa.edgeBegin.size());
         putSection(payload, kSecEdgeCh, fa.edgeCh.data(), fa.edgeCh.size());
         putSection(payload, kSecEdgeNext, fa.edgeNext.data(), fa.edgeNext.size());
-        const uint64_t filt[6] = {(uint64_t)f.log2Bits, (uint64_t)f.log2Bits4, (uint64_t)f.log2BitsF3, f.hasShort ? 1u : 0u, f.bitsSet, f.bitsSet4};
-        putSection(payload, kSecFilter, filt, 6);
+        const uint64_t filt[10] = {(uint64_t)f.log2Bits, (uint64_t)f.log2BitsLad, (uint64_t)f.log2BitsF3, f.hasShort ? 1u : 0u, f.bitsSet, f.bitsSetLad,
+                                  f.ladderStops, f.ladderGoOns, (uint64_t)f.ladderThin, (uint64_t)f.ladderExtend};
+        putSection(payload, kSecFilter, filt, 10);
         putSection(payload, kSecGram3, f.gram3.data(), f.gram3.size());
-        putSection(payload, kSecGram4, f.gram4.data(), f.gram4.size());
+        putSection(payload, kSecLadder, f.ladder.data(), f.ladder.size());
         putSection(payload, kSecFinal3, f.final3.data(), f.final3.size());
         putSection(payload, kSecShort, f.shortBits.data(), f.shortBits.size());
         if (c->perfMode == PFAC_SPACE_DRIVEN) {
@@ -974,7 +974,7 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
             case kSecEdgeNext: ok = takeSection(p, bytes, fa.edgeNext); break;
             case kSecFilter: ok = takeSection(p, bytes, filt); break;
             case kSecGram3: ok = takeSection(p, bytes, f.gram3); break;
-            case kSecGram4: ok = takeSection(p, bytes, f.gram4); break;
+            case kSecLadder: ok = takeSection(p, bytes, f.ladder); break;
             case kSecFinal3: ok = takeSection(p, bytes, f.final3); break;
             case kSecShort: ok = takeSection(p, bytes, f.shortBits); break;
             case kSecHashRow: ok = takeSection(p, bytes, c->h_hashRow); break;
@@ -985,25 +985,26 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
             }
             at += (size_t)bytes;
         }
-        ok = ok && scalars.size() == 5 && filt.size() == 6;
+        ok = ok && scalars.size() == 5 && filt.size() == 10;
         if (ok) {
             fa.numPatterns = scalars[0]; fa.maxPatternLen = scalars[1]; fa.initialState = scalars[2];
             fa.numStates = scalars[3]; fa.numLeaves = scalars[4];
-            f.log2Bits = (int)filt[0]; f.log2Bits4 = (int)filt[1]; f.log2BitsF3 = (int)filt[2]; f.hasShort = filt[3] != 0;
-            f.bitsSet = (size_t)filt[4]; f.bitsSet4 = (size_t)filt[5];
+            f.log2Bits = (int)filt[0]; f.log2BitsLad = (int)filt[1]; f.log2BitsF3 = (int)filt[2]; f.hasShort = filt[3] != 0;
+            f.bitsSet = (size_t)filt[4]; f.bitsSetLad = (size_t)filt[5];
+            f.ladderStops = (size_t)filt[6]; f.ladderGoOns = (size_t)filt[7]; f.ladderThin = (int)filt[8]; f.ladderExtend = (int)filt[9];
             const size_t S = (size_t)(fa.numStates > 0 ? fa.numStates : 0), F = (size_t)(fa.numPatterns >= 0 ? fa.numPatterns : 0);
             ok = fa.numStates > 0 && fa.numPatterns >= 0 && fa.initialState == fa.numPatterns + 1 && (size_t)fa.initialState < S &&
                  fa.patternOff.size() == F + 1 && fa.patternLen.size() == F + 1 && fa.sortedId.size() == F &&
                  fa.edgeBegin.size() == S + 1 && fa.edgeCh.size() == fa.edgeNext.size() && !fa.edgeBegin.empty() &&
                  (size_t)fa.edgeBegin.back() == fa.edgeCh.size() &&
-                 f.log2Bits >= 5 && f.log2Bits <= 19 && f.log2Bits4 >= 5 && f.log2Bits4 <= 17 && f.log2BitsF3 >= 5 && f.log2BitsF3 <= 16 &&
-                 f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.gram4.size() == (size_t(1) << f.log2Bits4) / 32 &&
+                 f.log2Bits >= 13 && f.log2Bits <= 18 && f.log2BitsLad >= 13 && f.log2BitsLad <= 19 && f.log2BitsF3 >= 10 && f.log2BitsF3 <= 13 &&
+                 ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 8192u : 0u) <= pfac::kFilterLdsBudget &&
+                 f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.ladder.size() == (size_t(1) << f.log2BitsLad) / 32 &&
                  f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
                  c->h_initialRow.size() == (size_t)pfac::kCharSet &&
                  h.jumpLog2 >= (uint32_t)pfac::kJumpLog2Min && h.jumpLog2 <= (uint32_t)pfac::kJumpLog2Max &&
                  c->h_chainSlots.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
-                 (h.perfMode == PFAC_TIME_DRIVEN ||
-                  (c->h_hashRow.size() == S && c->h_hashVal.size() + pfac::kCharSet + (size_t(1) << h.jumpLog2) == c->h_chainSlots.size()));
+                 (h.perfMode == PFAC_TIME_DRIVEN || c->h_hashRow.size() == S);
             if (ok) c->chainJumpLog2 = (int)h.jumpLog2;
             for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0;
             for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S;
@@ -1037,6 +1038,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
         hipMemcpy(v, handle->d_workCounters + pfac::kStatsWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;
     stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
+    stats->ladderCandidates = v[5];
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = PFAC_WALK_SETS;
     return PFAC_STATUS_SUCCESS;

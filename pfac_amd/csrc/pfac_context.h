@@ -37,7 +37,7 @@ struct Int2 { int x, y; };                    /* device layout of the hashed tab
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
 constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
-constexpr int kStatsCount = 5;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned */
+constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
 constexpr double kAutoDenseHitRate = 0.6;     /* PFACX_KERNEL_AUTO: above this level-1 hit rate the simple kernel is the faster one */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS
@@ -55,7 +55,8 @@ struct ChainSlot {
     unsigned char chain[8];                   /* chain bytes, zero padded; if the end state is final and
                                                  has successors: <= 3 chain bytes, pattern ID in [4..7]  */
 };
-constexpr size_t kFilterLdsBudget = 82 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp) */
+constexpr size_t kFilterLdsBudget = 97 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp); the rest of the
+                                                    CU's 160 KiB is the scanning waves' queues and stages (scan_gfx950.hip checks the sum) */
 constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state                         */
 constexpr uint32_t kSlotLeaf = 1u << 13;      /* the end state has no outgoing transition               */
 constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */
@@ -78,49 +79,66 @@ struct Automaton {
     std::vector<int> edgeNext;
 };
 
-/* Two-level prefilter (DESIGN.md "filter").  Level 1, tested for every input position: a start
- * position can only produce a non-zero result if its first three bytes hit gram3, or -- when
- * patterns shorter than 3 bytes exist -- its first two bytes hit shortBits.  Level 2, tested only
- * for the survivors just before they would touch the transition table: the first four bytes must
- * hit gram4, or the first three must hit final3 (a pattern of length exactly 3), or shortBits.
- * All bitmaps are supersets of the exact sets, so a miss proves the result is 0. */
+/* Prefilter.  Level 1, tested for every input position: a start position can only produce a
+ * non-zero result if its first three bytes hit gram3 (patterns of one or two bytes are folded into it).  Level 2,
+ * tested only for the survivors just before they would touch the transition table, is a LADDER of prefix tests over
+ * the 20 bytes a candidate brings along: prefix lengths 4, 6, ..., 20.  A trie node at one of these depths is either
+ *   S ("stop": walk the table from here) -- a pattern ends at this depth or the next, or at most ladderThin patterns
+ *      lie below it, or it is the last level; or
+ *   G ("go on": test the next level)      -- everything else; only these have their descendants in the ladder.
+ * Both kinds live in ONE Bloom bitmap keyed by a rolling hash of the prefix: S nodes set two bits, G nodes one (two
+ * at depth 4, where the test decides which level-1 hits become candidates at all).  A candidate walks the levels until it hits an S node (-> walk), or neither kind (-> its result is 0).
+ * Patterns shorter than 4 bytes bypass the ladder: final3 (length exactly 3) and shortBits (length 1-2).
+ * All bitmaps are supersets of the exact sets, so a miss proves the result is 0 (a false positive costs a walk or one
+ * more level, never correctness: a matching pattern's nodes are S or G at every level up to its first S node). */
 struct Filter {
     int log2Bits = 13;                        /* gram3  */
-    int log2Bits4 = 13;                       /* gram4  */
+    int log2BitsLad = 13;                     /* ladder */
     int log2BitsF3 = 10;                      /* final3 */
     bool hasShort = false;
     size_t bitsSet = 0;                       /* population of gram3 */
-    size_t bitsSet4 = 0;
+    size_t bitsSetLad = 0;                    /* population of the ladder bitmap */
+    size_t ladderStops = 0, ladderGoOns = 0;  /* S and G nodes inserted */
+    int ladderThin = 1;                       /* nodes with at most this many patterns below them are S (raised until the bitmap is sparse enough) */
+    int ladderExtend = 0;                     /* ... after this many more levels (0: at once): the deeper test spares the walk of a candidate that
+                                                 shares a pattern's prefix up to the thin node and no further */
     std::vector<uint32_t> gram3;              /* 2^log2Bits bits, key c0|c1<<8|c2<<16            */
-    std::vector<uint32_t> gram4;              /* 2^log2Bits4 bits, key c0|c1<<8|c2<<16|c3<<24    */
+    std::vector<uint32_t> ladder;             /* 2^log2BitsLad bits                              */
     std::vector<uint32_t> final3;             /* 2^log2BitsF3 bits, 3-byte patterns              */
     std::vector<uint32_t> shortBits;          /* 65536 bits, index c0 | c1<<8                    */
 };
 
+/* the ladder's hash: h(4) = (first four bytes, little endian) * kLadMul0; h(d) = (h(d-2) ^ (bytes d-2, d-1 as a 16-bit
+ * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
+ * bit), of h * kLadMulG (G) and, at depth 4 only, of h * kLadMulG2 (G, second bit).  scan_gfx950.hip evaluates exactly this. */
+constexpr int kLadderFirst = 4, kLadderStep = 2, kLadderLast = 20;
+constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
+constexpr uint32_t kLadMul0 = 0x9E3779B1u, kLadMul = 0x85EBCA77u, kLadMulS = 0xC2B2AE3Du, kLadMulG = 0x27D4EB2Fu, kLadMulG2 = 0x165667B1u;
+inline uint32_t ladderStart(uint32_t first4) { return first4 * kLadMul0; }
+inline uint32_t ladderRoll(uint32_t h, uint32_t piece16) { return (h ^ piece16) * kLadMul; }
+inline uint32_t ladderBitS1(uint32_t h, int log2Bits) { return h >> (32 - log2Bits); }
+inline uint32_t ladderBitS2(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulS) >> (32 - log2Bits); }
+inline uint32_t ladderBitG(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulG) >> (32 - log2Bits); }
+inline uint32_t ladderBitG2(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulG2) >> (32 - log2Bits); }
+
 constexpr uint32_t kGram3Mul = 0x8B92C5u;     /* 24-bit odd multiplier of the 3-gram hash, picked by scanning 160
                                                  candidates for the lowest false-positive rate on the text, binary
                                                  and near-miss streams */
-/* Bit of the level-1 bitmap that stands for a 3-gram: the dword comes from the top bits of the 24 x 24 -> 32 bit
- * product, the bit inside the dword from the low five bits of the first byte -- the kernel gets the dword address
- * with a shift and an AND and the bit with the implicit mod-32 of a shift by the gram itself (scan_gfx950.hip). */
-inline uint32_t gram3Hash(uint32_t key24, int log2Bits)
-{
-    return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits)) << 5 | (key24 & 31u);
-}
-constexpr uint32_t kGram4Mul = 0x9E3779B1u;   /* 32-bit odd multiplier of the 4-gram hash */
+/* Level 1 is a BLOCKED two-bit Bloom filter: a 3-gram owns two bits of ONE dword, so a position costs the kernel one
+ * LDS read (a one-bit filter of twice the size lets slightly fewer positions through, 4.8 % instead of 5.1 % of the
+ * Snort-style stream, and leaves the prefix ladder half the LDS).  The dword comes from the top bits of the 24 x 24 ->
+ * 32 bit product, the first bit from the low five bits of the first byte, the second from those of the second byte --
+ * the kernel gets the dword address with a shift and an AND and the bits with the implicit mod-32 of a shift by the
+ * gram itself and by the gram >> 8 (scan_gfx950.hip). */
+inline uint32_t gram3Word(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits); }
+inline uint32_t gram3Bit1(uint32_t key24) { return key24 & 31u; }
+inline uint32_t gram3Bit2(uint32_t key24) { return (key24 >> 8) & 31u; }
 constexpr uint32_t kJumpMul = 0x9E3779B1u;    /* jump table of the chained walker (tables.cpp): slot of a 4-byte prefix */
 constexpr int kJumpLog2Min = 10, kJumpLog2Max = 20;
 inline uint32_t jumpHash(uint32_t key32, int log2Slots) { return (uint32_t)(key32 * kJumpMul) >> (32 - log2Slots); }
-constexpr uint32_t kFinal3Mul = 0x85EBCBu;    /* 24-bit odd multiplier of the length-3 hash */
-inline uint32_t gram4Hash(uint32_t key32, int log2Bits) { return (uint32_t)(key32 * kGram4Mul) >> (32 - log2Bits); }
-/* level 2 is a two-hash Bloom filter: it runs for a few positions per hundred, 64 at a time, so the
- * second lookup is free, and at the bench set's 9 % density it cuts the false walks 5x */
-constexpr uint32_t kGram4Mul2 = 0x85EBCA77u;
-inline uint32_t gram4Hash2(uint32_t key32, int log2Bits) { return (uint32_t)(key32 * kGram4Mul2) >> (32 - log2Bits); }
-inline uint32_t final3Hash(uint32_t key24, int log2Bits)
-{
-    return (uint32_t)((key24 & 0xFFFFFFu) * kFinal3Mul) >> (32 - log2Bits);
-}
+constexpr uint32_t kFinal3Mul = 0x85EBCBu, kFinal3Mul2 = 0xB5297Bu;    /* 24-bit odd multipliers of the two length-3 hashes */
+inline uint32_t final3Hash(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kFinal3Mul) >> (32 - log2Bits); }
+inline uint32_t final3Hash2(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kFinal3Mul2) >> (32 - log2Bits); }
 
 } // namespace pfac
 
@@ -149,7 +167,7 @@ struct PFAC_context {
                                                  initial state's bucket (tables.cpp: buildChainedHashTable)                        */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
-    uint32_t *d_gram4 = nullptr;
+    uint32_t *d_ladder = nullptr;
     unsigned int *d_reduceCount = nullptr;    /* device counter of the compacted-output path */
     /* grow-only scratch of the compacted-output path (sort buffers), owned by the handle so that a
      * call does not pay for hipMalloc/hipFree */

@@ -19,8 +19,7 @@ PFAC_status_t buildDenseTable(const Automaton &fa, std::vector<int> &dense);
 PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
                              std::vector<Int2> &valPtr);
 
-PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2> &rowPtr,
-                                    const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots, int &jumpLog2);
+PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2);
 
 /* cpu_engine.cpp: PFAC_PLATFORM_CPU / PFAC_PLATFORM_CPU_OMP */
 PFAC_status_t matchOnCpu(const PFAC_context *ctx, const unsigned char *in, size_t n, int *out,

@@ -95,8 +95,11 @@ constexpr int kTrap = pfac::kTrapState;
 #ifndef PFAC_MIN_WAVES_PER_SIMD
 #define PFAC_MIN_WAVES_PER_SIMD 1                    /* HIP: second __launch_bounds__ argument = minimum waves per SIMD */
 #endif
+#ifndef PFAC_SLOT_AUX
+#define PFAC_SLOT_AUX 0                         /* cache policy of the walkers' slot loads (buffer path): 1 = sc0, 2 = nt, 16 = sc1 */
+#endif
 #ifndef PFAC_QUEUE_CAP
-#define PFAC_QUEUE_CAP 128
+#define PFAC_QUEUE_CAP 64
 #endif
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
@@ -121,10 +124,10 @@ struct ScanArgs {
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
     const int *initialRow;
     const uint32_t *gram3;
-    const uint32_t *gram4;
+    const uint32_t *ladder;
     const uint32_t *final3;
     const uint32_t *shortBits;
-    int log2Bits, log2Bits4, log2BitsF3;
+    int log2Bits, log2BitsLad, log2BitsF3;
     int numFinal;
     int initialState;
     unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
@@ -217,8 +220,8 @@ __device__ __forceinline__ uint32_t testBit(const uint32_t *bitmap, uint32_t h) 
 
 /* LDS view of one block */
 struct Lds {
-    const uint32_t *gram3, *gram4, *final3, *shortBits;
-    uint32_t shift3, shift4, shiftF3;
+    const uint32_t *gram3, *ladder, *final3, *shortBits;
+    uint32_t shift3, shiftLad, shiftF3;
 };
 
 /* 16 input bytes from the 4-byte aligned address at or below byte `pos`.  No bound: the launcher only
@@ -348,8 +351,12 @@ template <bool TEX> struct ChainLane {
     __device__ __forceinline__ void issue(const Ctx &c)
     {
         if (needSlot) {
+#if defined(PFAC_EXP_CONFINE)           /* timing experiment: every slot load inside one window of the table; results are wrong */
+            const uint32_t idx = (row + chainHashSlot(ks, b0)) & (PFAC_EXP_CONFINE - 1u);
+#else
             const uint32_t idx = row + chainHashSlot(ks, b0);
-            if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+#endif
+            if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, PFAC_SLOT_AUX);
             else t = c.slots[idx];
         }
         if (needWin) {                                         /* rare: the walk is more than 20 bytes deep */
@@ -403,6 +410,9 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
                                                 * a refill costs the whole wave ~40 instructions however few lanes it fills
                                                 * (C5 1.94 -> 1.82 ms, C3 -1 %; profiles/r02_ab_refill.txt) */
 #endif
+#ifndef PFAC_REFILL_BATCH
+#define PFAC_REFILL_BATCH 1                    /* ... and only when at least this many entries are queued (or the wave has no more chunks to filter) */
+#endif
 #ifndef PFAC_TIMING
 #define PFAC_TIMING 0
 #endif
@@ -410,9 +420,13 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #define PFAC_LIST_CAP 128
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
-constexpr uint32_t kReduceCap = 64;           /* (position, id) pairs staged per wave in the REDUCE variant: one ballot can add 64 */
+#ifndef PFAC_PATCH_STAGED
+#define PFAC_PATCH_STAGED 0                    /* full-result kernel: 1 = finished matches are staged per wave in LDS and stored kReduceCap at a time */
+#endif
+constexpr bool kStagedPatch = PFAC_PATCH_STAGED != 0;
+constexpr uint32_t kReduceCap = 16;           /* (position, id) pairs staged per wave in the REDUCE variant (a ballot with more goes out directly) */
 constexpr int kReduceScanners = kWavesPerBlock;       /* ... and no writer waves: every wave scans, with half the walk queue each (LDS) */
-constexpr uint32_t kReduceQueueCap = kQueueCap > 64 ? kQueueCap / 2 : kQueueCap;
+constexpr uint32_t kReduceQueueCap = kQueueCap;
 /* In-order hand-out of the input: -1 = the input is cut into kWorkParts contiguous parts, one
  * counter each; G >= 0 = one moving front: granules of 2^G pieces are dealt round-robin to the parts, so
  * all parts work inside one window of parts << G pieces that sweeps the input once. */
@@ -484,10 +498,10 @@ void pfac_scan_filter(ScanArgs a)
     using WCtx = ChainCtx<TEX>;
     using WLane = ChainLane<TEX>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int words3 = 1 << (a.log2Bits - 5), words4 = 1 << (a.log2Bits4 - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
+    const int words3 = 1 << (a.log2Bits - 5), wordsLad = 1 << (a.log2BitsLad - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *sGram4 = sGram3 + words3;
-    uint32_t *sFinal3 = sGram4 + words4;
+    uint32_t *sLadder = sGram3 + words3;
+    uint32_t *sFinal3 = sLadder + wordsLad;
     uint32_t *sShort = sFinal3 + wordsF3;
     constexpr int kWriters = REDUCE ? 0 : PFAC_WRITERS;             /* the compacted-output variant has no zeros to write */
     constexpr int kScanners = REDUCE ? kReduceScanners : kWavesPerBlock - kWriters;
@@ -508,7 +522,7 @@ void pfac_scan_filter(ScanArgs a)
             for (int i = tid; i < words / 4; i += kBlockThreads) s[i] = g[i];
         };
         copy16(sGram3, a.gram3, words3);
-        copy16(sGram4, a.gram4, words4);
+        copy16(sLadder, a.ladder, wordsLad);
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
@@ -526,8 +540,8 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t *stage = sStageAll + wave * kStageWords;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
-    const Lds lds{sGram3, sGram4, sFinal3, sShort,
-                  35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2Bits4, 32u - (uint32_t)a.log2BitsF3};
+    const Lds lds{sGram3, sLadder, sFinal3, sShort,
+                  35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2BitsLad, 32u - (uint32_t)a.log2BitsF3};
     const WCtx wctx(a);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
@@ -540,7 +554,7 @@ void pfac_scan_filter(ScanArgs a)
     /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     /* always-on counters of this wave (scalar adds), summed into a.work[kStatsWord..] at kernel end */
-    uint32_t stRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0;
+    uint32_t stRounds = 0, stLaneSteps = 0, stStarts = 0, stHits = 0, stCand = 0;
 #if PFAC_STATS
     uint32_t stFullRounds = 0, stSlotGathers = 0, stWinLoads = 0, stStartDead = 0;
 #endif
@@ -561,11 +575,17 @@ void pfac_scan_filter(ScanArgs a)
 
     auto report = [&](bool ended, const WLane &w, int s) {
         if (ended & (w.match != 0)) {
-            if (REDUCE) {                                  /* parked; stagePending() picks it up in uniform control flow */
+            if (REDUCE || kStagedPatch) {                  /* parked; stagePending() picks it up in uniform control flow */
                 pendMatch[s] = w.match;
                 pendPos[s] = w.pos;
             } else {
+#if defined(PFAC_EXP_PATCH_LOCAL)       /* timing experiment: the patch stores land in one small window of the result vector; results are wrong */
+                a.out[w.pos & 0xFFFFFu] = w.match;
+#elif defined(PFAC_EXP_PATCH_NT)
+                __builtin_nontemporal_store(w.match, &a.out[w.pos]);
+#elif !defined(PFAC_EXP_NOSTORE)        /* timing experiment (tools/ab.py): walks without the patch store; results are wrong */
                 a.out[w.pos] = w.match;
+#endif
             }
         }
     };
@@ -573,18 +593,22 @@ void pfac_scan_filter(ScanArgs a)
         if (rn == 0) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(a.reduceCount, rn);
-        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-        for (uint32_t i = lane; i < rn; i += 64) {
-            a.out[base + i] = (int)rId[i];
-            a.reducePos[base + i] = (int)(a.reduceBase + rPos[i]);
+        if (REDUCE) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(a.reduceCount, rn);
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            for (uint32_t i = lane; i < rn; i += 64) {
+                a.out[base + i] = (int)rId[i];
+                a.reducePos[base + i] = (int)(a.reduceBase + rPos[i]);
+            }
+        } else {                                           /* full-result kernel: the staged matches overwrite their zeros, one store instruction for all of them */
+            if ((uint32_t)lane < rn) a.out[rPos[lane]] = (int)rId[lane];
         }
         rn = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
     auto stagePending = [&]() {
-        if (!REDUCE) return;
+        if (!REDUCE && !kStagedPatch) return;
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             const bool has = pendMatch[s] != 0;
@@ -592,9 +616,21 @@ void pfac_scan_filter(ScanArgs a)
             if (m) {
                 const uint32_t cnt = (uint32_t)__popcll(m);
                 if (rn + cnt > kReduceCap) flushStaged();
-                const uint32_t at = rn + laneRankIn(m);
-                if (has) { rPos[at] = pendPos[s]; rId[at] = (uint32_t)pendMatch[s]; pendMatch[s] = 0; }
-                rn = uni(rn + cnt);
+                if (cnt > kReduceCap) {                            /* pattern-dense input: this ballot alone is worth an atomic / a store instruction */
+                    if (REDUCE) {
+                        unsigned int base = 0;
+                        if (lane == 0) base = atomicAdd(a.reduceCount, cnt);
+                        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base) + laneRankIn(m);
+                        if (has) { a.out[base] = pendMatch[s]; a.reducePos[base] = (int)(a.reduceBase + pendPos[s]); pendMatch[s] = 0; }
+                    } else if (has) {
+                        a.out[pendPos[s]] = pendMatch[s];
+                        pendMatch[s] = 0;
+                    }
+                } else {
+                    const uint32_t at = rn + laneRankIn(m);
+                    if (has) { rPos[at] = pendPos[s]; rId[at] = (uint32_t)pendMatch[s]; pendMatch[s] = 0; }
+                    rn = uni(rn + cnt);
+                }
             }
         }
     };
@@ -623,12 +659,14 @@ void pfac_scan_filter(ScanArgs a)
         }
         stagePending();
     };
+    constexpr uint32_t kRefillBatch = (uint32_t)PFAC_REFILL_BATCH < kQCap / 2 ? (uint32_t)PFAC_REFILL_BATCH : kQCap / 2;   /* the ladder stops feeding a queue with less than 16 free entries */
+    bool flushWalks = false;                        /* nothing left to filter: queued walks start however few they are */
     /* hand verified queue entries to idle walker lanes */
     auto walkRefill = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             const uint64_t idle = __ballot(!alive[s]);
-            if ((uint32_t)__popcll(idle) >= (uint32_t)PFAC_REFILL_MIN && qh != qv) {
+            if ((uint32_t)__popcll(idle) >= (uint32_t)PFAC_REFILL_MIN && qh != qv && (qv - qh >= kRefillBatch || flushWalks)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);
@@ -684,17 +722,34 @@ void pfac_scan_filter(ScanArgs a)
         /* ---- writer wave: claim, zero-fill, publish.  One span in flight per writer: keeping two in flight (the
          * next span claimed and issued before the previous one is waited for) was worth 2..4 % while the scanning
          * waves stalled on their own loads, is worth nothing since they do not, and costs 4 % when the launch is bound
-         * by the result stream (profiles/r02_ab_prefetch_registers_and_writers.txt, r02_ab_list_refill_order.txt) */
+         * by the result stream (profiles/r02_ab_prefetch_registers_and_writers.txt, r02_ab_list_refill_order.txt).
+         * A writer spends a third of its time on the claim (PFAC_TIMING build: 27 % in the device atomic, 9 % waiting for
+         * the other writer's), but asking for the next span while the zeros of this one drain only moves that time into
+         * the store queue: the zeros then take that much longer to issue, the launch takes the same time
+         * (profiles/r03_experiments.md) -- the result stream is bound by the memory system, not by the writers. */
         const i32x4 zero = {0, 0, 0, 0};
+#if PFAC_TIMING     /* profile build: where a writer wave's time goes */
+        uint32_t wt[6] = {0, 0, 0, 0, 0, 0};
+        uint64_t wLast = __builtin_readcyclecounter();
+#define PFAC_WTICK(k) do { __builtin_amdgcn_sched_barrier(0); const uint64_t tNow = __builtin_readcyclecounter(); wt[k] += (uint32_t)(tNow - wLast); wLast = tNow; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PFAC_WTICK(k) do { } while (0)
+#endif
         for (uint32_t k = (uint32_t)(wave - kScanners);; k += kWriters) {
+#if PFAC_TIMING
+            while (ldsLoad(&ctl->claimTurn) != k) __builtin_amdgcn_s_sleep(8);
+            PFAC_WTICK(0);
+#endif
             for (;;) {                                      /* my turn to claim, and a ring slot nobody still reads */
                 const uint32_t turn = ldsLoad(&ctl->claimTurn), pops = ldsLoad(&ctl->popCount);
                 if (turn == k && k < (pops >> kSpanLog2) + kRunAhead) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            PFAC_WTICK(1);
             unsigned int v = 0;
             if (lane == 0) v = atomicAdd(counter, 1u);
             const uint32_t span = pieceOf(uni(v));
+            PFAC_WTICK(2);
             ldsStore(&ctl->claimTurn, k + 1);
             if (span >= pieceEnd) {
                 if (lane == 0) atomicMin(&ctl->endSpan, k);
@@ -707,12 +762,19 @@ void pfac_scan_filter(ScanArgs a)
             /* non-temporal: plain stores run the launch 10 % slower, stores with a wider scope (sc0 / sc1) 2-3 times
              * (profiles/r02_ab_zero_store_policy.txt) */
             for (uint32_t i = 0; i < stores; i++) __builtin_nontemporal_store(zero, &o4[i * 64 + lane]);
+            PFAC_WTICK(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              /* the zeros are in L2 */
+            PFAC_WTICK(4);
             while (ldsLoad(&ctl->pubCount) != k) __builtin_amdgcn_s_sleep(2);             /* publish in order */
             ldsStore(&ctl->ring[k & (kRing - 1)], span);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             ldsStore(&ctl->pubCount, k + 1);
+            PFAC_WTICK(5);
         }
+#if PFAC_TIMING
+        if (lane == 0)
+            for (int k = 0; k < 6; k++) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 20 + k, (unsigned long long)wt[k]);
+#endif
     } else {
     /* ---- scanning wave */
     /* ticket for the next chunk (lane 0 holds the answer): cheap, asked for one chunk ahead ... */
@@ -761,8 +823,11 @@ void pfac_scan_filter(ScanArgs a)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"        /* "clobber list contains reserved registers": that is the point */
     auto prefetchChunk = [&](uint32_t c) {
-        const uint32_t off = c * (uint32_t)kChunkBytes + (uint32_t)lane * 16u;
-        const uint32_t offHalo = (c + 1u) * (uint32_t)kChunkBytes + (uint32_t)(lane & 7) * 4u;
+        /* the lane's offsets are computed on the spot (volatile: loop invariants the compiler would keep in -- or spill
+         * from -- registers that the walkers' state needs) */
+        uint32_t off, offHalo;
+        asm volatile("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(off) : "v"(lane), "s"(c * (uint32_t)kChunkBytes));
+        asm volatile("v_and_b32 %0, 7, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
         static_assert(kTilesPerIter == 2, "two tile registers are reserved");
         asm volatile("global_load_dwordx4 v[120:123], %0, %2\n\t"
                      "global_load_dwordx4 v[124:127], %0, %2 offset:1024\n\t"
@@ -800,6 +865,13 @@ void pfac_scan_filter(ScanArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(lds.shift3));
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
+    /* this lane's code of the list round that starts at entry `first` (wave-uniform); the address is computed on the spot */
+    const uint32_t listBaseBytes = (uint32_t)(reinterpret_cast<unsigned char *>(list) - smem);
+    auto listCode = [&](uint32_t first) -> uint32_t {
+        uint32_t addr;
+        asm volatile("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(lane), "s"(listBaseBytes + 2u * first));
+        return (uint32_t)*reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(addr);
+    };
 #if PFAC_TIMING     /* profile build: shader-clock cycles this wave spends in each stage (s_memtime at the stage boundaries) */
     uint32_t tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tLast = __builtin_readcyclecounter();
@@ -824,6 +896,7 @@ void pfac_scan_filter(ScanArgs a)
         PFAC_TICK(8);
         walkConsume();
         PFAC_TICK(0);
+        flushWalks = chunk == kEnd && listAt == listEnd;
         /* ---- 2. hand idle walker lanes new positions, start the next transition of
          *         every live walk */
         walkRefill();
@@ -887,7 +960,7 @@ void pfac_scan_filter(ScanArgs a)
                         }
 #pragma unroll
                         for (int q = 0; q < kBatch; q++)
-                            hits = __builtin_amdgcn_alignbit(word[q] >> (xs[q] & 31u), hits, 1);   /* bit 0 of the shifted word enters at the top */
+                            hits = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> ((xs[q] >> 8) & 31u)), hits, 1);   /* both bits of the 3-gram (low five bits of its first and of its second byte) set: bit 0 enters at the top */
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -920,45 +993,89 @@ void pfac_scan_filter(ScanArgs a)
                 hits &= hits - 1;
             }
             PFAC_TICK(10);
-            listAt = 0;
-            listEnd = total < kListCap ? total : kListCap;
-            stHits += listEnd;
+            const uint32_t listed = total < kListCap ? total : kListCap;
+            stHits += listed;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             PFAC_TICK(4);
+            /* ---- 5a. every listed hit: its first four bytes against level 4 of the prefix ladder (are they a pattern
+             * prefix at all?), the length-3 bitmap and the exact 2-byte bitmap.  Survivors stay in the list, compacted
+             * in place (a wave's LDS accesses execute in order: every lane has read its code before any lane writes, and
+             * the k-th round writes below the codes it has read); bit 15 = "walk, whatever follows" (an S node at depth
+             * 4, or a pattern of up to three bytes matches here). */
+            uint32_t kept = 0;
+            for (uint32_t base = 0; base < listed; base += 64u) {
+                const bool act = base + (uint32_t)lane < listed;
+                const uint32_t code = act ? listCode(base) : 0u;
+                const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
+                const uint32_t at = o >> 2, sh = o & 3u;
+                const uint32_t x = __builtin_amdgcn_alignbyte(stage[at + 1], stage[at], sh);
+                const uint32_t h = x * pfac::kLadMul0;
+                const uint32_t sHit = testBit(sLadder, h >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulS) >> lds.shiftLad);
+                const uint32_t gHit = testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulG2) >> lds.shiftLad);
+                uint32_t decided = sHit | (testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3) &
+                                           testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul2) >> lds.shiftF3));
+                if (HAS_SHORT) decided |= testBit(sShort, x & 0xFFFFu);
+                const bool keep = act && (decided | gHit) != 0;
+                const uint64_t keepMask = __ballot(keep);
+                if (keep) list[kept + laneRankIn(keepMask)] = (uint16_t)(code | (decided << 15));
+                kept = uni(kept + (uint32_t)__popcll(keepMask));
+            }
+            listAt = 0;
+            listEnd = kept;
+            stCand += kept;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            PFAC_TICK(11);
         }
-        /* ---- 5. one listed hit per lane: cut its 20 bytes out of the stage, filter level 2 (the walk survives
-         * four transitions, or a pattern of length <= 3 can match here), survivors -> walk queue */
-        /* a pass takes up to 64 entries while the queue has room for 64; with the short queue of the compacted-output
-         * variant it takes what fits, as long as that is half a wave */
+        /* ---- 5b. the prefix ladder, one candidate per lane: cut its 20 bytes out of the stage and test the prefixes
+         * of 6, 8, ..., 20 bytes against the ladder bitmap (pfac_context.h: struct Filter) until the candidate meets an
+         * S node (walk), or neither an S nor a G node (its result is 0).  Survivors -> walk queue.  A batch takes up
+         * to 64 candidates, fewer if the queue has less room (then at least 16, or all that are left). */
         for (;;) {
             const uint32_t left = listEnd - listAt, room = kQCap - (qv - qh);
-            const uint32_t want = left < 64u ? left : 64u, take = (REDUCE && room < want) ? room : want;
-            if (left == 0 || (REDUCE ? (take != want && take < 32u) : room < 64u)) break;
-            const uint32_t passEnd = listAt + take;
-            const bool act = listAt + (uint32_t)lane < passEnd;
-            const uint32_t code = act ? (uint32_t)list[listAt + lane] : 0u;
-            const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
+            const uint32_t want = left < 64u ? left : 64u, take = room < want ? room : want;
+            if (left == 0 || (take != want && take < 16u)) break;
+            const bool act = (uint32_t)lane < take;
+            const uint32_t code = act ? listCode(listAt) : 0u;
+            const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);
             const uint32_t at = o >> 2, sh = o & 3u;
-            const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
-            const uint32_t x = __builtin_amdgcn_alignbyte(e1, e0, sh);
-            uint32_t pass = testBit(sGram4, (x * pfac::kGram4Mul) >> lds.shift4) & testBit(sGram4, (x * pfac::kGram4Mul2) >> lds.shift4);
-            pass |= testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3);
-            if (HAS_SHORT) pass |= testBit(sShort, x & 0xFFFFu);
+            /* the candidate's bytes are read from the stage as the levels need them, and once more for the queue entry of
+             * a survivor: held in registers across the ladder they cost five registers the walkers' state needs */
+            uint32_t eLo = stage[at + 1];
+            uint32_t h = __builtin_amdgcn_alignbyte(eLo, stage[at], sh) * pfac::kLadMul0;
+            uint32_t walk = act ? (code >> 15) & 1u : 0u;
+            uint32_t und = act ? walk ^ 1u : 0u;                    /* undecided: a G node so far */
+            uint32_t xw = 0;
+#pragma unroll
+            for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
+                if (__ballot(und != 0) == 0) break;
+                if (lv & 1) {                                       /* bytes 4k .. 4k+3 of the candidate serve two levels */
+                    const uint32_t eHi = stage[at + (lv + 3) / 2];
+                    xw = __builtin_amdgcn_alignbyte(eHi, eLo, sh);
+                    eLo = eHi;
+                }
+                h = (h ^ ((lv & 1) ? (xw & 0xFFFFu) : (xw >> 16))) * pfac::kLadMul;
+                const uint32_t sHit = testBit(sLadder, h >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulS) >> lds.shiftLad);
+                walk |= und & sHit;
+                if (lv == pfac::kLadderLevels - 1) und = 0;          /* the last level has S nodes only */
+                else und &= testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & ~sHit;
+            }
 #if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
-            pass = (((o * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? pass : 0u;
+            walk = (((o * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? walk : 0u;
 #endif
-            const bool keep = act && pass != 0;
+            const bool keep = walk != 0;
             const uint64_t keepMask = __ballot(keep);
-            const u32x4 entry = {stagedBase + o, x, __builtin_amdgcn_alignbyte(e2, e1, sh), __builtin_amdgcn_alignbyte(e3, e2, sh)};
-            const u32x2 entryB = {__builtin_amdgcn_alignbyte(e4, e3, sh), __builtin_amdgcn_alignbyte(e5, e4, sh)};
             if (keep) {
+                const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
+                const u32x4 entry = {stagedBase + o, __builtin_amdgcn_alignbyte(e1, e0, sh), __builtin_amdgcn_alignbyte(e2, e1, sh), __builtin_amdgcn_alignbyte(e3, e2, sh)};
+                const u32x2 entryB = {__builtin_amdgcn_alignbyte(e4, e3, sh), __builtin_amdgcn_alignbyte(e5, e4, sh)};
                 const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
                 queue[qi] = entry;
                 queueB[qi] = entryB;
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
-            listAt = uni(passEnd);
+            listAt = uni(listAt + take);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         PFAC_TICK(5);
@@ -969,7 +1086,7 @@ void pfac_scan_filter(ScanArgs a)
 #if PFAC_ABLATE == 1
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
-    if (REDUCE) flushStaged();
+    if (REDUCE || kStagedPatch) flushStaged();
 #if PFAC_TIMING
     if (lane == 0)
         for (int k = 0; k < 12; k++) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 8 + k, (unsigned long long)tm[k]);
@@ -982,10 +1099,11 @@ void pfac_scan_filter(ScanArgs a)
     __syncthreads();
     if (lane == 0) {
         atomicAdd(&sGram3[0], stRounds); atomicAdd(&sGram3[1], stLaneSteps);
-        atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits);
+        atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits); atomicAdd(&sGram3[4], stCand);
     }
     __syncthreads();
     if (tid < 4) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
+    if (tid == 5) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 5, (unsigned long long)sGram3[4]);
     if (tid == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord)[4] = a.n;
 #if PFAC_STATS
     if (lane == 0 && (blockIdx.x % 32) == 0 && wave == 0)
@@ -1024,15 +1142,23 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 
 /* ------------------------------------------------------------- launching */
 
+/* the CU's 160 KiB: the prefilter bitmaps (<= kFilterLdsBudget, pattern_compiler.cpp) + control block + per scanning wave a
+ * walk queue (24 B per entry), the staged chunk and the hit list (+ the pair staging of the compacted-output variant) */
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * 24 + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0));
+constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
+static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + (kScannerLdsFull > kScannerLdsReduce ? kScannerLdsFull : kScannerLdsReduce) <= kLdsPerCu,
+              "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
+
 size_t filterLdsBytes(const PFAC_context *c, bool reduce)
 {
-    size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2Bits4) +
+    size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2BitsLad) +
                     (size_t(1) << c->filter.log2BitsF3)) / 8;
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
     bytes += scanners * ((reduce ? kReduceQueueCap : kQueueCap) * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
-    if (reduce) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
+    if (reduce || kStagedPatch) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     return bytes;
 }
 
@@ -1075,15 +1201,23 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     e = hipGetLastError();
 #if PFAC_TIMING
     {
-        unsigned long long t[12];
+        unsigned long long t[18];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(t, c->d_workCounters + pfac::kStatsWord + 16, sizeof(t), hipMemcpyDeviceToHost);
         double sum = 0;
         for (int k = 0; k < 12; k++) sum += (double)t[k];
-        static const char *names[12] = {"consume", "refill", "issue", "level1+stage", "list-fences", "passes", "resolve(wait for writers)+prefetch issue", "loop/pop/other",
-                                        "wait for loads (top of trip)", "popcount+scan", "emit-loop", "-"};
+        static const char *names[12] = {"consume", "refill", "issue", "level1+stage", "list-fences", "ladder+append", "resolve(wait for writers)+prefetch issue", "loop/pop/other",
+                                        "wait for loads (top of trip)", "popcount+scan", "emit-loop", "level-4 test"};
         fprintf(stderr, "PFAC_TIMING blocks %zu scanners %zu:", blocks, scanners);
-        for (int k = 0; k < 11; k++) fprintf(stderr, "  %s %.1f%% (%.0f cyc/wave)", names[k], 100.0 * t[k] / sum, (double)t[k] / (blocks * scanners));
+        for (int k = 0; k < 12; k++) fprintf(stderr, "  %s %.1f%% (%.0f cyc/wave)", names[k], 100.0 * t[k] / sum, (double)t[k] / (blocks * scanners));
+        if (!REDUCE && PFAC_WRITERS) {
+            static const char *wnames[6] = {"wait for the other writer's claim", "wait for run-ahead room (scanners)", "device claim (atomic)", "issue zero stores",
+                                            "wait until the zeros are in L2", "publish in order"};
+            double wsum = 0;
+            for (int k = 0; k < 6; k++) wsum += (double)t[12 + k];
+            fprintf(stderr, "\nPFAC_TIMING writers %d per block:", (int)PFAC_WRITERS);
+            for (int k = 0; k < 6; k++) fprintf(stderr, "  %s %.1f%% (%.0f cyc/wave)", wnames[k], 100.0 * t[12 + k] / wsum, (double)t[12 + k] / (blocks * PFAC_WRITERS));
+        }
         fprintf(stderr, "\n");
     }
 #endif
@@ -1124,7 +1258,7 @@ uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu 
 PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_string, size_t input_size,
                        int *d_matched_result, ScanArgs &a)
 {
-    if (!c->d_initialRow || !c->d_gram3 || !c->d_gram4 || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
+    if (!c->d_initialRow || !c->d_gram3 || !c->d_ladder || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
     if (!c->d_chainSlots || c->chainJumpLog2 <= 0 || (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense))
         return PFAC_STATUS_INTERNAL_ERROR;
     a = ScanArgs{};
@@ -1145,10 +1279,10 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;
     a.shortBits = c->d_shortBits;
-    a.gram4 = c->d_gram4;
+    a.ladder = c->d_ladder;
     a.final3 = c->d_final3;
     a.log2Bits = c->filter.log2Bits;
-    a.log2Bits4 = c->filter.log2Bits4;
+    a.log2BitsLad = c->filter.log2BitsLad;
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.work = c->d_workCounters;

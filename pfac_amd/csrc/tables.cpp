@@ -106,62 +106,29 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
 }
 
 /*
- * Device-only "chained" form of the hashed table for the gfx950 walker (scan_gfx950.hip).
+ * Device-only "chained" transition table for the gfx950 walker (scan_gfx950.hip), used in BOTH perf modes.
  *
- * Slot i corresponds 1:1 to slot i of the reference's hashValPtr.  Instead of {next, ch} it carries
- *   - the hashRowPtr entry of the state the walker will be in next, so a transition needs ONE
- *     dependent 16-byte load instead of the reference's two (rowPtr[state], then valPtr[...],
- *     PFAC_kernel_spaceDriven.cu:76-124);
- *   - the single-successor chain that follows `next`: while the current state is not final and has
- *     exactly one outgoing transition, the byte of that transition is appended (up to
- *     kChainMax bytes) and the state advances.  The walker compares the chain against the input
- *     and lands directly in the end state.  Skipping is exact: the skipped states are not final, so
- *     they could not have changed the reported match, and a mismatch anywhere in the chain is the
- *     trap state (PFAC_CPU.cpp:76-96).
- * The end state's number is only needed when it is final (it is the pattern ID).  A final leaf
- * keeps it in endRow (a leaf has no bucket); a final state with successors (a pattern that is a
- * prefix of another) keeps it in chain[4..7], and such a slot's chain is cut to <= 3 bytes (the cut
- * lands on a non-final chain state; the next slot carries on from there).
- */
-static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &rowPtr, int ch, int next,
-                               const unsigned char *forced = nullptr, int numForced = 0)
-{
-    /* forced: the first chain bytes are given (a path through non-final states that may branch: the jump slots
-     * below) and `next` is the state behind them; the single-successor chain carries on from there */
-    ChainSlot s;
-    std::memset(&s, 0, sizeof(s));
-    s.meta = kSlotEmpty;
-    s.endRow = -1;
-    if (next < 0) return s;
-    auto follow = [&](int limit, int &end) {
-        int k = 0;
-        for (; k < numForced; k++) s.chain[k] = forced[k];
-        end = next;
-        while (k < limit && end > fa.numPatterns && fa.edgeBegin[end + 1] - fa.edgeBegin[end] == 1) {
-            s.chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
-            end = fa.edgeNext[fa.edgeBegin[end]];
-        }
-        return k;
-    };
-    int cur;
-    int k = follow(kChainMax, cur);
-    if (cur <= fa.numPatterns && rowPtr[cur].x >= 0 && k > 3) {      /* final with successors: the ID needs chain[4..7] */
-        std::memset(s.chain, 0, sizeof(s.chain));
-        k = follow(3, cur);
-    }
-    const bool leaf = rowPtr[cur].x < 0;
-    const bool fin = cur <= fa.numPatterns;
-    const uint32_t hashK = leaf ? 0u : (uint32_t)rowPtr[cur].y >> 16;           /* 1..256 */
-    const uint32_t sizeMask = leaf ? 0u : (uint32_t)rowPtr[cur].y & 0xFFFFu;    /* S-1 <= 255 */
-    s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 15) |
-             (sizeMask << 24);
-    s.endRow = leaf ? (fin ? cur : -1) : rowPtr[cur].x;
-    if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));
-    return s;
-}
-
-/*
- * Behind the slots of the reference layout the array carries two more regions (device-only, like the rest):
+ * The reference's hashed layout (above) answers one transition with two dependent loads (rowPtr[state], then
+ * valPtr[...], PFAC_kernel_spaceDriven.cu:76-124) and gives every state a bucket.  The walker's table keeps the
+ * reference's hash family -- slot = ((k * ch) mod 257) & (S - 1), smallest collision-free k -- but
+ *   - a slot carries the bucket {offset, k, S} of the state the walker will be in next, so a transition needs ONE
+ *     dependent 16-byte load;
+ *   - a slot carries the single-successor chain that follows `next`: while the current state is not final and has
+ *     exactly one outgoing transition, the byte of that transition is appended (up to kChainMax bytes) and the state
+ *     advances.  The walker compares the chain against the input and lands directly in the end state.  Skipping is
+ *     exact: the skipped states are not final, so they could not have changed the reported match, and a mismatch
+ *     anywhere in the chain is the trap state (PFAC_CPU.cpp:76-96);
+ *   - only states a walk can LAND in have a bucket (nine out of ten states of a Snort-scale set are inside chains),
+ *     buckets are as small as the hash family allows (the smallest power of two >= the fan-out that has a
+ *     collision-free k; the reference's ladder gives a state with nine successors 128 slots) and they are laid out
+ *     breadth first, the top of the trie -- where walks spend their time -- in one contiguous piece: the table of the
+ *     30 k-pattern bench set shrinks from 11.9 MB to a few MB that stay in the 4 MiB L2 of an XCD next to the stream.
+ * The end state's number is only needed when it is final (it is the pattern ID).  A final leaf keeps it in endRow (a
+ * leaf has no bucket); a final state with successors (a pattern that is a prefix of another) keeps it in chain[4..7],
+ * and such a slot's chain is cut to <= 3 bytes (the cut lands on a non-final chain state; the next slot carries on
+ * from there).
+ *
+ * Behind the buckets the array carries two more regions:
  *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 1, S = 256);
  *   [jumpBase, jumpBase + 2^J) the JUMP table: one slot per 4-byte pattern prefix whose first three states are not
  *                              final, at hash(prefix), encoded as a transition on the first byte with the other
@@ -172,16 +139,121 @@ static ChainSlot makeChainSlot(const Automaton &fa, const std::vector<Int2> &row
  *                              state, or that the prefilter let through wrongly simply are not there, and the
  *                              walker falls back to the initial state's bucket.
  */
-PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2> &rowPtr,
-                                    const std::vector<Int2> &valPtr, std::vector<ChainSlot> &slots, int &jumpLog2)
+namespace {
+
+struct ChainBuilder {
+    const Automaton &fa;
+    std::vector<ChainSlot> &slots;                 /* the buckets; root row and jump table are appended at the end */
+    std::vector<int> bucketOff;                    /* per state: first slot of its bucket, -1 = none yet */
+    std::vector<uint32_t> bucketKS;                /* per state: k << 8 | (S - 1) */
+    std::vector<int> pending;                      /* states whose bucket is allocated but not filled, in allocation order */
+    bool failed = false;
+
+    ChainBuilder(const Automaton &a, std::vector<ChainSlot> &out)
+        : fa(a), slots(out), bucketOff((size_t)a.numStates, -1), bucketKS((size_t)a.numStates, 0u) {}
+
+    static ChainSlot emptySlot()
+    {
+        ChainSlot s;
+        std::memset(&s, 0, sizeof(s));
+        s.meta = kSlotEmpty;
+        s.endRow = -1;
+        return s;
+    }
+    int fanout(int s) const { return fa.edgeBegin[s + 1] - fa.edgeBegin[s]; }
+
+    /* the bucket of a state with successors: allocated on first use */
+    void needBucket(int state)
+    {
+        if (bucketOff[state] >= 0) return;
+        const int b = fa.edgeBegin[state], e = fa.edgeBegin[state + 1], fan = e - b;
+        int S = 1;
+        while (S < fan) S *= 2;
+        int k = -1;
+        for (; S <= 256 && k < 0; S *= 2) {
+            for (int cand = 1; cand <= 256 && k < 0; cand++) {
+                uint64_t used[4] = {0, 0, 0, 0};
+                bool ok = true;
+                for (int i = b; i < e && ok; i++) {
+                    const int slot = slotOf(cand, fa.edgeCh[i], S);
+                    const uint64_t bit = uint64_t(1) << (slot & 63);
+                    ok = !(used[slot >> 6] & bit);
+                    used[slot >> 6] |= bit;
+                }
+                if (ok) k = cand;
+            }
+            if (k >= 0) break;
+        }
+        if (k < 0) { failed = true; return; }      /* cannot happen: k = 1, S = 256 separates any 255 bytes */
+        bucketOff[state] = (int)slots.size();
+        bucketKS[state] = ((uint32_t)k << 8) | (uint32_t)(S - 1);
+        slots.resize(slots.size() + (size_t)S, emptySlot());
+        pending.push_back(state);
+    }
+
+    /* the slot of the transition on byte ch into state `next`; forced: the first chain bytes are given (a path through
+     * non-final states that may branch: the jump slots) and `next` is the state behind them */
+    ChainSlot makeSlot(int ch, int next, const unsigned char *forced = nullptr, int numForced = 0)
+    {
+        ChainSlot s = emptySlot();
+        if (next < 0) return s;
+        auto follow = [&](int limit, int &end) {
+            int k = 0;
+            for (; k < numForced; k++) s.chain[k] = forced[k];
+            end = next;
+            while (k < limit && end > fa.numPatterns && fanout(end) == 1) {
+                s.chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
+                end = fa.edgeNext[fa.edgeBegin[end]];
+            }
+            return k;
+        };
+        int cur;
+        int k = follow(kChainMax, cur);
+        if (cur <= fa.numPatterns && fanout(cur) > 0 && k > 3) {         /* final with successors: the ID needs chain[4..7] */
+            std::memset(s.chain, 0, sizeof(s.chain));
+            k = follow(3, cur);
+        }
+        const bool leaf = fanout(cur) == 0;
+        const bool fin = cur <= fa.numPatterns;
+        if (!leaf) needBucket(cur);
+        const uint32_t hashK = leaf ? 0u : bucketKS[cur] >> 8;           /* 1..256 */
+        const uint32_t sizeMask = leaf ? 0u : bucketKS[cur] & 0xFFu;     /* S-1 <= 255 */
+        s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 15) | (sizeMask << 24);
+        s.endRow = leaf ? (fin ? cur : -1) : bucketOff[cur];
+        if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));
+        return s;
+    }
+
+    /* fill the buckets allocated so far, and those their slots allocate, breadth first */
+    void drain()
+    {
+        for (size_t at = 0; at < pending.size() && !failed; at++) {
+            const int state = pending[at];
+            const int k = (int)(bucketKS[state] >> 8), S = (int)(bucketKS[state] & 0xFFu) + 1;
+            for (int e = fa.edgeBegin[state]; e < fa.edgeBegin[state + 1]; e++) {
+                const ChainSlot slot = makeSlot(fa.edgeCh[e], fa.edgeNext[e]);           /* may grow `slots` */
+                slots[(size_t)bucketOff[state] + (size_t)slotOf(k, fa.edgeCh[e], S)] = slot;
+            }
+        }
+        pending.clear();
+    }
+};
+
+} // namespace
+
+PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2)
 {
-    for (const Int2 &r : rowPtr)
-        if (r.x >= 0 && (((uint32_t)r.y >> 16) > 256u || ((uint32_t)r.y & 0xFFFFu) > 255u)) return PFAC_STATUS_INTERNAL_ERROR;
     const int F = fa.numPatterns, init = fa.initialState;
     /* 4-byte prefixes: {key, state at depth 4} */
     struct Prefix { uint32_t key; int state; };
     std::vector<Prefix> prefixes;
     try {
+        slots.clear();
+        if (fa.numStates <= init) {                                /* no patterns: root row + smallest jump table, all empty */
+            jumpLog2 = kJumpLog2Min;
+            slots.assign((size_t)kCharSet + (size_t(1) << jumpLog2), ChainBuilder::emptySlot());
+            return PFAC_STATUS_SUCCESS;
+        }
         for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
             const int s1 = fa.edgeNext[e1];
             if (s1 <= F) continue;
@@ -200,20 +272,21 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, const std::vector<Int2>
         }
         jumpLog2 = kJumpLog2Min;
         while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < 8 * prefixes.size()) jumpLog2++;
-        const size_t rootRow = valPtr.size(), jumpBase = rootRow + kCharSet;
-        slots.resize(jumpBase + (size_t(1) << jumpLog2));
-        for (size_t i = 0; i < valPtr.size(); i++) slots[i] = makeChainSlot(fa, rowPtr, valPtr[i].y, valPtr[i].x);
-        const ChainSlot empty = makeChainSlot(fa, rowPtr, 0, kTrapState);
-        for (int c = 0; c < kCharSet; c++) slots[rootRow + c] = empty;
-        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++)
-            slots[rootRow + fa.edgeCh[e]] = makeChainSlot(fa, rowPtr, fa.edgeCh[e], fa.edgeNext[e]);
-        for (size_t i = jumpBase; i < slots.size(); i++) slots[i] = empty;
+        ChainBuilder b(fa, slots);
+        std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
+        /* the top of the trie first: what the initial state's transitions land in, then what the jump slots land in,
+         * then everything below, level by level */
+        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++) root[fa.edgeCh[e]] = b.makeSlot(fa.edgeCh[e], fa.edgeNext[e]);
         for (const Prefix &p : prefixes) {
-            ChainSlot &dst = slots[jumpBase + jumpHash(p.key, jumpLog2)];
+            ChainSlot &dst = jump[jumpHash(p.key, jumpLog2)];
             if (!(dst.meta & kSlotEmpty)) continue;            /* taken: this prefix walks from the initial state */
             const unsigned char rest[3] = {(unsigned char)(p.key >> 8), (unsigned char)(p.key >> 16), (unsigned char)(p.key >> 24)};
-            dst = makeChainSlot(fa, rowPtr, (int)(p.key & 0xFFu), p.state, rest, 3);
+            dst = b.makeSlot((int)(p.key & 0xFFu), p.state, rest, 3);
         }
+        b.drain();
+        if (b.failed) return PFAC_STATUS_INTERNAL_ERROR;
+        slots.insert(slots.end(), root.begin(), root.end());
+        slots.insert(slots.end(), jump.begin(), jump.end());
     } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     return PFAC_STATUS_SUCCESS;
 }

@@ -1,0 +1,55 @@
+"""The prefilter of the scan kernel as a numpy model (test infrastructure): level 1 (blocked two-bit 3-gram bitmap), the
+bypass for patterns of up to three bytes, and the prefix ladder, evaluated exactly as scan_gfx950.hip does from the
+tables the library compiled (contract: struct Filter and the hash helpers in pfac_amd/csrc/pfac_context.h)."""
+import numpy as np
+
+from pfac_amd import api
+
+GRAM3_MUL, FINAL3_MUL, FINAL3_MUL2 = 0x8B92C5, 0x85EBCB, 0xB5297B
+LAD_MUL0, LAD_MUL, LAD_MULS, LAD_MULG, LAD_MULG2 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F, 0x165667B1
+LADDER_LAST = 20
+
+
+def prefilter_model(h, data):
+    """(level-1 hits, ladder candidates, positions that are walked): boolean arrays over the positions of `data`."""
+    info = h.info()
+    g3, lad = h.table(api.PFACX_TABLE_FILTER_GRAM3), h.table(api.PFACX_TABLE_FILTER_LADDER)
+    f3, sb = h.table(api.PFACX_TABLE_FILTER_FINAL3), h.table(api.PFACX_TABLE_FILTER_SHORT)
+    u = np.uint64
+    m32 = u(0xFFFFFFFF)
+    n = data.size
+    d = np.concatenate([data, np.zeros(24, dtype=np.uint8)]).astype(np.uint64)
+    x = d[:n] | (d[1:n + 1] << u(8)) | (d[2:n + 2] << u(16)) | (d[3:n + 3] << u(24))
+
+    def bit(bitmap, hv):
+        return ((bitmap[(hv >> u(5)).astype(np.int64)] >> (hv & u(31)).astype(np.uint32)) & 1).astype(bool)
+
+    # level 1: two bits of one dword (patterns of 1-2 bytes are folded into the bitmap)
+    prod = ((x & u(0xFFFFFF)) * u(GRAM3_MUL)) & m32
+    word = g3[(prod >> u(37 - info.filterLog2Bits)).astype(np.int64)]
+    level1 = (((word >> (x & u(31)).astype(np.uint32)) & (word >> ((x >> u(8)) & u(31)).astype(np.uint32))) & 1).astype(bool)
+    k3 = x & u(0xFFFFFF)
+    sf = u(32 - info.filterLog2BitsFinal3)
+    bypass = bit(f3, ((k3 * u(FINAL3_MUL)) & m32) >> sf) & bit(f3, ((k3 * u(FINAL3_MUL2)) & m32) >> sf)
+    if info.filterHasShort:
+        bypass |= bit(sb, x & u(0xFFFF))
+    sh = u(32 - info.filterLog2BitsLadder)
+
+    def stop(hh):
+        return bit(lad, hh >> sh) & bit(lad, ((hh * u(LAD_MULS)) & m32) >> sh)
+
+    def go_on(hh):
+        return bit(lad, ((hh * u(LAD_MULG)) & m32) >> sh)
+
+    hh = (x * u(LAD_MUL0)) & m32
+    s, g = stop(hh), go_on(hh) & bit(lad, ((hh * u(LAD_MULG2)) & m32) >> sh)       # depth 4: G nodes set two bits
+    walk = level1 & (bypass | s)
+    cand = level1 & (bypass | s | g)
+    und = cand & ~walk
+    for depth in range(6, LADDER_LAST + 2, 2):
+        piece = d[depth - 2:n + depth - 2] | (d[depth - 1:n + depth - 1] << u(8))
+        hh = ((hh ^ piece) * u(LAD_MUL)) & m32
+        s = stop(hh)
+        walk |= und & s
+        und = und & go_on(hh) & ~s if depth < LADDER_LAST else und & False
+    return level1, cand, walk

@@ -183,32 +183,36 @@ def test_pattern_file_quirks(tmp_path):
     h.destroy()
 
 
+from tests.filter_model import prefilter_model       # noqa: E402
+
+
 @pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
 def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
-    """Every position with a non-zero result passes both filter levels as the kernel evaluates them."""
+    """Every position with a non-zero result passes level 1 and the prefix ladder as the kernel evaluates them."""
     w = workloads[name]
     h = api.PFAC.createHostOnly()
     h.readPatternFromFile(w.pattern_file)
     info = h.info()
-    g3, g4 = h.table(api.PFACX_TABLE_FILTER_GRAM3), h.table(api.PFACX_TABLE_FILTER_GRAM4)
-    f3, sb = h.table(api.PFACX_TABLE_FILTER_FINAL3), h.table(api.PFACX_TABLE_FILTER_SHORT)
+    level1, cand, walk = prefilter_model(h, w.data)
     h.destroy()
-    d = np.concatenate([w.data, np.zeros(4, dtype=np.uint8)]).astype(np.uint64)
-    x = d[:-4] | (d[1:-3] << 8) | (d[2:-2] << 16) | (d[3:-1] << 24)
-
-    def bit(bitmap, hv):
-        return (bitmap[(hv >> 5).astype(np.int64)] >> (hv & 31).astype(np.uint32)) & 1
-
-    h3 = (((((x & 0xFFFFFF) * 0x8B92C5) & 0xFFFFFFFF) >> (37 - info.filterLog2Bits)) << 5) | (x & 31)
-    h4 = ((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
-    h4b = ((x * 0x85EBCA77) & 0xFFFFFFFF) >> (32 - info.filterLog2Bits4)
-    hf = (((x & 0xFFFFFF) * 0x85EBCB) & 0xFFFFFFFF) >> (32 - info.filterLog2BitsFinal3)
-    short = bit(sb, x & 0xFFFF)
-    level1 = bit(g3, h3)                               # patterns of 1-2 bytes are folded into the 3-gram bitmap
-    level2 = (bit(g4, h4) & bit(g4, h4b)) | bit(f3, hf) | short
     hit = oracle_results[name] != 0
-    assert np.all(level1[hit] == 1) and np.all(level2[hit] == 1)
+    assert np.all(level1[hit]) and np.all(cand[hit]) and np.all(walk[hit])
     assert info.filterHasShort == int(any(len(p) < 3 for p in open(w.pattern_file, "rb").read().split(b"\n") if p))
+    lds = ((1 << info.filterLog2Bits) + (1 << info.filterLog2BitsLadder) + (1 << info.filterLog2BitsFinal3)) // 8 + 8192 * info.filterHasShort
+    assert lds <= 97 * 1024, "the bitmaps share the LDS budget of the kernel (pfac_context.h: kFilterLdsBudget)"
+
+
+def test_prefix_ladder_prunes_the_snort_style_stream(workloads, oracle_results):
+    """The ladder is why the bench workload walks few positions: on the C3 sample fewer than half of the candidates
+    (level-1 hits whose first four bytes are a pattern prefix) survive it, and every true match does."""
+    w = workloads["c3"]
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(w.pattern_file)
+    info = h.info()
+    level1, cand, walk = prefilter_model(h, w.data)
+    h.destroy()
+    assert info.ladderStops > 0 and info.ladderGoOns > 0 and info.ladderThin == 1 and info.ladderExtend == 1
+    assert walk.sum() < 0.5 * cand.sum() and np.all(walk[oracle_results["c3"] != 0])
 
 
 def test_read_pattern_from_memory_equals_read_from_file(workloads):
@@ -256,10 +260,11 @@ def test_compiled_set_round_trip_on_the_host(workloads, oracle_results, tmp_path
     b.loadCompiled(path)
     ia, ib = a.info(), b.info()
     for field in ("numOfPatterns", "numOfStates", "initialState", "maxPatternLen", "numOfLeaves", "perfMode",
-                  "numOfTableEntry", "sizeOfTableInBytes", "filterLog2Bits", "filterHasShort", "filterBitsSet", "filterLog2Bits4"):
+                  "numOfTableEntry", "sizeOfTableInBytes", "filterLog2Bits", "filterHasShort", "filterBitsSet", "filterLog2BitsLadder",
+                  "filterBitsSetLadder", "ladderStops", "ladderGoOns", "ladderThin", "ladderExtend"):
         assert getattr(ia, field) == getattr(ib, field), field
     tables = [api.PFACX_TABLE_INITIAL_ROW, api.PFACX_TABLE_FILTER_GRAM3, api.PFACX_TABLE_FILTER_SHORT,
-              api.PFACX_TABLE_FILTER_GRAM4, api.PFACX_TABLE_FILTER_FINAL3]
+              api.PFACX_TABLE_FILTER_LADDER, api.PFACX_TABLE_FILTER_FINAL3]
     tables += [api.PFACX_TABLE_DENSE] if perf == api.PFAC_TIME_DRIVEN else [api.PFACX_TABLE_HASH_ROWPTR, api.PFACX_TABLE_HASH_VALPTR]
     for which in tables:
         assert np.array_equal(a.table(which), b.table(which)), which

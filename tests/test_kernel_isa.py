@@ -77,19 +77,25 @@ def test_filter_kernel_register_contract(isa):
 
 
 def test_scan_loop_waits_once_per_trip(isa):
-    """Inside the scan loop the only wait for vector memory is the explicit one at the top of a trip."""
+    """Inside the scan loop the only wait for vector memory is the explicit one at the top of a trip (and, in the
+    compacted-output instances, the ones behind the returning atomics that hand out chunks and output slots)."""
     for name, (body, _) in _kernels(isa).items():
         lines = body.splitlines()
         # the scan loop: from the first copy out of a reserved register back to the enclosing loop header
         first_copy = next(i for i, l in enumerate(lines) if re.search(r"v_mov_b32 v\d+, v120\b", l))
         header = max(i for i, l in enumerate(lines[:first_copy]) if "Loop Header: Depth=1" in l)
         label = re.match(r"\.L(BB\d+_\d+):", lines[header]).group(1)
-        last_block = max(i for i, l in enumerate(lines) if f"Header={label} " in l)      # last block annotated as part of the loop
-        end = next(i for i, l in enumerate(lines) if i > last_block and re.match(r"\.LBB\d+_\d+:", l))
-        loop = lines[header:end]
+        member = [i for i, l in enumerate(lines) if f"Header={label} " in l]             # blocks annotated as part of the loop
+        end = next(i for i, l in enumerate(lines) if i > max(member) and re.match(r"\.LBB\d+_\d+:", l))
+        # the compiler may place blocks of the loop (its rotated top, with the explicit wait) in front of the header label
+        start = min(header, max(i for i, l in enumerate(lines[:min(member)]) if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", l)))
+        loop = lines[start:end]
         waits = [i for i, l in enumerate(loop) if "s_waitcnt" in l and "vmcnt" in l]
         # the compacted-output instances flush their staged pairs with a returning atomic now and then and wait for it
         after_atomic = [i for i in waits if any("global_atomic_add" in l for l in loop[max(0, i - 4):i])]
-        assert len(waits) - len(after_atomic) == 1, (name, [loop[i].strip() for i in waits])
+        # ... of which the compiler may lay out one copy per path into the loop top (tail duplication): every copy is
+        # followed by the same instruction, the first of the walkers' consume stage
+        top = {loop[i + 1].strip() for i in waits if i not in after_atomic}
+        assert len(top) == 1 and 1 <= len(waits) - len(after_atomic) <= 2, (name, [loop[i].strip() + " / " + loop[i + 1].strip() for i in waits])
         if "ELb0ELi2E" in name:                        # REDUCE = false: no atomics at all in the loop
             assert not after_atomic, name

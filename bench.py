@@ -88,6 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="target duration of ONE CPU-baseline run (3 runs are timed)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real path; gloo lets several ranks share one GPU for a dry run")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the facts all-gather even with one rank (one RCCL all_gather on "
+                         "hardware without a multi-GPU node: tests/test_gpu_round3.py)")
     ap.add_argument("--worker", default=None, choices=[None, "cpu", "pmc", "rank"],
                     help="rank: be the single rank right here, no orchestrator and no child process (the form to put behind `rocprofv3 ... --`); "
                          "pmc: the same, a few launches only; cpu: the CPU-baseline process")
@@ -510,7 +513,13 @@ def rank_main(args):
     elif args.dist_backend != "gloo":
         log("[bench] --platform cpu_omp needs --dist-backend gloo")
         return 2
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if args.force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -519,7 +528,7 @@ def rank_main(args):
     from pfac_amd import sharding
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     t_setup = time.perf_counter()
@@ -557,7 +566,7 @@ def rank_main(args):
 
     # ---- gather per-rank facts (RCCL: 5 x int64 per rank) ----------------------------------------
     allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
-                                     device=device if (gpu and args.dist_backend == "nccl") else None)
+                                     device=device if (gpu and args.dist_backend == "nccl") else None, force=args.force_dist)
     elapsed_max = float(allf[:, 3].max()) / 1e9
     total_matches, folded = sharding.combine_checksums([(int(c), int(s)) for c, s in allf[:, :2]])
     all_ok = bool(allf[:, 2].all())
@@ -591,7 +600,7 @@ def rank_main(args):
                 "table": "hashed" if run.perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
                 "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "platform": args.platform,
                 "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
-                "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if world > 1 else None,
+                "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if use_dist else None,
                 "folded_result": {"match_count": total_matches, "checksum": folded & 0x7FFFFFFFFFFFFFFF},
                 "folded_reference": expected,
             },
@@ -691,7 +700,7 @@ def rank_main(args):
             log("[bench] RESULT NOT BIT-EXACT")
             rc = 1
     run.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return rc
 

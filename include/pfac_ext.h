@@ -87,7 +87,9 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 #define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
 #define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic)           */
 #define PFACX_KERNEL_AUTO   2   /* default: FILTER, except that calls of less than 1 MiB take NAIVE
-                                   alone (lower latency: the filter kernel has a ~35 us floor)      */
+                                   alone (lower latency: the filter kernel has a ~35 us floor).  Either way
+                                   the filter kernel hands pattern-dense 2 KiB chunks (most positions pass
+                                   its first level) to the simple kernel that follows it.              */
 
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 
@@ -119,6 +121,8 @@ typedef struct {
     int walksPerLane;                     /* independent walks per lane                                        */
     unsigned long long ladderCandidates;  /* level-1 hits whose first four bytes are a pattern prefix (or a short
                                              pattern): what the prefix ladder was asked about                  */
+    unsigned long long denseChunks;       /* 2 KiB chunks in which more than 90 % of the positions passed level 1:
+                                             left to the simple kernel that follows the filter kernel          */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);

@@ -68,7 +68,7 @@ class PFACX_info(C.Structure):
 class PFACX_scan_stats(C.Structure):
     _fields_ = [("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
                 ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
-                ("ladderCandidates", C.c_ulonglong)]
+                ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong)]
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")

@@ -85,8 +85,8 @@ void freeResources(PFAC_context *c)
     c->hostReduceBytes = 0;
     freeHostStage(c);
     devFree(c->d_final3);
-    if (c->h_statsPinned) { (void)hipHostFree(c->h_statsPinned); c->h_statsPinned = nullptr; }
-    c->autoCalls = 0;
+    devFree(c->d_denseList);
+    c->denseListEntries = 0;
     for (auto &child : c->children) (void)PFAC_destroy(child.second);
     c->children.clear();
     c->fa = pfac::Automaton();
@@ -170,15 +170,6 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
         pfac::buildFilter(c->fa, c->filter);
     }
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
-    if (!c->h_statsPinned) {
-        void *p = nullptr;
-        if (hipHostMalloc(&p, pfac::kStatsCount * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
-            c->h_statsPinned = static_cast<unsigned long long *>(p);
-            std::memset(p, 0, pfac::kStatsCount * sizeof(unsigned long long));
-        } else {
-            (void)hipGetLastError();                   /* the AUTO heuristic simply has no data then */
-        }
-    }
     PFAC_status_t st = upload(c->d_initialRow, c->h_initialRow.data(), c->h_initialRow.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram3, c->filter.gram3.data(), c->filter.gram3.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
@@ -1039,6 +1030,11 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
         return PFAC_STATUS_INTERNAL_ERROR;
     stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
     stats->ladderCandidates = v[5];
+    for (int part = 0; part < pfac::kWorkParts; part++) {    /* scan_gfx950.hip denseCountWord(part): one counter line per input part */
+        unsigned int dense = 0;
+        if (hipMemcpy(&dense, handle->d_workCounters + (32 + part) * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        stats->denseChunks += dense;
+    }
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = PFAC_WALK_SETS;
     return PFAC_STATUS_SUCCESS;

@@ -38,7 +38,6 @@ constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel ha
 constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
-constexpr double kAutoDenseHitRate = 0.6;     /* PFACX_KERNEL_AUTO: above this level-1 hit rate the simple kernel is the faster one */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS
 #define PFAC_WALK_SETS 2                       /* independent walks per lane */
@@ -212,10 +211,9 @@ struct PFAC_context {
     std::mutex lock;
     /* per-device handles of PFACX_matchFromHostMultiGPU, created on first use: (device, handle) */
     std::vector<std::pair<int, PFAC_context *>> children;
-    /* PFACX_KERNEL_AUTO: level-1 hit density of recent filter launches, copied to pinned host memory behind each
-     * launch (no synchronisation: a heuristic reads whatever has arrived) */
-    unsigned long long *h_statsPinned = nullptr;          /* kStatsCount counters + the positions they refer to */
-    unsigned int autoCalls = 0;
+    /* chunks the filter kernel found pattern-dense and left to the simple kernel (scan_gfx950.hip): grow-only, one entry per chunk of a launch */
+    unsigned int *d_denseList = nullptr;
+    size_t denseListEntries = 0;
 
     bool hasDevice = false;
     int device = -1;

@@ -135,7 +135,24 @@ struct ScanArgs {
     int *reducePos;
     unsigned int *reduceCount;
     unsigned int reduceBase;                           /* position of a.in[0] inside the caller's stream */
+    /* pattern-dense chunks (full-result path): the filter kernel lists the chunks in which most positions pass level 1
+     * instead of filtering them; the simple kernel that follows it (the launch that also scans the end of the input)
+     * walks their positions one per thread.  denseIn / denseOut / denseReadable describe the filter launch the chunk
+     * numbers refer to.  The list has one segment of denseSegment entries per input part (blocks that share a claim
+     * counter share a segment), filled through the part's own counter a.work[denseCountWord(part)]: one counter for
+     * the whole launch would saturate at ~90 appends per microsecond, 1.5 ms for 256 MiB of pattern-dense input. */
+    unsigned int *denseList;
+    unsigned int denseSegment;
+    const unsigned char *denseIn;
+    int *denseOut;
+    size_t denseReadable;
 };
+constexpr int denseCountWord(int part) { return (32 + part) * 32; }   /* the launch counters are one 128-byte line per part: lines 0..31 hand out
+                                                                         the input (at most 32 parts), lines 32..63 count the parts' dense chunks */
+constexpr uint32_t kDenseHits = 1843;                  /* of the 2048 positions of a chunk: above 90 % the prefilter only adds work.  (Input in which every
+                                                          position matches: 40 GB/s through the filter kernel, 80-118 through the simple one; text in which a
+                                                          third of the positions match and two thirds pass level 1 is still faster through the filter kernel,
+                                                          137-168 against 65-120 GB/s: profiles/r03_experiments.md) */
 
 /* ---------------------------------------------------------------- lookups */
 
@@ -865,6 +882,7 @@ void pfac_scan_filter(ScanArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(lds.shift3));
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
+    bool freshChunk = false;                    /* level 1 of the staged chunk has just run: `hits` holds all of its hits */
     /* this lane's code of the list round that starts at entry `first` (wave-uniform); the address is computed on the spot */
     const uint32_t listBaseBytes = (uint32_t)(reinterpret_cast<unsigned char *>(list) - smem);
     auto listCode = [&](uint32_t first) -> uint32_t {
@@ -965,6 +983,7 @@ void pfac_scan_filter(ScanArgs a)
                     }
                 }
                 stagedBase = chunk * kChunkBytes;
+                freshChunk = true;
                 PFAC_TICK(3);
                 /* the chunk registers are free again: prefetch the next chunk.  Past the end the last chunk is
                  * loaded again, not nothing (it is never taken) */
@@ -987,13 +1006,22 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t idx = incl - cnt;
             PFAC_TICK(9);
+            const bool dense = !REDUCE && freshChunk && total > kDenseHits && a.denseList != nullptr;      /* wave-uniform */
+            if (dense) {
+                /* a pattern-dense chunk (most positions pass level 1: patterns of one or two bytes over text, a run of
+                 * one byte that is a pattern): listing, testing and queueing every position costs more than walking them
+                 * all.  The chunk goes on the launch's dense list and the simple kernel behind this one does it. */
+                if (lane == 0) a.denseList[part * a.denseSegment + atomicAdd(a.work + denseCountWord((int)part), 1u)] = stagedBase / (uint32_t)kChunkBytes;
+                hits = 0;
+            }
+            freshChunk = false;
             while (hits != 0 && idx < kListCap) {       /* divergent: as many rounds as the busiest lane has hits */
                 list[idx] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)__builtin_ctz(hits));
                 idx++;
                 hits &= hits - 1;
             }
             PFAC_TICK(10);
-            const uint32_t listed = total < kListCap ? total : kListCap;
+            const uint32_t listed = dense ? 0u : (total < kListCap ? total : kListCap);
             stHits += listed;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1116,6 +1144,7 @@ void pfac_scan_filter(ScanArgs a)
 /* One thread per input byte, no prefilter: the reference's algorithm with only the initial-state row
  * staged in LDS.  Alignment-agnostic, 64-bit positions.  Produces results for positions [0, owned);
  * walks may read up to a.n (owned <= n). */
+constexpr size_t kChunkBytesDev = (size_t)pfac::kChunkTiles * kTileBytes;
 template <int MODE>
 __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 {
@@ -1137,6 +1166,28 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
             }
         }
         a.out[j] = match;
+    }
+    /* the chunks the filter kernel in front of this launch found pattern-dense (ScanArgs::denseList): every position of
+     * a listed chunk, one per thread; walks read on into whatever follows the chunk */
+    if (a.denseList == nullptr) return;
+    for (int part = 0; part < pfac::kWorkParts; part++) {
+    const unsigned int listed = a.work[denseCountWord(part)];
+    for (unsigned int i = blockIdx.x; i < listed; i += gridDim.x) {
+        const size_t base = (size_t)a.denseList[(size_t)part * a.denseSegment + i] * kChunkBytesDev;
+        for (size_t j = base + threadIdx.x; j < base + kChunkBytesDev; j += 256) {
+            int state = sInit[a.denseIn[j]];
+            int match = 0;
+            if (state != kTrap) {
+                if (state <= a.numFinal) match = state;
+                for (size_t pos = j + 1; pos < a.denseReadable; pos++) {
+                    state = lookup(state, a.denseIn[pos]);
+                    if (state == kTrap) break;
+                    if (state <= a.numFinal) match = state;
+                }
+            }
+            a.denseOut[j] = match;
+        }
+    }
     }
 }
 
@@ -1165,9 +1216,13 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
 constexpr size_t kChunkBytesHost = (size_t)kGroupTiles * kTileBytes;
 size_t chunkBytes(const PFAC_context *) { return kChunkBytesHost; }
 
-/* The launch shape of an instantiation depends on the kernel and its LDS size only (fixed per loaded pattern
- * set): hipFuncSetAttribute and the occupancy query run once per (instantiation, LDS size), not per call. */
-struct ShapeCache { std::mutex lock; size_t lds = 0; int perCU = 0; };
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy answer are per DEVICE state of one kernel
+ * instantiation: a process that drives several GPUs (PFACX_matchFromHostMultiGPU: one thread and one handle per device)
+ * must set the attribute on each of them.  It is set to the whole CU once per (instantiation, device), so that no launch
+ * ever depends on what another handle with another pattern set asked for in between; the occupancy query runs with
+ * that size (a 1024-thread block with 128 registers per thread fills a CU by itself whatever its LDS). */
+constexpr int kMaxDevices = 64;
+struct ShapeCache { std::mutex lock; int perCU[kMaxDevices] = {}; };
 
 template <bool TEX, bool HAS_SHORT, bool REDUCE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
@@ -1175,20 +1230,23 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, PFAC_WALK_SETS>;
     static ShapeCache cache;
     const size_t lds = filterLdsBytes(c, REDUCE);
+    int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
+    hipError_t de = hipGetDevice(&dev);
+    if (de != hipSuccess) return de;
+    if (lds > kLdsPerCu || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidValue;
     int perCU;
     {
         std::lock_guard<std::mutex> g(cache.lock);
-        if (cache.lds != lds) {
+        if (cache.perCU[dev] == 0) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
             if (e != hipSuccess) return e;
             int n = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, kLdsPerCu);
             if (e != hipSuccess) return e;
-            cache.perCU = n < 1 ? 1 : n;
-            cache.lds = lds;
+            cache.perCU[dev] = n < 1 ? 1 : n;
         }
-        perCU = cache.perCU;
+        perCU = cache.perCU[dev];
     }
     const size_t numChunks = a.n / kChunkBytesHost;
     constexpr size_t scanners = REDUCE ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
@@ -1221,11 +1279,6 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
         fprintf(stderr, "\n");
     }
 #endif
-    /* PFACX_KERNEL_AUTO looks at the level-1 hit density of recent launches: their counters follow the kernel
-     * into pinned host memory, nobody waits for them */
-    if (e == hipSuccess && c->kernelVariant == PFACX_KERNEL_AUTO && c->h_statsPinned)
-        e = hipMemcpyAsync(c->h_statsPinned, c->d_workCounters + pfac::kStatsWord, pfac::kStatsCount * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, 0);
     return e;
 }
 
@@ -1235,6 +1288,8 @@ hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
     size_t blocks = (a.owned + 255) / 256;
     const size_t cap = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * 8;
     if (blocks > cap) blocks = cap;
+    if (a.denseList) blocks = cap;                                  /* a launch that may find a list of pattern-dense chunks: enough blocks to walk them
+                                                                       (they read the list's length and leave if it is empty) */
     hipLaunchKernelGGL(pfac_scan_naive<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
     return hipGetLastError();
 }
@@ -1310,15 +1365,6 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
         if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
-        /* pattern-dense input (most positions pass level 1, e.g. 1-byte patterns over text): the prefilter only adds
-         * work and the simple kernel is faster.  Judged by what recent launches on this handle saw; every 8th call
-         * takes the filter kernel anyway, so the estimate follows the data. */
-        if (c->h_statsPinned) {
-            const volatile unsigned long long *st = c->h_statsPinned;
-            const unsigned long long hits = st[3], positions = st[4];
-            PFAC_context *mc = const_cast<PFAC_context *>(c);
-            if (positions && (double)hits > pfac::kAutoDenseHitRate * (double)positions && (++mc->autoCalls & 7u) != 0) return 0;
-        }
     }
     const size_t margin = (size_t)c->fa.maxPatternLen + 32;
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
@@ -1329,6 +1375,22 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
 /* The vector kernel keeps byte positions in 32 bits: larger inputs are scanned as consecutive windows */
 constexpr size_t kMaxLaunchBytes = (size_t(1) << 32) - (size_t(1) << 24);
 
+/* The filter kernel reads the input 16 bytes per lane: it starts at the first 16-byte aligned input byte.  The (at most
+ * 15) positions in front of it go to the simple kernel, like the end of the input.  The result vector needs no alignment
+ * beyond that of an int (its 16-byte stores then straddle lines; a 1 KiB-per-instruction stream does not care). */
+size_t headPositions(const unsigned char *in, size_t input_size)
+{
+    const size_t head = (16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u;
+    return head < input_size ? head : input_size;
+}
+
+template <class Launch>
+hipError_t launchNaiveFor(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part, Launch &&)
+{
+    if (hashed) return tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
+    return tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
+}
+
 PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size, int *d_matched_result, bool hashed)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
@@ -1337,25 +1399,55 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     const PFAC_status_t st = fillArgs(c, hashed, d_input_string, input_size, d_matched_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
-    const bool vectorOk = ((reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+    const bool vectorOk = (reinterpret_cast<uintptr_t>(a.out) & 3u) == 0;       /* an int vector that is not int-aligned: simple kernel only */
     hipError_t e = hipSuccess;
-    for (size_t first = 0; first < input_size && e == hipSuccess; first += kMaxLaunchBytes) {
+    const size_t head = vectorOk ? headPositions(a.in, input_size) : 0;
+    if (head) {
+        ScanArgs part = a;
+        part.owned = head;
+        part.n = input_size;
+        e = launchNaiveFor(c, hashed, tex, part, 0);
+    }
+    for (size_t first = head; first < input_size && e == hipSuccess; first += kMaxLaunchBytes) {
         const size_t ownEnd = input_size - first < kMaxLaunchBytes ? input_size : first + kMaxLaunchBytes;
         const size_t mainLen = filterLength(c, first, ownEnd, input_size, vectorOk);
         ScanArgs part = a;
         part.in = a.in + first;
         part.out = a.out + first;
         if (mainLen) {
+            /* room for the list of pattern-dense chunks this launch may leave to the simple kernel: a grow-only buffer of
+             * the handle (the caller holds its lock) */
+            /* a part is dealt granules of 2^PFAC_FRONT_LOG2 spans round-robin: its share of the chunks, rounded up to whole granules */
+            const size_t granule = (size_t(1) << (PFAC_FRONT_LOG2 > 0 ? PFAC_FRONT_LOG2 : 0)) * kSpanChunks;
+            const size_t segment = ((mainLen / kChunkBytesHost + granule - 1) / granule + pfac::kWorkParts - 1) / pfac::kWorkParts * granule + granule;
+            const size_t chunks = segment * pfac::kWorkParts;
+            if (handle->denseListEntries < chunks) {
+                if (handle->d_denseList) (void)hipFree(handle->d_denseList);
+                handle->d_denseList = nullptr;
+                handle->denseListEntries = 0;
+                if (hipMalloc(reinterpret_cast<void **>(&handle->d_denseList), chunks * sizeof(unsigned int)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    handle->d_denseList = nullptr;
+                    return PFAC_STATUS_CUDA_ALLOC_FAILED;
+                }
+                handle->denseListEntries = chunks;
+            }
+            part.denseList = handle->d_denseList;
+            part.denseSegment = (unsigned int)segment;
             part.n = part.owned = mainLen;
             e = launchChained<false>(c, part, tex);
         }
-        if (e == hipSuccess && first + mainLen < ownEnd) {
-            part.in += mainLen;
-            part.out += mainLen;
-            part.owned = ownEnd - first - mainLen;
-            part.n = input_size - first - mainLen;
-            if (hashed) e = tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
-            else        e = tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
+        if (e == hipSuccess && (mainLen || first + mainLen < ownEnd)) {
+            /* the end of the input (bounds-checked), and the chunks the filter launch listed as pattern-dense */
+            ScanArgs rest = part;
+            rest.denseIn = part.in;
+            rest.denseOut = part.out;
+            rest.denseReadable = input_size - first;
+            rest.in = part.in + mainLen;
+            rest.out = part.out + mainLen;
+            rest.owned = ownEnd - first - mainLen;
+            rest.n = input_size - first - mainLen;
+            e = launchNaiveFor(c, hashed, tex, rest, 0);
         }
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
@@ -1404,15 +1496,47 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     unsigned int count = 0;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
 
-    const bool vectorOk = (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0;
-    const size_t mainLen = filterLength(c, 0, n, n, vectorOk);
+    /* positions [first, first + len) through the simple kernel: full results into the handle's scratch, compacted on
+     * the host and appended to the caller's arrays (the <= 15 positions in front of the first 16-byte aligned input
+     * byte, and the end of the input) */
+    auto simpleRange = [&](size_t first, size_t len) -> PFAC_status_t {
+        if (!len) return PFAC_STATUS_SUCCESS;
+        char *scratch = nullptr;
+        PFAC_status_t s2 = reduceScratch(handle, len * sizeof(int), &scratch);
+        if (s2 != PFAC_STATUS_SUCCESS) return s2;
+        int *d_full = reinterpret_cast<int *>(scratch);
+        ScanArgs part = a;
+        part.in = a.in + first;
+        part.out = d_full;
+        part.owned = len;
+        part.n = n - first;
+        if (launchNaiveFor(c, hashed, tex, part, 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        std::vector<int> full(len), ids, pos;
+        if (hipMemcpy(full.data(), d_full, len * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        for (size_t i = 0; i < len; i++)
+            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)(first + i)); }
+        if (!ids.empty() && (hipMemcpy(d_match_result + count, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(d_pos + count, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+            return PFAC_STATUS_INTERNAL_ERROR;
+        count += (unsigned int)ids.size();
+        return PFAC_STATUS_SUCCESS;
+    };
+
+    const size_t head = headPositions(a.in, n);
+    try {
+        st = simpleRange(0, head);
+    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    const size_t mainLen = filterLength(c, head, n, n, true);
     if (mainLen) {
         ScanArgs part = a;
+        part.in = a.in + head;
         part.n = part.owned = mainLen;
         part.reducePos = d_pos;
         part.reduceCount = c->d_reduceCount;
-        part.reduceBase = 0;
-        if (hipMemsetAsync(c->d_reduceCount, 0, sizeof(unsigned int), 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        part.reduceBase = (unsigned int)head;
+        /* the kernel appends behind the matches of the head */
+        if (hipMemcpyAsync(c->d_reduceCount, &count, sizeof(unsigned int), hipMemcpyHostToDevice, 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         hipError_t e;
         e = launchChained<true>(c, part, tex);
         if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
@@ -1422,7 +1546,9 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             unsigned int *keysIn = reinterpret_cast<unsigned int *>(d_pos);
             unsigned int *nullKeys = nullptr;
             int *nullVals = nullptr;
-            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, 32, 0) != hipSuccess)
+            unsigned int keyBits = 1;                      /* positions are below n: fewer digits to sort */
+            while (keyBits < 32 && (n - 1) >> keyBits) keyBits++;
+            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, keyBits, 0) != hipSuccess)
                 return PFAC_STATUS_INTERNAL_ERROR;
             /* scratch = sorted keys | sorted values | rocPRIM workspace, each 256-byte aligned */
             const size_t arrayBytes = ((size_t)count * sizeof(int) + 255) / 256 * 256;
@@ -1433,39 +1559,18 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             unsigned int *keysOut = reinterpret_cast<unsigned int *>(base);
             int *valuesOut = reinterpret_cast<int *>(base + arrayBytes);
             void *temp = base + 2 * arrayBytes;
-            hipError_t se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, 32, 0);
+            hipError_t se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, keyBits, 0);
             if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
             if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
             if (se == hipSuccess) se = hipStreamSynchronize(0);
             if (se != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
         }
     }
-    if (mainLen < n) {
-        /* the rest: full results into a scratch vector, compacted on the host */
-        const size_t rest = n - mainLen;
-        char *scratch = nullptr;
-        st = reduceScratch(handle, rest * sizeof(int), &scratch);        /* the sort above is finished: same scratch */
-        if (st != PFAC_STATUS_SUCCESS) return st;
-        int *d_full = reinterpret_cast<int *>(scratch);
-        ScanArgs part = a;
-        part.in = a.in + mainLen;
-        part.out = d_full;
-        part.n = part.owned = rest;
-        hipError_t e;
-        if (hashed) e = tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
-        else        e = tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
-        std::vector<int> full(rest), ids, pos;
-        st = e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
-        if (st == PFAC_STATUS_SUCCESS && hipMemcpy(full.data(), d_full, rest * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-            st = PFAC_STATUS_INTERNAL_ERROR;
-        if (st != PFAC_STATUS_SUCCESS) return st;
-        for (size_t i = 0; i < rest; i++)
-            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)(mainLen + i)); }
-        if (!ids.empty() && (hipMemcpy(d_match_result + count, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemcpy(d_pos + count, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
-            return PFAC_STATUS_INTERNAL_ERROR;
-        count += (unsigned int)ids.size();
-    }
+    /* the rest: its positions follow all others (the sort above is finished: same scratch) */
+    try {
+        st = simpleRange(head + mainLen, n - head - mainLen);
+    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    if (st != PFAC_STATUS_SUCCESS) return st;
     *h_num_matched = (int)count;
     if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;

@@ -89,14 +89,15 @@ def rank_input(cfg, n: int, rank: int, world: int, max_pattern_len: int):
     return buf, n
 
 
-def all_gather_facts(values, device=None):
+def all_gather_facts(values, device=None, force=False):
     """All-gather a short list of int64 facts from every rank (RCCL on GPU, gloo on CPU).
-    Returns a [world, len(values)] numpy array; no-op for a single process."""
+    Returns a [world, len(values)] numpy array; no-op for a single process unless `force` (then the collective runs
+    with a world of one: the same RCCL code path on a machine with one GPU)."""
     import numpy as np
     import torch
     import torch.distributed as dist
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return t.cpu().numpy()[None, :]
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)

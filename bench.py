@@ -73,7 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--size-mib", type=int, default=1024, help="input bytes per GPU, MiB")
-    ap.add_argument("--variant", default="filter", choices=["filter", "naive"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "filter", "naive"],
+                    help="auto = the library default (PFACX_KERNEL_AUTO: what a drop-in PFAC.h caller gets; the filter kernel at bench sizes)")
     ap.add_argument("--texture", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--perf-mode", default=None, choices=[None, "dense", "hash"])
     ap.add_argument("--platform", default="gpu", choices=["gpu", "cpu_omp"],
@@ -349,8 +350,9 @@ class Run:
             self.handle.setPlatform(api.PFAC_PLATFORM_CPU_OMP)
         self.handle.setPerfMode(self.perf_mode)
         self.handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[texture])
-        self.variant = api.PFACX_KERNEL_FILTER if args.variant == "filter" else api.PFACX_KERNEL_NAIVE
-        self.handle.setKernelVariant(self.variant)
+        self.variant = {"auto": api.PFACX_KERNEL_AUTO, "filter": api.PFACX_KERNEL_FILTER, "naive": api.PFACX_KERNEL_NAIVE}[args.variant]
+        if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
+            self.handle.setKernelVariant(self.variant)
         self.handle.readPatternFromFile(self.pattern_file)
         self.info = self.handle.info()
         # slice `rank` of the N x size stream plus the head of the next slice (generators are prefix-stable)
@@ -443,6 +445,37 @@ class Run:
         self.handle.destroy()
 
 
+def kernel_name(args, run):
+    """The kernel a launch of this run goes to (the library default takes the filter kernel from 1 MiB up)."""
+    if args.variant == "naive" or (args.variant == "auto" and run.n_read < (1 << 20)):
+        return "pfac_scan_naive"
+    return "pfac_scan_filter"
+
+
+def walker_table(args, run):
+    """What the kernel walks: the filter kernel walks the device-only chained table in BOTH perf modes; only the simple
+    kernel walks the reference-layout table that `table` names."""
+    return "chained (device-only, both perf modes)" if kernel_name(args, run) == "pfac_scan_filter" else ("hashed" if run.perf_mode else "dense")
+
+
+_BUILD = None
+
+
+def build_info():
+    """Compile-time shape of the kernel module (PFACX_buildInfo of libpfac_gfx950.so)."""
+    global _BUILD
+    if _BUILD is None:
+        import ctypes as C
+        from pfac_amd import api
+        try:
+            mod = C.CDLL(api.library_paths()[1])
+            mod.PFACX_buildInfo.restype = C.c_char_p
+            _BUILD = mod.PFACX_buildInfo().decode()
+        except (OSError, AttributeError):
+            _BUILD = "unknown"
+    return _BUILD
+
+
 def roofline_block(kernel_ms, n_read, kname):
     avg_s = float(np.mean(kernel_ms)) / 1e3
     achieved = ALGO_BYTES_PER_INPUT_BYTE * n_read / avg_s / 1e9
@@ -471,8 +504,9 @@ def other_configs(args, device, buffers):
         run.step()
         ok, method, pos, _ = run.verify(args, 0, 1)
         ms, _ = run.timed(OTHER_STEPS, 2, 8)
-        r = roofline_block(ms, run.n_read, "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive")
-        entry = {"workload": run.cfg.description, "table": "hashed" if run.perf_mode else "dense",
+        r = roofline_block(ms, run.n_read, kernel_name(args, run))
+        entry = {"workload": run.cfg.description.replace("dense table", "hashed table") if run.perf_mode else run.cfg.description,
+                 "table": "hashed" if run.perf_mode else "dense", "walker_table": walker_table(args, run),
                  "texture_mode": int(run.handle.info().textureMode), "steps": OTHER_STEPS,
                  "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_min": r["kernel_ms_min"], "frac": r["frac"],
                  "input_GBps": round(run.n_read / (r["kernel_ms_avg"] / 1e3) / 1e9, 1),
@@ -563,6 +597,13 @@ def rank_main(args):
     # that run up to 15 % slower.  SETTLE_STEPS untimed launches precede the W warmup steps.
     kernel_ms, elapsed = run.timed(args.steps, args.warmup, SETTLE_STEPS if gpu else 0, barrier)
     log(f"[bench r{rank}] timed region done {time.perf_counter() - t_setup:.1f}s")
+    # the result of the LAST timed launch, checked like the first (a match lost under back-to-back launches at full clocks
+    # would otherwise go unnoticed: the zeros come from other waves than the matches)
+    if not args.no_verify:
+        pos2, ids2 = run.sparse()
+        if not (np.array_equal(pos2, pos) and np.array_equal(ids2, ids)):
+            log(f"[bench r{rank}] RESULT OF THE LAST TIMED LAUNCH DIFFERS")
+            ok = False
 
     # ---- gather per-rank facts (RCCL: 5 x int64 per rank) ----------------------------------------
     allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
@@ -585,7 +626,7 @@ def rank_main(args):
         if ranks_seen != list(range(world)):
             all_ok = False
         n = run.n
-        kname = "pfac_scan_filter" if args.variant == "filter" else "pfac_scan_naive"
+        kname = kernel_name(args, run)
         out = {
             "metric": "input GB/s scanned (PFAC_matchFromDevice, bit-exact)" if gpu else
                       "input GB/s scanned (DRY RUN on the CPU_OMP platform, not the metric)",
@@ -598,7 +639,9 @@ def rank_main(args):
                             + (f", slices overlap {sharding.overlap_bytes(info.maxPatternLen)} B" if world > 1 else ""),
                 "patterns": info.numOfPatterns, "states": info.numOfStates,
                 "table": "hashed" if run.perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
-                "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "platform": args.platform,
+                "walker_table": walker_table(args, run),
+                "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname,
+                "build": build_info(), "platform": args.platform,
                 "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
                 "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if use_dist else None,
                 "folded_result": {"match_count": total_matches, "checksum": folded & 0x7FFFFFFFFFFFFFFF},
@@ -616,19 +659,31 @@ def rank_main(args):
             d_pos = torch.empty_like(run.d_out)
             run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
             torch.cuda.synchronize()
+            from pfac_amd import hiprt
+            rev = [(hiprt.Event(), hiprt.Event()) for _ in range(5)]
             t0r = time.perf_counter()
-            for _ in range(5):
+            for ea, eb in rev:
+                ea.record(0)
                 _, rcount = run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
+                eb.record(0)
             torch.cuda.synchronize()
             tr = (time.perf_counter() - t0r) / 5
+            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel + sort + copies, on the launch stream
             rp = d_pos[:rcount].cpu().numpy().astype(np.int64)
             ri = run.d_out[:rcount].cpu().numpy()
             keep = rp < n
             same = bool(np.array_equal(rp[keep], pos) and np.array_equal(ri[keep], ids))
+            algo = int(run.n_read + 8 * rcount)
             out["reduce_api"] = {"value": round(run.n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
+                                 "gpu_ms": round(gpu_ms, 4), "host_overhead_ms": round(tr * 1e3 - gpu_ms, 4),
                                  "matches": int(rcount), "same_result_as_full_vector": same,
-                                 "algorithmic_bytes_per_call": int(run.n_read + 8 * rcount),
-                                 "note": "PFAC_matchFromDeviceReduce incl. count readback; ~1 B/input byte of HBM traffic"}
+                                 "pairs_checksum": int(sharding.position_checksum(rp[keep], ri[keep])), "full_vector_checksum": int(checksum),
+                                 "algorithmic_bytes_per_call": algo,
+                                 "roofline": {"bound": "hbm", "achieved": round(algo / (gpu_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(algo / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: scan kernel, sort by position, copies); "
+                                                      "the scan kernel alone is in profiles/ (rocprofv3 kernel stats); this path is bound by the scanning waves' instruction issue, not by HBM"},
+                                 "note": "PFAC_matchFromDeviceReduce, synchronous (the match count returns to the host); ~1 B of HBM traffic per input byte"}
             if not same:
                 all_ok = False
                 out["config"]["bit_exact"] = False
@@ -646,6 +701,11 @@ def rank_main(args):
                         saved = (run.d_in, run.d_out)
                         run.d_in, run.d_out = b_in, b_out
                         ms, _ = run.timed(10, 2, 8)
+                        p3, i3 = run.sparse()
+                        if not (np.array_equal(p3, pos) and np.array_equal(i3, ids)):
+                            all_ok = False
+                            out["config"]["bit_exact"] = False
+                            log(f"[bench] result differs on buffer pair {name_in}/{name_out}")
                         run.d_in, run.d_out = saved
                         spread[f"input {name_in} / result {name_out} allocation"] = round(float(np.mean(ms)), 4)
                 out["roofline"]["placement_spread_kernel_ms"] = spread
@@ -670,6 +730,23 @@ def rank_main(args):
                     host_path[kind] = {"input_GBps": round(hn / th / 1e9, 2), "ms_per_call": round(th * 1e3, 3),
                                        "same_result": bool(np.array_equal(hp, pos[keep]))}
                     del h_in, h_out
+                # what bounds it: the upload (1 B per position over the link) and the zero fill of the caller's vector by
+                # the call's helper threads (4 B per position of host memory bandwidth)
+                probe_in = torch.from_numpy(run.host_in[:hn].copy()).pin_memory()
+                torch.cuda.synchronize()
+                t0h = time.perf_counter()
+                for _ in range(3):
+                    run.d_in[:hn].copy_(probe_in, non_blocking=True)
+                torch.cuda.synchronize()
+                host_path["link_h2d_GBps_pinned"] = round(3 * hn / (time.perf_counter() - t0h) / 1e9, 1)
+                fill = np.empty(hn, dtype=np.int32)
+                fill.fill(1)
+                t0h = time.perf_counter()
+                fill.fill(0)
+                host_path["host_zero_fill_GBps_one_thread"] = round(4 * hn / (time.perf_counter() - t0h) / 1e9, 1)
+                host_path["bound"] = "per position: 1 B over the host link + 4 B of zero fill in host memory (2-8 helper threads) + the pairs of the matches; " \
+                                     "the scan of a 32 Mi-position piece runs beside the upload of the next"
+                del probe_in, fill
                 out["host_path_pcie_inclusive"] = host_path
             # What this part sustains for the traffic shape of the path with nothing else in it ("also
             # measure a 1R:4W streaming kernel as the achievable ceiling and report both"): pfac_stream_1r4w of the
@@ -763,7 +840,7 @@ def orchestrate(args, argv):
                 rc = rc or 1
         except Exception:
             log(f"[bench] CPU baseline worker failed (rc {p.returncode})")
-    if single and args.pmc == "auto" and args.variant == "filter":
+    if single and args.pmc == "auto" and args.variant != "naive":
         common = ["--workload", args.workload, "--size-mib", str(args.size_mib), "--texture", args.texture, "--no-verify"]
         if args.perf_mode:
             common += ["--perf-mode", args.perf_mode]
@@ -776,7 +853,7 @@ def orchestrate(args, argv):
             out["roofline"]["traffic_detail"] = traffic
         else:
             out["roofline"]["traffic_note"] = src
-    if single and args.pmc == "auto" and args.variant == "filter" and out["roofline"]["traffic"] is None \
+    if single and args.pmc == "auto" and args.variant != "naive" and out["roofline"]["traffic"] is None \
             and args.size_mib == 1024 and args.perf_mode is None:      # the PMC passes of this run failed: last committed profile
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = committed_traffic(args.workload, out["roofline"]["kernel"])
     print(json.dumps(out), flush=True)

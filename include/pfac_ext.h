@@ -30,6 +30,19 @@ PFAC_status_t PFACX_createHostOnly(PFAC_handle_t *handle);
  * previously loaded set.  The buffer is copied. */
 PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patterns, size_t size);
 
+/* The two readers with options (defined behaviour for what the reference does silently).
+ *   PFACX_READ_STRICT    bytes behind the last '\n' -- a last line without a newline, which the reference drops without
+ *                        a word (PFAC_reorder_Table.cpp:181-195) -- are PFAC_STATUS_INVALID_PARAMETER.  Without the flag
+ *                        they are ignored as in the reference, and PFACX_getInfo reports how many there were
+ *                        (trailingBytesIgnored).
+ *   PFACX_READ_STRIP_CR  "\r\n" line ends: the '\r' is not part of the pattern (the reference keeps it: user guide r1.2
+ *                        p.15 item 5).  A '\r' elsewhere in a line stays.
+ * flags == 0 is exactly PFAC_readPatternFromFile / PFACX_readPatternFromMemory. */
+#define PFACX_READ_STRICT   1u
+#define PFACX_READ_STRIP_CR 2u
+PFAC_status_t PFACX_readPatternFromFileEx(PFAC_handle_t handle, const char *filename, unsigned int flags);
+PFAC_status_t PFACX_readPatternFromMemoryEx(PFAC_handle_t handle, const char *patterns, size_t size, unsigned int flags);
+
 typedef struct {
     int numOfPatterns;        /* F                                             */
     int numOfStates;          /* includes the unused state 0 (ref PFAC.cpp:704) */
@@ -59,6 +72,7 @@ typedef struct {
     size_t ladderGoOns;       /* ... and as "go on: test the next prefix length"                             */
     int ladderThin;           /* nodes with at most this many patterns below them are stops ...             */
     int ladderExtend;         /* ... this many levels further down                                          */
+    size_t trailingBytesIgnored; /* bytes behind the last '\n' of the pattern file that were ignored (0: none)  */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);

@@ -54,6 +54,10 @@ PFAC_status_t PFAC_reduce_inplace_kernel(PFAC_handle_t handle, int *d_input_stri
  * bench.py reports it next to the scan as "what this part sustains for 1 B read : 4 B written" (SURVEY 8d). */
 double PFACX_streamProbe(const void *d_in, void *d_out, size_t n, int launches);
 
+/* Measurement only: the compile-time shape of this module (block size, writer waves, walk sets, queue and list capacity,
+ * front geometry, ablation / timing builds) as one static string for the bench record. */
+const char *PFACX_buildInfo(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ PFAC_AUTOMATIC, PFAC_TEXTURE_ON, PFAC_TEXTURE_OFF = 0, 1, 2
 PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO = 0, 1, 2
+PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
@@ -62,6 +63,7 @@ class PFACX_info(C.Structure):
         ("filterLog2BitsLadder", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSetLadder", C.c_size_t),
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
+        ("trailingBytesIgnored", C.c_size_t),
     ]
 
 
@@ -82,11 +84,11 @@ EXPORTED_SYMBOLS = (
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
-    "PFACX_matchFromHostMultiGPU",
+    "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
-    "PFAC_reduce_kernel", "PFAC_reduce_inplace_kernel", "PFACX_streamProbe",
+    "PFAC_reduce_kernel", "PFAC_reduce_inplace_kernel", "PFACX_streamProbe", "PFACX_buildInfo",
 )
 
 
@@ -125,6 +127,8 @@ def load_library() -> C.CDLL:
     lib.PFACX_getTable.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
+    lib.PFACX_readPatternFromFileEx.argtypes = [H, C.c_char_p, C.c_uint]
+    lib.PFACX_readPatternFromMemoryEx.argtypes = [H, C.c_char_p, C.c_size_t, C.c_uint]
     lib.PFACX_getScanStats.argtypes = [H, C.POINTER(PFACX_scan_stats)]
     lib.PFACX_saveCompiled.argtypes = [H, C.c_char_p]
     lib.PFACX_loadCompiled.argtypes = [H, C.c_char_p]
@@ -223,6 +227,14 @@ class PFAC:
     def readPatternFromMemory(self, data: bytes, check: bool = True) -> int:
         """``PFACX_readPatternFromMemory``: the pattern-file bytes without a file."""
         return self._ret(self._lib.PFACX_readPatternFromMemory(self._h, data, len(data)), "PFACX_readPatternFromMemory", check)
+
+    def readPatternFromFileEx(self, filename, flags: int, check: bool = True) -> int:
+        """``PFACX_readPatternFromFileEx``: flags = PFACX_READ_STRICT | PFACX_READ_STRIP_CR."""
+        name = None if filename is None else os.fsencode(filename)
+        return self._ret(self._lib.PFACX_readPatternFromFileEx(self._h, name, flags), "PFACX_readPatternFromFileEx", check)
+
+    def readPatternFromMemoryEx(self, data: bytes, flags: int, check: bool = True) -> int:
+        return self._ret(self._lib.PFACX_readPatternFromMemoryEx(self._h, data, len(data), flags), "PFACX_readPatternFromMemoryEx", check)
 
     def saveCompiled(self, filename, check: bool = True) -> int:
         """``PFACX_saveCompiled``: the compiled pattern set (trie, tables, prefilter) to a file."""

@@ -105,7 +105,7 @@ private:
 
 } // namespace
 
-PFAC_status_t compilePatternFile(const char *filename, Automaton &fa)
+PFAC_status_t compilePatternFile(const char *filename, Automaton &fa, unsigned int flags)
 {
     fa = Automaton();
     if (!filename) return PFAC_STATUS_INVALID_PARAMETER;
@@ -122,15 +122,28 @@ PFAC_status_t compilePatternFile(const char *filename, Automaton &fa)
     size_t got = fsz ? std::fread(bytes.data(), 1, (size_t)fsz, fp) : 0;
     std::fclose(fp);
     bytes.resize(got);
-    return compilePatternBytes(std::move(bytes), fa);
+    return compilePatternBytes(std::move(bytes), fa, flags);
 }
 
 /* the pattern-file format from memory: one pattern per '\n'-terminated line (PFAC_reorder_Table.cpp:121-231) */
-PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa)
+PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa, unsigned int flags)
 {
     fa = Automaton();
+    if (flags & PFACX_READ_STRIP_CR) {              /* "\r\n" line ends: the '\r' is not part of the pattern (the reference keeps it, user guide r1.2 p.15 item 5) */
+        size_t w = 0;
+        for (size_t i = 0; i < bytes.size(); i++)
+            if (!(bytes[i] == '\r' && i + 1 < bytes.size() && bytes[i + 1] == '\n')) bytes[w++] = bytes[i];
+        bytes.resize(w);
+    }
     fa.file = std::move(bytes);
     const size_t got = fa.file.size();
+    {   /* bytes behind the last newline: the reference counts newline-terminated lines only and silently drops them
+         * (PFAC_reorder_Table.cpp:181-195); so does this build, but it says so (PFACX_getInfo) or refuses (PFACX_READ_STRICT) */
+        size_t last = got;
+        while (last > 0 && fa.file[last - 1] != '\n') last--;
+        fa.trailingBytes = got - last;
+        if ((flags & PFACX_READ_STRICT) && fa.trailingBytes) return PFAC_STATUS_INVALID_PARAMETER;
+    }
 
     /* split into lines; `start` only moves past a NON-empty line (ref :181-190),
      * so a blank line poisons the next pattern -- reported, not asserted. */

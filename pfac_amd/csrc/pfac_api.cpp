@@ -356,15 +356,16 @@ PFAC_status_t PFAC_dumpTransitionTable(PFAC_handle_t handle, FILE *fp)
     return PFAC_STATUS_SUCCESS;
 }
 
-PFAC_status_t PFAC_readPatternFromFile(PFAC_handle_t handle, char *filename)
+static PFAC_status_t readFromFile(PFAC_handle_t handle, const char *filename, unsigned int flags)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!filename) return PFAC_STATUS_INVALID_PARAMETER;
+    if (!filename || (flags & ~(PFACX_READ_STRICT | PFACX_READ_STRIP_CR))) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     if (handle->isPatternsReady) freeResources(handle);            /* ref PFAC.cpp:663-666 */
     if (std::strlen(filename) >= (size_t)pfac::kFileNameLen) return PFAC_STATUS_INTERNAL_ERROR;  /* ref :668-672 */
     handle->patternFile = filename;
 
-    PFAC_status_t st = pfac::compilePatternFile(filename, handle->fa);
+    PFAC_status_t st = pfac::compilePatternFile(filename, handle->fa, flags);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(handle); return st; }
     handle->isPatternsReady = true;
     st = bindCommon(handle);
@@ -373,16 +374,16 @@ PFAC_status_t PFAC_readPatternFromFile(PFAC_handle_t handle, char *filename)
     return PFAC_STATUS_SUCCESS;
 }
 
-/* pfac_ext.h: the same pattern-file bytes from memory instead of from a file (SURVEY 8f rank 3) */
-PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patterns, size_t size)
+static PFAC_status_t readFromMemory(PFAC_handle_t handle, const char *patterns, size_t size, unsigned int flags)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!patterns && size) return PFAC_STATUS_INVALID_PARAMETER;
+    if ((!patterns && size) || (flags & ~(PFACX_READ_STRICT | PFACX_READ_STRIP_CR))) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     if (handle->isPatternsReady) freeResources(handle);
     handle->patternFile.clear();
     PFAC_status_t st;
     try {
-        st = pfac::compilePatternBytes(std::vector<unsigned char>(patterns, patterns + size), handle->fa);
+        st = pfac::compilePatternBytes(std::vector<unsigned char>(patterns, patterns + size), handle->fa, flags);
     } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
     if (st != PFAC_STATUS_SUCCESS) { freeResources(handle); return st; }
     handle->isPatternsReady = true;
@@ -390,6 +391,18 @@ PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patt
     if (st == PFAC_STATUS_SUCCESS) st = bindTable(handle);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(handle); return st; }
     return PFAC_STATUS_SUCCESS;
+}
+
+PFAC_status_t PFAC_readPatternFromFile(PFAC_handle_t handle, char *filename) { return readFromFile(handle, filename, 0); }
+
+/* pfac_ext.h: the same pattern-file bytes from memory instead of from a file (SURVEY 8f rank 3) */
+PFAC_status_t PFACX_readPatternFromMemory(PFAC_handle_t handle, const char *patterns, size_t size) { return readFromMemory(handle, patterns, size, 0); }
+
+/* pfac_ext.h: ... with options: strict about a last line without a newline, CRLF line ends */
+PFAC_status_t PFACX_readPatternFromFileEx(PFAC_handle_t handle, const char *filename, unsigned int flags) { return readFromFile(handle, filename, flags); }
+PFAC_status_t PFACX_readPatternFromMemoryEx(PFAC_handle_t handle, const char *patterns, size_t size, unsigned int flags)
+{
+    return readFromMemory(handle, patterns, size, flags);
 }
 
 } /* extern "C" */
@@ -769,6 +782,7 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
     info->ladderGoOns = handle->filter.ladderGoOns;
     info->ladderThin = handle->filter.ladderThin;
     info->ladderExtend = handle->filter.ladderExtend;
+    info->trailingBytesIgnored = handle->fa.trailingBytes;
     info->chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
     info->chainSlots = handle->h_chainSlots.size();
     info->multiProcessorCount = handle->multiProcessorCount;

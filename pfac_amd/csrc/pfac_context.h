@@ -69,6 +69,7 @@ struct Automaton {
     std::vector<int> patternLen;              /* [F+1] by ID ([0] = 0)                           */
     std::vector<int> sortedId;                /* [F] IDs in (signed-char, prefix-first) order    */
     int maxPatternLen = 0;
+    size_t trailingBytes = 0;                 /* bytes behind the last '\n' of the pattern file: ignored, like the reference ignores them */
     int initialState = 0;                     /* F+1                                             */
     int numStates = 0;                        /* next unused id; counts unused state 0           */
     int numLeaves = 0;

@@ -9,8 +9,8 @@
 namespace pfac {
 
 /* pattern_compiler.cpp */
-PFAC_status_t compilePatternFile(const char *filename, Automaton &fa);
-PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa);
+PFAC_status_t compilePatternFile(const char *filename, Automaton &fa, unsigned int flags = 0);
+PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa, unsigned int flags = 0);   /* flags: PFACX_READ_* */
 void buildInitialRow(const Automaton &fa, std::vector<int> &row);
 void buildFilter(const Automaton &fa, Filter &f);
 

@@ -1599,6 +1599,16 @@ __global__ __launch_bounds__(256) void pfac_stream_1r4w(const u32x4 *in, i32x4 *
 
 extern "C" {
 
+/* compile-time shape of this module, for the bench record */
+#define PFAC_STR2(x) #x
+#define PFAC_STR(x) PFAC_STR2(x)
+const char *PFACX_buildInfo(void)
+{
+    return "gfx950 block=" PFAC_STR(PFAC_BLOCK_THREADS) " writers=" PFAC_STR(PFAC_WRITERS) " walk_sets=" PFAC_STR(PFAC_WALK_SETS) " queue=" PFAC_STR(PFAC_QUEUE_CAP)
+           " list=" PFAC_STR(PFAC_LIST_CAP) " span_log2=" PFAC_STR(PFAC_SPAN_LOG2) " front_log2=" PFAC_STR(PFAC_FRONT_LOG2) " parts=" PFAC_STR(PFAC_WORK_PARTS)
+           " refill_min=" PFAC_STR(PFAC_REFILL_MIN) " ablate=" PFAC_STR(PFAC_ABLATE) " timing=" PFAC_STR(PFAC_TIMING);
+}
+
 /* average milliseconds of `launches` back-to-back launches of pfac_stream_1r4w over the first n (a multiple of 4096)
  * bytes of d_in, 4 n bytes of d_out are overwritten with zeros; < 0: a HIP error */
 double PFACX_streamProbe(const void *d_in, void *d_out, size_t n, int launches)

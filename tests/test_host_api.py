@@ -186,6 +186,40 @@ def test_pattern_file_quirks(tmp_path):
 from tests.filter_model import prefilter_model       # noqa: E402
 
 
+def test_strict_and_crlf_readers(tmp_path):
+    """PFACX_readPatternFromFileEx / ...MemoryEx: a last line without a newline is dropped like in the
+    reference (PFAC_reorder_Table.cpp:181-195) but reported, or refused with PFACX_READ_STRICT; PFACX_READ_STRIP_CR takes
+    "\\r\\n" line ends (the reference keeps the CR, user guide r1.2 p.15); flags 0 == the plain readers."""
+    h = api.PFAC.createHostOnly()
+    try:
+        assert h.readPatternFromMemory(b"AB\nCD\nEF") == 0
+        assert h.info().numOfPatterns == 2 and h.info().trailingBytesIgnored == 2
+        assert h.readPatternFromMemoryEx(b"AB\nCD\nEF", api.PFACX_READ_STRICT, check=False) == api.STATUS.INVALID_PARAMETER
+        buf = np.zeros(4, dtype=np.int32)
+        assert h.matchFromHost(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.PATTERNS_NOT_READY     # a refused load leaves nothing behind
+        assert h.readPatternFromMemoryEx(b"AB\nCD\nEF\n", api.PFACX_READ_STRICT) == 0
+        assert h.info().numOfPatterns == 3 and h.info().trailingBytesIgnored == 0
+        # CRLF: without the flag the CR belongs to the pattern (and "EF\r" does not match "EF "), with it the set is {AB, C\rD, EF}
+        crlf = b"AB\r\nC\rD\r\nEF\r\n"
+        data = np.frombuffer(b"xxAByyC\rDzzEF EF\rq", dtype=np.uint8)
+        assert h.readPatternFromMemory(crlf) == 0 and h.info().maxPatternLen == 4
+        assert list(np.flatnonzero(h.match_host_array(data))) == [14]                  # only "EF\r"
+        assert h.readPatternFromMemoryEx(crlf, api.PFACX_READ_STRIP_CR) == 0 and h.info().maxPatternLen == 3
+        got = h.match_host_array(data)
+        assert list(np.flatnonzero(got)) == [2, 6, 11, 14] and list(got[[2, 6, 11, 14]]) == [1, 2, 3, 3]
+        assert h.readPatternFromMemoryEx(crlf[:-1], api.PFACX_READ_STRIP_CR | api.PFACX_READ_STRICT, check=False) == api.STATUS.INVALID_PARAMETER
+        assert h.readPatternFromMemoryEx(b"AB\n", 4, check=False) == api.STATUS.INVALID_PARAMETER                # unknown flag
+        # the file reader takes the same flags
+        p = tmp_path / "crlf.pat"
+        p.write_bytes(crlf + b"GH")
+        assert h.readPatternFromFileEx(str(p), api.PFACX_READ_STRIP_CR) == 0
+        assert h.info().numOfPatterns == 3 and h.info().trailingBytesIgnored == 2
+        assert h.readPatternFromFileEx(str(p), api.PFACX_READ_STRICT, check=False) == api.STATUS.INVALID_PARAMETER
+        assert h.readPatternFromFileEx(str(tmp_path / "missing"), 0, check=False) == api.STATUS.FILE_OPEN_ERROR
+    finally:
+        h.destroy()
+
+
 @pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
 def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     """Every position with a non-zero result passes level 1 and the prefix ladder as the kernel evaluates them."""

@@ -437,6 +437,12 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #define PFAC_LIST_CAP 128
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
+#ifndef PFAC_REDUCE_LADDER_LEVELS
+#define PFAC_REDUCE_LADDER_LEVELS 0            /* ladder levels behind depth 4 that the compacted-output kernel tests (8 = all of them): that kernel is bound by
+                                                * instruction issue, not by the memory system, and there a walk is cheaper than the levels that would spare it
+                                                * (C3 0.97 / 0.96 / 0.93 / 0.90 ms per call with 8 / 4 / 2 / 0 levels, C5 1.37 / 1.28 / 1.22 / 1.16) */
+#endif
+constexpr int kReduceLadderLevels = PFAC_REDUCE_LADDER_LEVELS;
 #ifndef PFAC_PATCH_STAGED
 #define PFAC_PATCH_STAGED 0                    /* full-result kernel: 1 = finished matches are staged per wave in LDS and stored kReduceCap at a time */
 #endif
@@ -944,7 +950,12 @@ void pfac_scan_filter(ScanArgs a)
                     uint32_t follow;                   /* lane 0: the dword behind this tile */
                     if (tt == 0) takeTile0(dt, follow);
                     else takeTile1(dt, follow);
-                    reinterpret_cast<u32x4 *>(stage)[tt * 64 + lane] = dt;
+                    {   /* the lane's place in the stage, computed on the spot (see the halo below) */
+                        uint32_t at16;
+                        const uint32_t tileBase = (uint32_t)(reinterpret_cast<unsigned char *>(stage) - smem) + (uint32_t)tt * (uint32_t)kTileBytes;
+                        asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(at16) : "v"(lane), "s"(tileBase));
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(at16) = dt;
+                    }
                     if (tt == kTilesPerIter - 1 && lane < 8) {
                         /* the address is computed on the spot (volatile: not hoisted out of the loop into a register
                          * that lives -- or is spilled -- across it) */
@@ -965,20 +976,26 @@ void pfac_scan_filter(ScanArgs a)
                     constexpr int kBatch = 8;
 #pragma unroll
                     for (int b0 = 0; b0 < 16; b0 += kBatch) {
-                        uint32_t word[kBatch], xs[kBatch];
+                        uint32_t word[kBatch], xs[kBatch + 1];
 #pragma unroll
                         for (int q = 0; q < kBatch; q++) {
                             const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
                             const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
                             /* bytes pos..pos+2 in the low 24 bits (the multiply ignores the rest) */
                             const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
+                            /* dword of the 3-gram: the top bits of the 24 x 24 -> 32 bit product, as a byte address.  (The high half of
+                             * the 48-bit product -- one v_mul_hi_u32_u24 and an AND -- would save an instruction, but the first byte of
+                             * the gram hardly reaches it: level-1 hits went from 5 % to 18 % of the text stream.) */
                             const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
                             word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
                             xs[q] = x;
                         }
+                        /* the second bit of a 3-gram is numbered by the low five bits of its SECOND byte: the first byte of the
+                         * next position -- whose gram (or whose raw dword) is at hand, no shift needed */
+                        xs[kBatch] = b0 + kBatch < 16 ? dw[(b0 + kBatch) >> 2] : nxtLane;
 #pragma unroll
                         for (int q = 0; q < kBatch; q++)
-                            hits = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> ((xs[q] >> 8) & 31u)), hits, 1);   /* both bits of the 3-gram (low five bits of its first and of its second byte) set: bit 0 enters at the top */
+                            hits = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> (xs[q + 1] & 31u)), hits, 1);   /* both bits set: bit 0 enters at the top */
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1077,6 +1094,7 @@ void pfac_scan_filter(ScanArgs a)
             uint32_t xw = 0;
 #pragma unroll
             for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
+                if (REDUCE && lv > kReduceLadderLevels) break;      /* the compacted-output kernel stops early: see kReduceLadderLevels */
                 if (__ballot(und != 0) == 0) break;
                 if (lv & 1) {                                       /* bytes 4k .. 4k+3 of the candidate serve two levels */
                     const uint32_t eHi = stage[at + (lv + 3) / 2];
@@ -1089,6 +1107,7 @@ void pfac_scan_filter(ScanArgs a)
                 if (lv == pfac::kLadderLevels - 1) und = 0;          /* the last level has S nodes only */
                 else und &= testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & ~sHit;
             }
+            if (REDUCE) walk |= und;                                /* undecided after the last level tested: walk */
 #if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
             walk = (((o * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? walk : 0u;
 #endif

@@ -889,6 +889,7 @@ void pfac_scan_filter(ScanArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     bool freshChunk = false;                    /* level 1 of the staged chunk has just run: `hits` holds all of its hits */
+    uint32_t ladderIdle = 0, ladderSkip = 0;    /* wave-uniform: batches in a row that the ladder did not thin out / batches left to walk untested */
     /* this lane's code of the list round that starts at entry `first` (wave-uniform); the address is computed on the spot */
     const uint32_t listBaseBytes = (uint32_t)(reinterpret_cast<unsigned char *>(list) - smem);
     auto listCode = [&](uint32_t first) -> uint32_t {
@@ -965,7 +966,8 @@ void pfac_scan_filter(ScanArgs a)
                         *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(at) = follow;
                     }
                     const uint32_t dw[4] = {dt.x, dt.y, dt.z, dt.w};
-                    uint32_t nxtLane = (uint32_t)__shfl_down((int)dw[0], 1);
+                    /* the first dword of the next lane: one DPP move (wave_shl:1), no lane-number register for a bpermute */
+                    uint32_t nxtLane = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw[0], 0x130, 0xf, 0xf, false);
                     const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)follow);
                     if (lane == 63) nxtLane = wrap;
                     /* kBatch positions at a time (that many LDS reads in flight); the scheduling barrier keeps the
@@ -1092,6 +1094,12 @@ void pfac_scan_filter(ScanArgs a)
             uint32_t walk = act ? (code >> 15) & 1u : 0u;
             uint32_t und = act ? walk ^ 1u : 0u;                    /* undecided: a G node so far */
             uint32_t xw = 0;
+            /* Input that follows the patterns deeper than the ladder looks (near misses of long patterns: BASELINE config 5)
+             * passes every level: the ladder then only costs.  A wave whose last four batches each spared less than an eighth
+             * of their undecided candidates walks the next 28 batches' candidates untested, then looks again. */
+            const uint32_t und0 = (uint32_t)__popcll(__ballot(und != 0));
+            const bool skipLadder = !REDUCE && ladderSkip != 0;
+            if (skipLadder) { ladderSkip--; walk |= und; und = 0; }
 #pragma unroll
             for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
                 if (REDUCE && lv > kReduceLadderLevels) break;      /* the compacted-output kernel stops early: see kReduceLadderLevels */
@@ -1108,6 +1116,11 @@ void pfac_scan_filter(ScanArgs a)
                 else und &= testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & ~sHit;
             }
             if (REDUCE) walk |= und;                                /* undecided after the last level tested: walk */
+            if (!REDUCE && !skipLadder && und0 >= 16u) {
+                const uint32_t walked = (uint32_t)__popcll(__ballot(walk != 0)) - (take - und0);           /* of the und0 that were undecided (the other take - und0 walk anyway) */
+                ladderIdle = (und0 - walked) * 8u < und0 ? ladderIdle + 1u : 0u;
+                if (ladderIdle >= 4u) { ladderIdle = 0; ladderSkip = 28; }
+            }
 #if PFAC_ABLATE >= 3          /* timing experiment: walk only a fraction of the candidates (results are wrong) */
             walk = (((o * 2654435761u) >> 28) < (PFAC_ABLATE - 2) * 4u) ? walk : 0u;
 #endif

@@ -115,6 +115,12 @@ PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename);
 PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename);
 
+/* The handle keeps its device temporaries between calls (the reference allocates and frees them per call,
+ * PFAC.cpp:920-958): two staging sets of PFAC_matchFromHost (about 9 B per position of a 32 Mi-position piece), the copies
+ * of PFAC_matchFromHostReduce (9 B per input byte), sort scratch.  PFACX_trim frees them; the next call that needs one
+ * allocates it again.  The pattern set and its tables stay. */
+PFAC_status_t PFACX_trim(PFAC_handle_t handle);
+
 /* One call shards a host stream over several GPUs of the node (reference users write this
  * themselves after PFAC/test/omp_PFAC.cpp:257-394): one worker thread and one internal handle per entry of
  * `devices` (NULL = devices 0..numDevices-1; numDevices 0 = every visible device), contiguous slices scanned

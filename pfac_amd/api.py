@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = (
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
-    "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx",
+    "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -127,6 +127,7 @@ def load_library() -> C.CDLL:
     lib.PFACX_getTable.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
+    lib.PFACX_trim.argtypes = [H]
     lib.PFACX_readPatternFromFileEx.argtypes = [H, C.c_char_p, C.c_uint]
     lib.PFACX_readPatternFromMemoryEx.argtypes = [H, C.c_char_p, C.c_size_t, C.c_uint]
     lib.PFACX_getScanStats.argtypes = [H, C.POINTER(PFACX_scan_stats)]
@@ -227,6 +228,10 @@ class PFAC:
     def readPatternFromMemory(self, data: bytes, check: bool = True) -> int:
         """``PFACX_readPatternFromMemory``: the pattern-file bytes without a file."""
         return self._ret(self._lib.PFACX_readPatternFromMemory(self._h, data, len(data)), "PFACX_readPatternFromMemory", check)
+
+    def trim(self, check: bool = True) -> int:
+        """``PFACX_trim``: free the handle's grow-only device temporaries."""
+        return self._ret(self._lib.PFACX_trim(self._h), "PFACX_trim", check)
 
     def readPatternFromFileEx(self, filename, flags: int, check: bool = True) -> int:
         """``PFACX_readPatternFromFileEx``: flags = PFACX_READ_STRICT | PFACX_READ_STRIP_CR."""

@@ -10,6 +10,7 @@
  * (scan_gfx950.hip).
  */
 #include <dlfcn.h>
+#include <sched.h>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
@@ -281,6 +282,7 @@ PFAC_status_t PFAC_setPlatform(PFAC_handle_t handle, PFAC_platform_t platform)
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (platform != PFAC_PLATFORM_GPU && platform != PFAC_PLATFORM_CPU && platform != PFAC_PLATFORM_CPU_OMP)
         return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     handle->platform = (int)platform;
     return PFAC_STATUS_SUCCESS;
 }
@@ -290,6 +292,7 @@ PFAC_status_t PFAC_setTextureMode(PFAC_handle_t handle, PFAC_textureMode_t textu
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (textureModeSel != PFAC_AUTOMATIC && textureModeSel != PFAC_TEXTURE_ON && textureModeSel != PFAC_TEXTURE_OFF)
         return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     handle->textureMode = (int)textureModeSel;
     return PFAC_STATUS_SUCCESS;
 }
@@ -298,6 +301,7 @@ PFAC_status_t PFAC_setPerfMode(PFAC_handle_t handle, PFAC_perfMode_t perfModeSel
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (perfModeSel != PFAC_TIME_DRIVEN && perfModeSel != PFAC_SPACE_DRIVEN) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     const bool rebuild = handle->isPatternsReady && (int)perfModeSel != handle->perfMode;
     handle->perfMode = (int)perfModeSel;
     if (rebuild) {                                         /* ref PFAC.cpp:794-814 */
@@ -511,16 +515,19 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
     /* zero fill of the caller's vector, in parallel with everything below */
     unsigned helpers = 0;
     if (owned >= (size_t(4) << 20)) {
-        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t allowed;                                 /* the cores this thread may run on (a caller bound to a cpuset: fewer than the machine has) */
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) hw = (unsigned)CPU_COUNT(&allowed);
         helpers = hw >= 64 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
     }
     std::vector<std::thread> fillers;
     try {
+        fillers.reserve(helpers);
         for (unsigned t = 0; t < helpers; t++) {
             const size_t lo = owned * t / helpers, hi = owned * (t + 1) / helpers;
             fillers.emplace_back([=]() { std::memset(h_matched_result + lo, 0, (hi - lo) * sizeof(int)); });
         }
-    } catch (const std::system_error &) { /* fewer helpers than planned: the rest is filled below */ }
+    } catch (...) { /* no memory for the vector, or fewer threads than planned: what the helpers started do not cover is filled below */ }
     const size_t filledByHelpers = fillers.empty() ? 0 : owned * fillers.size() / helpers;
     auto joinAll = [&]() { for (std::thread &t : fillers) if (t.joinable()) t.join(); };
 
@@ -951,13 +958,12 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     std::fclose(fp);
     if (!ok || fnv1a64(payload.data(), payload.size()) != h.payloadFnv1a) return PFAC_STATUS_INVALID_PARAMETER;   /* not a compiled set of this build, or damaged */
 
-    std::lock_guard<std::mutex> guard(handle->lock);
-    PFAC_context *c = handle;
-    if (c->isPatternsReady) freeResources(c);
-    c->patternFile = filename;
-    c->perfMode = (int)h.perfMode;
-    pfac::Automaton &fa = c->fa;
-    pfac::Filter &f = c->filter;
+    /* everything is parsed and checked in temporaries: a refused file leaves the handle as it was */
+    pfac::Automaton fa;
+    pfac::Filter f;
+    std::vector<Int2> hashRow, hashVal;
+    std::vector<pfac::ChainSlot> chain;
+    std::vector<int> initialRow;
     std::vector<int32_t> scalars;
     std::vector<uint64_t> filt;
     try {
@@ -982,10 +988,10 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
             case kSecLadder: ok = takeSection(p, bytes, f.ladder); break;
             case kSecFinal3: ok = takeSection(p, bytes, f.final3); break;
             case kSecShort: ok = takeSection(p, bytes, f.shortBits); break;
-            case kSecHashRow: ok = takeSection(p, bytes, c->h_hashRow); break;
-            case kSecHashVal: ok = takeSection(p, bytes, c->h_hashVal); break;
-            case kSecChain: ok = takeSection(p, bytes, c->h_chainSlots); break;
-            case kSecInitialRow: ok = takeSection(p, bytes, c->h_initialRow); break;
+            case kSecHashRow: ok = takeSection(p, bytes, hashRow); break;
+            case kSecHashVal: ok = takeSection(p, bytes, hashVal); break;
+            case kSecChain: ok = takeSection(p, bytes, chain); break;
+            case kSecInitialRow: ok = takeSection(p, bytes, initialRow); break;
             default: break;                                    /* unknown section of a later writer: skipped */
             }
             at += (size_t)bytes;
@@ -1006,28 +1012,70 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
                  ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 8192u : 0u) <= pfac::kFilterLdsBudget &&
                  f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.ladder.size() == (size_t(1) << f.log2BitsLad) / 32 &&
                  f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
-                 c->h_initialRow.size() == (size_t)pfac::kCharSet &&
+                 initialRow.size() == (size_t)pfac::kCharSet &&
                  h.jumpLog2 >= (uint32_t)pfac::kJumpLog2Min && h.jumpLog2 <= (uint32_t)pfac::kJumpLog2Max &&
-                 c->h_chainSlots.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
-                 (h.perfMode == PFAC_TIME_DRIVEN || c->h_hashRow.size() == S);
-            if (ok) c->chainJumpLog2 = (int)h.jumpLog2;
+                 chain.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
+                 (h.perfMode == PFAC_TIME_DRIVEN || hashRow.size() == S);
             for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0;
             for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S;
-            /* a slot's bucket must lie inside the slot array: the walker indexes it without a bound on the global path */
-            const size_t slots = c->h_chainSlots.size();
+            /* what the kernels and the host path take on trust: the longest pattern (overlap of pieces and slices, the
+             * safety margin at the end of the input), the pattern lengths and offsets, the initial state's row */
+            int longest = 0;
+            for (size_t id = 1; ok && id <= F; id++) {
+                ok = fa.patternLen[id] >= 1 && fa.patternOff[id] >= 0 && (size_t)fa.patternOff[id] + (size_t)fa.patternLen[id] <= fa.file.size();
+                longest = fa.patternLen[id] > longest ? fa.patternLen[id] : longest;
+            }
+            ok = ok && fa.maxPatternLen == longest;
+            for (size_t i = 0; ok && i < initialRow.size(); i++) ok = initialRow[i] == pfac::kTrapState || (initialRow[i] > 0 && (size_t)initialRow[i] < S);
+            /* a slot's bucket must lie inside the slot array (the walker indexes it without a bound on the global path),
+             * a final slot's pattern ID must be one */
+            const size_t slots = chain.size();
             auto slotOk = [&](const pfac::ChainSlot &sl) {
-                if (sl.meta & (pfac::kSlotEmpty | pfac::kSlotLeaf)) return true;
+                if (sl.meta & pfac::kSlotEmpty) return true;
+                if (sl.meta & pfac::kSlotLeaf) return !(sl.meta & pfac::kSlotFinal) || (sl.endRow >= 1 && (size_t)sl.endRow <= F);
                 const size_t sizeMask = sl.meta >> 24;
-                return sl.endRow >= 0 && (size_t)sl.endRow + sizeMask < slots;
+                int id = 1;
+                if (sl.meta & pfac::kSlotFinal) std::memcpy(&id, sl.chain + 4, sizeof(int));
+                return sl.endRow >= 0 && (size_t)sl.endRow + sizeMask < slots && id >= 1 && (size_t)id <= F;
             };
-            for (size_t i = 0; ok && i < slots; i++) ok = slotOk(c->h_chainSlots[i]);
+            for (size_t i = 0; ok && i < slots; i++) ok = slotOk(chain[i]);
         }
-    } catch (const std::bad_alloc &) { freeResources(c); return PFAC_STATUS_ALLOC_FAILED; }
-    if (!ok) { freeResources(c); return PFAC_STATUS_INVALID_PARAMETER; }
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+    if (!ok) return PFAC_STATUS_INVALID_PARAMETER;
+
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    if (c->isPatternsReady) freeResources(c);
+    c->patternFile = filename;
+    c->perfMode = (int)h.perfMode;
+    c->fa = std::move(fa);
+    c->filter = std::move(f);
+    c->h_hashRow = std::move(hashRow);
+    c->h_hashVal = std::move(hashVal);
+    c->h_chainSlots = std::move(chain);
+    c->h_initialRow = std::move(initialRow);
+    c->chainJumpLog2 = (int)h.jumpLog2;
     c->isPatternsReady = true;
     PFAC_status_t st = bindCommon(c, /*build=*/false);
     if (st == PFAC_STATUS_SUCCESS) st = bindTable(c);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(c); return st; }
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* pfac_ext.h: give back the grow-only device buffers of the handle (staging of PFAC_matchFromHost, copies of
+ * PFAC_matchFromHostReduce, sort scratch, the dense-chunk list); the next call that needs one allocates it again */
+PFAC_status_t PFACX_trim(PFAC_handle_t handle)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    std::lock_guard<std::mutex> guard(handle->lock);
+    freeHostStage(handle);
+    devFree(handle->d_reduceScratch);
+    handle->reduceScratchBytes = 0;
+    devFree(handle->d_hostReduce);
+    handle->hostReduceBytes = 0;
+    devFree(handle->d_denseList);
+    handle->denseListEntries = 0;
+    for (auto &child : handle->children) if (child.second) (void)PFACX_trim(child.second);
     return PFAC_STATUS_SUCCESS;
 }
 
@@ -1037,6 +1085,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     if (!stats) return PFAC_STATUS_INVALID_PARAMETER;
     std::memset(stats, 0, sizeof(*stats));
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    std::lock_guard<std::mutex> guard(handle->lock);
     if (!handle->hasDevice || !handle->d_workCounters) return PFAC_STATUS_LIB_NOT_EXIST;
     unsigned long long v[pfac::kStatsCount];
     if (hipStreamSynchronize(nullptr) != hipSuccess ||
@@ -1058,6 +1107,7 @@ PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (variant != PFACX_KERNEL_FILTER && variant != PFACX_KERNEL_NAIVE && variant != PFACX_KERNEL_AUTO) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
     handle->kernelVariant = variant;
     return PFAC_STATUS_SUCCESS;
 }

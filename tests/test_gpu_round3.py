@@ -114,10 +114,11 @@ def test_multi_gpu_driver_on_every_visible_device(workdir):
     o.close()
     h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC)
     try:
-        for devices in (list(range(ndev)), list(range(ndev)) * 2):
+        for devices in (list(range(ndev)), list(range(ndev)) * 2, list(range(ndev))):
             got = np.full(n, -3, dtype=np.int32)
             h.matchFromHostMultiGPU(data.ctypes.data, n, got.ctypes.data, devices)
             assert np.array_equal(got, want), f"devices {devices}"
+            h.trim()                                              # PFACX_trim: the staging buffers come back on the next call
     finally:
         h.destroy()
         torch.cuda.set_device(0)

@@ -319,6 +319,9 @@ def test_compiled_set_round_trip_on_the_host(workloads, oracle_results, tmp_path
     for bad in (raw[: len(raw) // 2], raw[:100] + bytes([raw[100] ^ 0x40]) + raw[101:], b"NOTPFACX" + raw[8:], b""):
         open(path, "wb").write(bad)
         assert b.loadCompiled(path, check=False) == api.STATUS.INVALID_PARAMETER
+        # a refused file leaves the handle as it was: same perf mode, same patterns, same results
+        assert b.info().perfMode == (api.PFAC_SPACE_DRIVEN if perf == api.PFAC_TIME_DRIVEN else api.PFAC_TIME_DRIVEN)
+        assert np.array_equal(b.match_host_array(w.data), oracle_results[name])
     assert a.saveCompiled(str(tmp_path / "no_such_dir" / "x"), check=False) == api.STATUS.FILE_OPEN_ERROR
     a.destroy()
     b.destroy()

@@ -700,7 +700,7 @@ def rank_main(args):
                     for name_out, b_out in (("first", run.d_out), ("second", alt_out)):
                         saved = (run.d_in, run.d_out)
                         run.d_in, run.d_out = b_in, b_out
-                        ms, _ = run.timed(10, 2, 8)
+                        ms, _ = run.timed(10, 2, SETTLE_STEPS)      # the check of the previous pair left the GPU idle: same settling as the headline
                         p3, i3 = run.sparse()
                         if not (np.array_equal(p3, pos) and np.array_equal(i3, ids)):
                             all_ok = False

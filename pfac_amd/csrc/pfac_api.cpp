@@ -1093,11 +1093,9 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
         return PFAC_STATUS_INTERNAL_ERROR;
     stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
     stats->ladderCandidates = v[5];
-    for (int part = 0; part < pfac::kWorkParts; part++) {    /* scan_gfx950.hip denseCountWord(part): one counter line per input part */
-        unsigned int dense = 0;
-        if (hipMemcpy(&dense, handle->d_workCounters + (32 + part) * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        stats->denseChunks += dense;
-    }
+    unsigned int dense = 0;                                  /* scan_gfx950.hip kDenseCountWord: counter line 32 */
+    if (hipMemcpy(&dense, handle->d_workCounters + 32 * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    stats->denseChunks = dense;
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = PFAC_WALK_SETS;
     return PFAC_STATUS_SUCCESS;

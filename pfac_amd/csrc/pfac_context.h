@@ -32,7 +32,7 @@ constexpr int kFileNameLen = 256;             /* ref FILENAME_LEN, PFAC_P.h:34 *
 
 struct Int2 { int x, y; };                    /* device layout of the hashed tables (CUDA int2) */
 #ifndef PFAC_WORK_PARTS
-#define PFAC_WORK_PARTS 16
+#define PFAC_WORK_PARTS 2
 #endif
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
 constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */

@@ -138,17 +138,16 @@ struct ScanArgs {
     /* pattern-dense chunks (full-result path): the filter kernel lists the chunks in which most positions pass level 1
      * instead of filtering them; the simple kernel that follows it (the launch that also scans the end of the input)
      * walks their positions one per thread.  denseIn / denseOut / denseReadable describe the filter launch the chunk
-     * numbers refer to.  The list has one segment of denseSegment entries per input part (blocks that share a claim
-     * counter share a segment), filled through the part's own counter a.work[denseCountWord(part)]: one counter for
-     * the whole launch would saturate at ~90 appends per microsecond, 1.5 ms for 256 MiB of pattern-dense input. */
+     * numbers refer to.  The list's length is a.work[kDenseCountWord]; a wave appends 16 chunks at a time (one device
+     * counter answers ~90 atomics per microsecond: an append per chunk cost 1.5 ms for 256 MiB of pattern-dense input). */
     unsigned int *denseList;
-    unsigned int denseSegment;
     const unsigned char *denseIn;
     int *denseOut;
     size_t denseReadable;
 };
-constexpr int denseCountWord(int part) { return (32 + part) * 32; }   /* the launch counters are one 128-byte line per part: lines 0..31 hand out
-                                                                         the input (at most 32 parts), lines 32..63 count the parts' dense chunks */
+constexpr int kDenseCountWord = 32 * 32;                /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
+                                                          line 32 counts the dense chunks (zeroed with the rest before every launch) */
+constexpr uint32_t kDenseStage = 16;                    /* dense chunks a wave collects in LDS before it appends them to the list */
 constexpr uint32_t kDenseHits = 1843;                  /* of the 2048 positions of a chunk: above 90 % the prefilter only adds work.  (Input in which every
                                                           position matches: 40 GB/s through the filter kernel, 80-118 through the simple one; text in which a
                                                           third of the positions match and two thirds pass level 1 is still faster through the filter kernel,
@@ -454,7 +453,7 @@ constexpr uint32_t kReduceQueueCap = kQueueCap;
  * counter each; G >= 0 = one moving front: granules of 2^G pieces are dealt round-robin to the parts, so
  * all parts work inside one window of parts << G pieces that sweeps the input once. */
 #ifndef PFAC_FRONT_LOG2
-#define PFAC_FRONT_LOG2 2
+#define PFAC_FRONT_LOG2 4
 #endif
 
 /* Zero-fill by dedicated WRITER waves (full-result kernel only).  The API writes 4 bytes per input byte, almost
@@ -535,6 +534,7 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t *sStageAll = sQueueBAll + kScanners * kQCap * 2;            /* per scanning wave: the chunk being filtered + the 32 bytes behind it */
     uint32_t *sListAll = sStageAll + kScanners * kStageWords;            /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
     uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
+    uint32_t *sDenseAll = sReduceAll + ((REDUCE || kStagedPatch) ? kScanners * 2 * kReduceCap : 0);   /* full-result kernel: per-wave staging of dense chunk numbers */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* the level-1 bitmap is addressed by number: sGram3 must sit at LDS address 0 */
@@ -889,6 +889,22 @@ void pfac_scan_filter(ScanArgs a)
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     bool freshChunk = false;                    /* level 1 of the staged chunk has just run: `hits` holds all of its hits */
+    uint32_t *sDense = sDenseAll + wave * kDenseStage;     /* pattern-dense chunks of this wave, not yet on the launch's list */
+    uint32_t nDense = 0;
+    auto flushDense = [&]() {                   /* wave-uniform control flow */
+        if (nDense == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(a.work + kDenseCountWord, nDense);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < nDense) {
+            uint32_t at;                                   /* computed on the spot: not an address the compiler keeps (or spills) across the scan loop */
+            asm volatile("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(at) : "v"(lane), "s"((uint32_t)(reinterpret_cast<unsigned char *>(sDense) - smem)));
+            a.denseList[base + lane] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(at);
+        }
+        nDense = 0;
+    };
     uint32_t ladderIdle = 0, ladderSkip = 0;    /* wave-uniform: batches in a row that the ladder did not thin out / batches left to walk untested */
     /* this lane's code of the list round that starts at entry `first` (wave-uniform); the address is computed on the spot */
     const uint32_t listBaseBytes = (uint32_t)(reinterpret_cast<unsigned char *>(list) - smem);
@@ -1030,7 +1046,9 @@ void pfac_scan_filter(ScanArgs a)
                 /* a pattern-dense chunk (most positions pass level 1: patterns of one or two bytes over text, a run of
                  * one byte that is a pattern): listing, testing and queueing every position costs more than walking them
                  * all.  The chunk goes on the launch's dense list and the simple kernel behind this one does it. */
-                if (lane == 0) a.denseList[part * a.denseSegment + atomicAdd(a.work + denseCountWord((int)part), 1u)] = stagedBase / (uint32_t)kChunkBytes;
+                if (lane == 0) sDense[nDense] = stagedBase / (uint32_t)kChunkBytes;
+                nDense++;
+                if (nDense == kDenseStage) flushDense();
                 hits = 0;
             }
             freshChunk = false;
@@ -1147,6 +1165,7 @@ void pfac_scan_filter(ScanArgs a)
     if (ablateSink == 0x12345u) a.out[0] = 1;
 #endif
     if (REDUCE || kStagedPatch) flushStaged();
+    if (!REDUCE && a.denseList != nullptr) flushDense();
 #if PFAC_TIMING
     if (lane == 0)
         for (int k = 0; k < 12; k++) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 8 + k, (unsigned long long)tm[k]);
@@ -1202,10 +1221,9 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
     /* the chunks the filter kernel in front of this launch found pattern-dense (ScanArgs::denseList): every position of
      * a listed chunk, one per thread; walks read on into whatever follows the chunk */
     if (a.denseList == nullptr) return;
-    for (int part = 0; part < pfac::kWorkParts; part++) {
-    const unsigned int listed = a.work[denseCountWord(part)];
+    const unsigned int listed = a.work[kDenseCountWord];
     for (unsigned int i = blockIdx.x; i < listed; i += gridDim.x) {
-        const size_t base = (size_t)a.denseList[(size_t)part * a.denseSegment + i] * kChunkBytesDev;
+        const size_t base = (size_t)a.denseList[i] * kChunkBytesDev;
         for (size_t j = base + threadIdx.x; j < base + kChunkBytesDev; j += 256) {
             int state = sInit[a.denseIn[j]];
             int match = 0;
@@ -1220,7 +1238,6 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
             a.denseOut[j] = match;
         }
     }
-    }
 }
 
 /* ------------------------------------------------------------- launching */
@@ -1228,7 +1245,7 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 /* the CU's 160 KiB: the prefilter bitmaps (<= kFilterLdsBudget, pattern_compiler.cpp) + control block + per scanning wave a
  * walk queue (24 B per entry), the staged chunk and the hit list (+ the pair staging of the compacted-output variant) */
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * 24 + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0));
+constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * 24 + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
 constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
 static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + (kScannerLdsFull > kScannerLdsReduce ? kScannerLdsFull : kScannerLdsReduce) <= kLdsPerCu,
               "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
@@ -1242,6 +1259,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     bytes += kControlWords * sizeof(uint32_t);
     bytes += scanners * ((reduce ? kReduceQueueCap : kQueueCap) * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
     if (reduce || kStagedPatch) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
+    if (!reduce) bytes += scanners * kDenseStage * sizeof(uint32_t);
     return bytes;
 }
 
@@ -1449,10 +1467,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         if (mainLen) {
             /* room for the list of pattern-dense chunks this launch may leave to the simple kernel: a grow-only buffer of
              * the handle (the caller holds its lock) */
-            /* a part is dealt granules of 2^PFAC_FRONT_LOG2 spans round-robin: its share of the chunks, rounded up to whole granules */
-            const size_t granule = (size_t(1) << (PFAC_FRONT_LOG2 > 0 ? PFAC_FRONT_LOG2 : 0)) * kSpanChunks;
-            const size_t segment = ((mainLen / kChunkBytesHost + granule - 1) / granule + pfac::kWorkParts - 1) / pfac::kWorkParts * granule + granule;
-            const size_t chunks = segment * pfac::kWorkParts;
+            const size_t chunks = mainLen / kChunkBytesHost;
             if (handle->denseListEntries < chunks) {
                 if (handle->d_denseList) (void)hipFree(handle->d_denseList);
                 handle->d_denseList = nullptr;
@@ -1465,7 +1480,6 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
                 handle->denseListEntries = chunks;
             }
             part.denseList = handle->d_denseList;
-            part.denseSegment = (unsigned int)segment;
             part.n = part.owned = mainLen;
             e = launchChained<false>(c, part, tex);
         }

@@ -465,7 +465,7 @@ constexpr uint32_t kReduceQueueCap = kQueueCap;
  * published spans from an LDS ticket counter and only ever store matches, on top of zeros that are already in
  * L2 (same CU, same L2: ordered).  Writers run at most kRunAhead spans ahead of the scanners. */
 #ifndef PFAC_WRITERS
-#define PFAC_WRITERS 2
+#define PFAC_WRITERS 3
 #endif
 #ifndef PFAC_SPAN_LOG2
 #define PFAC_SPAN_LOG2 2

@@ -2,7 +2,7 @@
 # tools/measure_round.sh <tag>  -- the measurement set committed under profiles/ each round (GPU box only):
 # bench lines (each with its own PMC traffic passes and CPU baseline), rocprofv3 kernel stats of the same
 # workload run as a single rank, the 2-rank dry run.  Everything under `timeout`.
-T=${1:-r02}; O=gpurun_out/$T; mkdir -p $O; export TMPDIR=/tmp
+T=${1:-r03}; O=gpurun_out/$T; mkdir -p $O; export TMPDIR=/tmp
 timeout 600 python bench.py > $O/bench_c3_default.json 2> $O/bench_c3_default.err
 timeout 400 python bench.py --workload c2 --no-other-configs > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 400 python bench.py --workload c5 --no-other-configs > $O/bench_c5_dense.json 2> $O/bench_c5_dense.err

@@ -436,6 +436,9 @@ constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 b
 #define PFAC_LIST_CAP 128
 #endif
 constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more level-1 hits in one chunk take another round */
+#ifndef PFAC_REDUCE_PARTS
+#define PFAC_REDUCE_PARTS 32                    /* claim counters of the compacted-output kernel (its waves claim granules of chunks themselves) */
+#endif
 #ifndef PFAC_REDUCE_LADDER_LEVELS
 #define PFAC_REDUCE_LADDER_LEVELS 0            /* ladder levels behind depth 4 that the compacted-output kernel tests (8 = all of them): that kernel is bound by
                                                 * instruction issue, not by the memory system, and there a walk is cheaper than the levels that would spare it
@@ -728,7 +731,7 @@ void pfac_scan_filter(ScanArgs a)
     /* parts: few for the full-result kernel (a narrow front: 16 parts ran 1 % (Snort-style) to 4 % (random patterns)
      * faster than 32, 64 were 2..4 % slower), more for the compacted-output kernel, whose waves claim single chunks
      * and would queue up at the counters */
-    constexpr uint32_t kParts = REDUCE ? 32u : (uint32_t)pfac::kWorkParts;
+    constexpr uint32_t kParts = REDUCE ? (uint32_t)PFAC_REDUCE_PARTS : (uint32_t)pfac::kWorkParts;
     const uint32_t parts = gridDim.x < kParts ? gridDim.x : kParts;
     const uint32_t part = blockIdx.x % parts;
     constexpr bool kFrontOn = PFAC_FRONT_LOG2 >= 0;
@@ -1594,7 +1597,10 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             int *nullVals = nullptr;
             unsigned int keyBits = 1;                      /* positions are below n: fewer digits to sort */
             while (keyBits < 32 && (n - 1) >> keyBits) keyBits++;
-            if (rocprim::radix_sort_pairs(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, keyBits, 0) != hipSuccess)
+            /* rocPRIM sorts fewer than 2^20 items with a merge sort: a block sort and ten merge passes, 0.14 ms for the
+             * 583 K pairs of the bench stream.  Onesweep from 2^16 items on: four digit passes */
+            using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+            if (rocprim::radix_sort_pairs<SortConfig>(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, keyBits, 0) != hipSuccess)
                 return PFAC_STATUS_INTERNAL_ERROR;
             /* scratch = sorted keys | sorted values | rocPRIM workspace, each 256-byte aligned */
             const size_t arrayBytes = ((size_t)count * sizeof(int) + 255) / 256 * 256;
@@ -1605,7 +1611,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
             unsigned int *keysOut = reinterpret_cast<unsigned int *>(base);
             int *valuesOut = reinterpret_cast<int *>(base + arrayBytes);
             void *temp = base + 2 * arrayBytes;
-            hipError_t se = rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, keyBits, 0);
+            hipError_t se = rocprim::radix_sort_pairs<SortConfig>(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, keyBits, 0);
             if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
             if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
             if (se == hipSuccess) se = hipStreamSynchronize(0);

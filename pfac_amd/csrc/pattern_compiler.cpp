@@ -332,7 +332,7 @@ void buildFilter(const Automaton &fa, Filter &f)
     f.log2BitsF3 = sizeLog2(len3, 10, 13);
     f.log2BitsLad = 19;
     auto total = [&]() {
-        return ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (anyShort ? 65536 / 8 : 0);
+        return kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (anyShort ? 65536 / 8 : 0);   /* level 1 has its 32 KiB whatever its size */
     };
     while (total() > kFilterLdsBudget) {
         if (f.log2BitsLad > 17) f.log2BitsLad--;

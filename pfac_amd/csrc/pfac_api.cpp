@@ -1009,7 +1009,7 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
                  fa.edgeBegin.size() == S + 1 && fa.edgeCh.size() == fa.edgeNext.size() && !fa.edgeBegin.empty() &&
                  (size_t)fa.edgeBegin.back() == fa.edgeCh.size() &&
                  f.log2Bits >= 13 && f.log2Bits <= 18 && f.log2BitsLad >= 13 && f.log2BitsLad <= 19 && f.log2BitsF3 >= 10 && f.log2BitsF3 <= 13 &&
-                 ((size_t(1) << f.log2Bits) + (size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 8192u : 0u) <= pfac::kFilterLdsBudget &&
+                 pfac::kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 8192u : 0u) <= pfac::kFilterLdsBudget &&
                  f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.ladder.size() == (size_t(1) << f.log2BitsLad) / 32 &&
                  f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
                  initialRow.size() == (size_t)pfac::kCharSet &&
@@ -1097,7 +1097,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     if (hipMemcpy(&dense, handle->d_workCounters + 32 * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     stats->denseChunks = dense;
     stats->tilesPerChunk = pfac::kChunkTiles;
-    stats->walksPerLane = PFAC_WALK_SETS;
+    stats->walksPerLane = PFAC_WALK_SETS_FULL;        /* of the full-result kernel; the compacted-output kernel runs PFAC_WALK_SETS */
     return PFAC_STATUS_SUCCESS;
 }
 

@@ -40,7 +40,10 @@ constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of 
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS
-#define PFAC_WALK_SETS 2                       /* independent walks per lane */
+#define PFAC_WALK_SETS 2                       /* independent walks per lane, compacted-output kernel (every candidate behind the level-4 test walks there) */
+#endif
+#ifndef PFAC_WALK_SETS_FULL
+#define PFAC_WALK_SETS_FULL 1                  /* ... full-result kernel: behind the prefix ladder one walk per lane keeps up, and is 1 % (C3) to 5 % (C5) faster */
 #endif
 constexpr int kChunkTiles = 2;                 /* KiB of input a wave stages at a time */
 constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
@@ -54,6 +57,7 @@ struct ChainSlot {
     unsigned char chain[8];                   /* chain bytes, zero padded; if the end state is final and
                                                  has successors: <= 3 chain bytes, pattern ID in [4..7]  */
 };
+constexpr size_t kGram3LdsBytes = 32 * 1024;     /* LDS set aside for the level-1 bitmap (2^18 bits at most): the ladder behind it sits at a compile-time address */
 constexpr size_t kFilterLdsBudget = 97 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp); the rest of the
                                                     CU's 160 KiB is the scanning waves' queues and stages (scan_gfx950.hip checks the sum) */
 constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state                         */

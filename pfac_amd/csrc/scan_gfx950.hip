@@ -104,6 +104,7 @@ constexpr int kTrap = pfac::kTrapState;
 constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kTileBytes = 1024;              /* input bytes one wave-wide 16 B/lane load covers */
+constexpr uint32_t kLadderLdsOffset = (uint32_t)pfac::kGram3LdsBytes;  /* LDS: [0, 32 KiB) the level-1 bitmap (at most 2^18 bits), then the prefix ladder */
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -525,7 +526,8 @@ void pfac_scan_filter(ScanArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words3 = 1 << (a.log2Bits - 5), wordsLad = 1 << (a.log2BitsLad - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *sLadder = sGram3 + words3;
+    uint32_t *sLadder = sGram3 + kLadderLdsOffset / 4;          /* at a compile-time address whatever the size of the level-1 bitmap: a ladder probe's
+                                                                  ds_read takes it as its immediate offset */
     uint32_t *sFinal3 = sLadder + wordsLad;
     uint32_t *sShort = sFinal3 + wordsF3;
     constexpr int kWriters = REDUCE ? 0 : PFAC_WRITERS;             /* the compacted-output variant has no zeros to write */
@@ -568,6 +570,11 @@ void pfac_scan_filter(ScanArgs a)
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sLadder, sFinal3, sShort,
                   35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2BitsLad, 32u - (uint32_t)a.log2BitsF3};
+    /* one probe of the prefix ladder: bit `v >> shiftLad` of the bitmap, in bit 0 of the result (the bits above it are garbage) */
+    auto ladProbe = [&](uint32_t v) -> uint32_t {
+        const uint32_t idx = v >> lds.shiftLad;
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(((idx >> 3) & ~3u) + kLadderLdsOffset) >> (idx & 31u);
+    };
     const WCtx wctx(a);
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
@@ -1079,8 +1086,8 @@ void pfac_scan_filter(ScanArgs a)
                 const uint32_t at = o >> 2, sh = o & 3u;
                 const uint32_t x = __builtin_amdgcn_alignbyte(stage[at + 1], stage[at], sh);
                 const uint32_t h = x * pfac::kLadMul0;
-                const uint32_t sHit = testBit(sLadder, h >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulS) >> lds.shiftLad);
-                const uint32_t gHit = testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulG2) >> lds.shiftLad);
+                const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS) & 1u;
+                const uint32_t gHit = ladProbe(h * pfac::kLadMulG) & ladProbe(h * pfac::kLadMulG2) & 1u;
                 uint32_t decided = sHit | (testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3) &
                                            testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul2) >> lds.shiftF3));
                 if (HAS_SHORT) decided |= testBit(sShort, x & 0xFFFFu);
@@ -1131,10 +1138,10 @@ void pfac_scan_filter(ScanArgs a)
                     eLo = eHi;
                 }
                 h = (h ^ ((lv & 1) ? (xw & 0xFFFFu) : (xw >> 16))) * pfac::kLadMul;
-                const uint32_t sHit = testBit(sLadder, h >> lds.shiftLad) & testBit(sLadder, (h * pfac::kLadMulS) >> lds.shiftLad);
+                const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
                 walk |= und & sHit;
                 if (lv == pfac::kLadderLevels - 1) und = 0;          /* the last level has S nodes only */
-                else und &= testBit(sLadder, (h * pfac::kLadMulG) >> lds.shiftLad) & ~sHit;
+                else und &= ladProbe(h * pfac::kLadMulG) & ~sHit;
             }
             if (REDUCE) walk |= und;                                /* undecided after the last level tested: walk */
             if (!REDUCE && !skipLadder && und0 >= 16u) {
@@ -1255,8 +1262,7 @@ static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + (kScannerLdsFull > kS
 
 size_t filterLdsBytes(const PFAC_context *c, bool reduce)
 {
-    size_t bytes = ((size_t(1) << c->filter.log2Bits) + (size_t(1) << c->filter.log2BitsLad) +
-                    (size_t(1) << c->filter.log2BitsF3)) / 8;
+    size_t bytes = kLadderLdsOffset + ((size_t(1) << c->filter.log2BitsLad) + (size_t(1) << c->filter.log2BitsF3)) / 8;   /* the level-1 bitmap has its 32 KiB whatever its size */
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
@@ -1280,7 +1286,7 @@ struct ShapeCache { std::mutex lock; int perCU[kMaxDevices] = {}; };
 template <bool TEX, bool HAS_SHORT, bool REDUCE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
 {
-    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, PFAC_WALK_SETS>;
+    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL>;
     static ShapeCache cache;
     const size_t lds = filterLdsBytes(c, REDUCE);
     int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
@@ -1656,7 +1662,7 @@ extern "C" {
 #define PFAC_STR(x) PFAC_STR2(x)
 const char *PFACX_buildInfo(void)
 {
-    return "gfx950 block=" PFAC_STR(PFAC_BLOCK_THREADS) " writers=" PFAC_STR(PFAC_WRITERS) " walk_sets=" PFAC_STR(PFAC_WALK_SETS) " queue=" PFAC_STR(PFAC_QUEUE_CAP)
+    return "gfx950 block=" PFAC_STR(PFAC_BLOCK_THREADS) " writers=" PFAC_STR(PFAC_WRITERS) " walk_sets=" PFAC_STR(PFAC_WALK_SETS_FULL) "/" PFAC_STR(PFAC_WALK_SETS) " queue=" PFAC_STR(PFAC_QUEUE_CAP)
            " list=" PFAC_STR(PFAC_LIST_CAP) " span_log2=" PFAC_STR(PFAC_SPAN_LOG2) " front_log2=" PFAC_STR(PFAC_FRONT_LOG2) " parts=" PFAC_STR(PFAC_WORK_PARTS)
            " refill_min=" PFAC_STR(PFAC_REFILL_MIN) " ablate=" PFAC_STR(PFAC_ABLATE) " timing=" PFAC_STR(PFAC_TIMING);
 }

@@ -232,7 +232,8 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     hit = oracle_results[name] != 0
     assert np.all(level1[hit]) and np.all(cand[hit]) and np.all(walk[hit])
     assert info.filterHasShort == int(any(len(p) < 3 for p in open(w.pattern_file, "rb").read().split(b"\n") if p))
-    lds = ((1 << info.filterLog2Bits) + (1 << info.filterLog2BitsLadder) + (1 << info.filterLog2BitsFinal3)) // 8 + 8192 * info.filterHasShort
+    assert info.filterLog2Bits <= 18
+    lds = 32768 + ((1 << info.filterLog2BitsLadder) + (1 << info.filterLog2BitsFinal3)) // 8 + 8192 * info.filterHasShort    # level 1 has its 32 KiB whatever its size
     assert lds <= 97 * 1024, "the bitmaps share the LDS budget of the kernel (pfac_context.h: kFilterLdsBudget)"
 
 

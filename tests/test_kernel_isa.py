@@ -97,5 +97,5 @@ def test_scan_loop_waits_once_per_trip(isa):
         # followed by the same instruction, the first of the walkers' consume stage
         top = {loop[i + 1].strip() for i in waits if i not in after_atomic}
         assert len(top) == 1 and 1 <= len(waits) - len(after_atomic) <= 2, (name, [loop[i].strip() + " / " + loop[i + 1].strip() for i in waits])
-        if "ELb0ELi2E" in name:                        # REDUCE = false: one atomic, the append to the list of pattern-dense chunks
+        if re.search(r"ELb0ELi\dE", name):                        # REDUCE = false: one atomic, the append to the list of pattern-dense chunks
             assert len(after_atomic) <= 1, name

@@ -237,6 +237,36 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     assert lds <= 97 * 1024, "the bitmaps share the LDS budget of the kernel (pfac_context.h: kFilterLdsBudget)"
 
 
+def test_prefix_ladder_of_a_very_large_pattern_set(tmp_path):
+    """120 000 patterns of 12..24 bytes over a 16-letter alphabet: more ladder nodes than the LDS bitmap may hold at a
+    fifth full.  The compiler then gives up the extra level behind thin nodes and raises the thin threshold (fewer,
+    shallower nodes); the filter must still pass every position the CPU platform (which never looks at the filter)
+    reports."""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"abcdefghijklmnop", dtype=np.uint8)
+    pats = {alpha[rng.integers(0, 16, size=int(rng.integers(12, 25)))].tobytes() for _ in range(120000)}
+    p = tmp_path / "big.pat"
+    p.write_bytes(b"\n".join(sorted(pats)) + b"\n")
+    h = api.PFAC.createHostOnly()
+    h.setPerfMode(api.PFAC_SPACE_DRIVEN)                     # the dense table of this set would be > 1 GB
+    h.readPatternFromFile(str(p))
+    info = h.info()
+    assert info.numOfPatterns == len(pats)
+    assert info.ladderExtend == 0 and info.ladderThin >= 1 and 5 * (2 * info.ladderStops + info.ladderGoOns) <= (1 << info.filterLog2BitsLadder) * 1.0001 \
+        or info.ladderThin >= (1 << 30)
+    data = alpha[rng.integers(0, 16, size=400000)].copy()
+    plist = sorted(pats)
+    for k in range(2000):                                       # random text alone would hardly ever match a 12-byte pattern
+        q = np.frombuffer(plist[int(rng.integers(0, len(plist)))], dtype=np.uint8)
+        at = int(rng.integers(0, data.size - 32))
+        data[at:at + q.size] = q
+    want = h.match_host_array(data)
+    level1, cand, walk = prefilter_model(h, data)
+    h.destroy()
+    hit = want != 0
+    assert hit.sum() > 1000 and np.all(level1[hit]) and np.all(cand[hit]) and np.all(walk[hit])
+
+
 def test_prefix_ladder_prunes_the_snort_style_stream(workloads, oracle_results):
     """The ladder is why the bench workload walks few positions: on the C3 sample fewer than half of the candidates
     (level-1 hits whose first four bytes are a pattern prefix) survive it, and every true match does."""

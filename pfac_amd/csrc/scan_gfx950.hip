@@ -1115,33 +1115,40 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t code = act ? listCode(listAt) : 0u;
             const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);
             const uint32_t at = o >> 2, sh = o & 3u;
-            /* the candidate's bytes are read from the stage as the levels need them, and once more for the queue entry of
-             * a survivor: held in registers across the ladder they cost five registers the walkers' state needs */
-            uint32_t eLo = stage[at + 1];
-            uint32_t h = __builtin_amdgcn_alignbyte(eLo, stage[at], sh) * pfac::kLadMul0;
+            /* the candidate's 20 bytes and the rolling hashes of all its prefixes first: nothing in them depends on the outcome
+             * of a level, so the probes of several levels are in flight together (the kernel has the registers for it since
+             * the full-result variant runs one walk per lane; the compacted-output variant tests no level here) */
+            const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(e1, e0, sh), x1 = __builtin_amdgcn_alignbyte(e2, e1, sh), x2 = __builtin_amdgcn_alignbyte(e3, e2, sh),
+                           x3 = __builtin_amdgcn_alignbyte(e4, e3, sh), x4 = __builtin_amdgcn_alignbyte(e5, e4, sh);
             uint32_t walk = act ? (code >> 15) & 1u : 0u;
             uint32_t und = act ? walk ^ 1u : 0u;                    /* undecided: a G node so far */
-            uint32_t xw = 0;
             /* Input that follows the patterns deeper than the ladder looks (near misses of long patterns: BASELINE config 5)
              * passes every level: the ladder then only costs.  A wave whose last four batches each spared less than an eighth
              * of their undecided candidates walks the next 28 batches' candidates untested, then looks again. */
             const uint32_t und0 = (uint32_t)__popcll(__ballot(und != 0));
             const bool skipLadder = !REDUCE && ladderSkip != 0;
             if (skipLadder) { ladderSkip--; walk |= und; und = 0; }
+            if (!(REDUCE && kReduceLadderLevels == 0) && __ballot(und != 0) != 0) {
+                uint32_t hl[pfac::kLadderLevels];
+                hl[0] = x0 * pfac::kLadMul0;
 #pragma unroll
-            for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
-                if (REDUCE && lv > kReduceLadderLevels) break;      /* the compacted-output kernel stops early: see kReduceLadderLevels */
-                if (__ballot(und != 0) == 0) break;
-                if (lv & 1) {                                       /* bytes 4k .. 4k+3 of the candidate serve two levels */
-                    const uint32_t eHi = stage[at + (lv + 3) / 2];
-                    xw = __builtin_amdgcn_alignbyte(eHi, eLo, sh);
-                    eLo = eHi;
+                for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
+                    const uint32_t xw = lv <= 2 ? x1 : lv <= 4 ? x2 : lv <= 6 ? x3 : x4;
+                    hl[lv] = (hl[lv - 1] ^ ((lv & 1) ? (xw & 0xFFFFu) : (xw >> 16))) * pfac::kLadMul;
                 }
-                h = (h ^ ((lv & 1) ? (xw & 0xFFFFu) : (xw >> 16))) * pfac::kLadMul;
-                const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
-                walk |= und & sHit;
-                if (lv == pfac::kLadderLevels - 1) und = 0;          /* the last level has S nodes only */
-                else und &= ladProbe(h * pfac::kLadMulG) & ~sHit;
+#pragma unroll
+                for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
+                    if (REDUCE && lv > kReduceLadderLevels) break;  /* the compacted-output kernel stops early: see kReduceLadderLevels */
+                    /* one early exit, in the middle: a check per level makes every level wait for the LDS reads of the one before
+                     * it, and on text a batch almost always has a candidate that follows some long keyword to the last levels */
+                    if (lv == 5 && __ballot(und != 0) == 0) break;
+                    const uint32_t h = hl[lv];
+                    const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
+                    walk |= und & sHit;
+                    if (lv == pfac::kLadderLevels - 1) und = 0;      /* the last level has S nodes only */
+                    else und &= ladProbe(h * pfac::kLadMulG) & ~sHit;
+                }
             }
             if (REDUCE) walk |= und;                                /* undecided after the last level tested: walk */
             if (!REDUCE && !skipLadder && und0 >= 16u) {
@@ -1155,9 +1162,8 @@ void pfac_scan_filter(ScanArgs a)
             const bool keep = walk != 0;
             const uint64_t keepMask = __ballot(keep);
             if (keep) {
-                const uint32_t e0 = stage[at], e1 = stage[at + 1], e2 = stage[at + 2], e3 = stage[at + 3], e4 = stage[at + 4], e5 = stage[at + 5];
-                const u32x4 entry = {stagedBase + o, __builtin_amdgcn_alignbyte(e1, e0, sh), __builtin_amdgcn_alignbyte(e2, e1, sh), __builtin_amdgcn_alignbyte(e3, e2, sh)};
-                const u32x2 entryB = {__builtin_amdgcn_alignbyte(e4, e3, sh), __builtin_amdgcn_alignbyte(e5, e4, sh)};
+                const u32x4 entry = {stagedBase + o, x0, x1, x2};
+                const u32x2 entryB = {x3, x4};
                 const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
                 queue[qi] = entry;
                 queueB[qi] = entryB;

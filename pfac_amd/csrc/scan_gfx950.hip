@@ -17,42 +17,50 @@
  *   HBM, the limit.  pfac_scan_filter is one persistent 1024-thread block per CU
  *   with two kinds of waves:
  *
- *   WRITER waves (2 of 16) only zero-fill: they claim 8 KiB spans of the input in
- *   order (one moving front over the whole grid), write the 32 KiB of zeros of the
+ *   WRITER waves (3 of 16) only zero-fill: they claim 8 KiB spans of the input in
+ *   order -- ONE NARROW MOVING FRONT over the whole grid: granules of 16 spans dealt
+ *   round-robin to 2 device counters, so all 256 CUs work inside one 256 KiB window of
+ *   the input that sweeps the buffers once --, write the 32 KiB of zeros of the
  *   span with non-temporal 16 B/lane stores, wait until those are in L2 and publish
  *   the span in an LDS ring.  The result stream is 80 % of the traffic and does not
  *   depend on the input; kept out of the scanning waves it neither stalls them nor
  *   is stalled by them.
  *
  *   SCANNING waves take 2 KiB chunks of published spans from an LDS ticket counter:
- *   1. FILTER, level 1 (every position, LDS only): lane l tests its 16 positions of
- *      each tile against a 3-gram Bloom bitmap (aligned dword read + shift; patterns
- *      of 1-2 bytes are folded into it when the set is compiled).  A miss proves the
- *      result is 0.  The chunk is staged in LDS on the way; the next chunk is
- *      prefetched into nine registers the compiler is told not to use (v119..v127,
- *      inline assembly), so that no register copy ever waits for it.
+ *   1. LEVEL 1 (every position, LDS only): lane l tests its 16 positions of each tile
+ *      against a blocked two-bit 3-gram Bloom bitmap (two bits of one dword per 3-gram:
+ *      one aligned read, two shifts; patterns of 1-2 bytes are folded into it when the
+ *      set is compiled).  A miss proves the result is 0.  The chunk is staged in LDS on
+ *      the way; the next chunk is prefetched into nine registers the compiler is told
+ *      not to use (v119..v127, inline assembly), so that no register copy ever waits
+ *      for it.
  *   2. LIST.  The lanes' hits become one list of 16-bit codes (prefix sum of the hit
- *      counts, one divergent loop).
- *   3. FILTER, level 2, one hit per lane: 20 bytes cut out of the stage, tested
- *      against a two-hash 4-gram bitmap (+ length-3 bitmap, + exact 2-byte bitmap);
- *      survivors go to the wave's walk queue {position, 20 input bytes}.
- *   4. WALK.  Each lane runs 2 split-phase walkers over a device-only "chained"
- *      copy of the reference's hash table (tables.cpp; used for BOTH perf modes),
- *      16 bytes per slot: one gathered load per edge byte + up to 7 single-
- *      successor bytes; the loads of a step are issued in one trip of the loop and
+ *      counts, one divergent loop).  A chunk in which more than 90 % of the positions
+ *      hit is not listed: it goes on the launch's dense list, and the simple kernel
+ *      behind this launch walks its positions one per thread.
+ *   3. LEVEL-4 TEST, one hit per lane: the first four bytes against level 4 of the
+ *      prefix ladder (+ length-3 bitmap, + exact 2-byte bitmap); survivors stay in the
+ *      list, compacted in place.
+ *   4. PREFIX LADDER, one candidate per lane: its 20 bytes are cut out of the stage and
+ *      the rolling hashes of its prefixes of 6, 8, ..., 20 bytes are tested against ONE
+ *      Bloom bitmap in LDS of "stop" and "go on" trie nodes (pfac_context.h: struct
+ *      Filter).  A candidate goes to the wave's walk queue {position, 20 input bytes}
+ *      only if it follows some pattern until that pattern is alone on its path, and one
+ *      level beyond.
+ *   5. WALK.  Each lane runs a split-phase walker (two in the compacted-output variant)
+ *      over a device-only "chained" table (tables.cpp; used for BOTH perf modes; compact,
+ *      breadth first), 16 bytes per slot: one gathered load per edge byte + up to 7 single-
+ *      successor bytes; the load of a step is issued in one trip of the loop and
  *      consumed in the next.  A walk starts in a JUMP table keyed by its first four
- *      bytes (which level 2 has just found to be a probable pattern prefix) and
- *      restarts in the initial state's bucket if its prefix is not there.  The input
- *      window stays in registers: the entry's 20 bytes end 99.9 % of the walks
- *      without an input load.  "Texture" mode = buffer-resource loads.
- *   5. PATCH.  A non-zero result overwrites its zero, which the writer wave had in
+ *      bytes and restarts in the initial state's bucket if its prefix is not there.  The
+ *      input window stays in registers: the entry's 20 bytes end practically every walk
+ *      of text without an input load.  "Texture" mode = buffer-resource loads.
+ *   6. PATCH.  A non-zero result overwrites its zero, which the writer wave had in
  *      L2 before the chunk was handed out (same CU, same L2: ordered).
  *   The loop has ONE copy of every stage and ONE wait for vector memory: a trip is
  *   wait -> consume the walkers' slots -> refill -> issue the next slots -> (if the
  *   staged chunk is listed and tested) level 1 of the next chunk + prefetch of the
- *   one after it -> list -> passes while the queue has room.  The wait counter is
- *   in-order; the walkers' gathered loads are what the wait is mostly for, so they
- *   go first and have the rest of the trip to land.
+ *   one after it -> list + level-4 test -> ladder batches while the queue has room.
  *
  *   The compacted-output variant (REDUCE) has no zeros to write and no writer waves;
  *   its scanning waves claim chunks from the device counters themselves.  So do the
@@ -61,11 +69,11 @@
  *   gfx9-family hardware (zero store acknowledged before a later load of the same
  *   wave returns).
  *
- *   The kernel never checks a bound: the launcher gives it whole chunks that end
- *   at least maxPatternLen + 32 bytes before the end of the input.  The rest --
- *   and everything when a pointer is not 16-byte aligned -- goes to
- *   pfac_scan_naive (one thread per byte, reference-layout tables), which is
- *   also the independent second implementation the tests cross-check against.
+ *   The kernel never checks a bound: the launcher gives it whole chunks that start at
+ *   a 16-byte aligned input byte and end at least maxPatternLen + 32 bytes before the
+ *   end of the input.  The <= 15 positions in front, the end, and the dense list go to
+ *   pfac_scan_naive (one thread per byte, reference-layout tables), which
+ *   is also the independent second implementation the tests cross-check against.
  *   No MFMA: nothing here is a contraction.
  */
 #if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
@@ -414,11 +422,12 @@ template <bool TEX> struct ChainLane {
 #define PFAC_ABLATE 0                         /* timing experiments only (tools/ab.sh): 1 = stream + level 1, 2 = no walks */
 #endif
 #ifndef PFAC_STATS
-#define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (tools/kstats.sh) */
+#define PFAC_STATS 0                          /* -DPFAC_STATS=1: per-block counters printed at kernel end (PFAC_STATS build) */
 #endif
 /* A scanning wave works on one CHUNK of two 1 KiB tiles at a time: the chunk is staged in LDS (+ the 32 bytes
  * behind it), every lane's level-1 hits go to a per-wave list of 16-bit codes, and 64 list entries at a time
- * are cut out of the stage, tested against level 2 and appended to the walk queue -- one entry per lane. */
+ * go through the level-4 test and the prefix ladder; what is left is cut out of the stage and appended to the walk
+ * queue -- one entry per lane. */
 constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
 constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
@@ -559,7 +568,7 @@ void pfac_scan_filter(ScanArgs a)
 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform by construction: keep it (and what derives from it) scalar */
-    /* ring of {byte position (32-bit), input bytes pos..pos+19} that passed both filter levels, kept as a 16-byte
+    /* ring of {byte position (32-bit), input bytes pos..pos+19} that passed level 1 and the prefix ladder, kept as a 16-byte
      * and an 8-byte array: the twenty bytes carry practically every walk to its end without a single input load
      * (gathered loads are the scarce resource) */
     u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQCap;
@@ -581,7 +590,7 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
     for (int s = 0; s < kWalkSets; s++) alive[s] = false;
     /* Ring-queue counters (wave-uniform, monotonically increasing; index = counter & (cap-1)):
-     *   [qh, qv)  passed both filter levels, waiting for a walker lane */
+     *   [qh, qv)  passed level 1 and the ladder, waiting for a walker lane */
     uint32_t qh = 0, qv = 0;
     constexpr uint32_t kMask = kQCap - 1;
     /* the counters are wave-uniform; saying so keeps them (and every branch on them) on the scalar unit */
@@ -724,20 +733,22 @@ void pfac_scan_filter(ScanArgs a)
     };
 
     /* Work is handed out dynamically and IN ORDER: block b serves part b % parts of the input and takes the
-     * next piece of its part from a device counter (one per part, in a.work).  With PFAC_FRONT_LOG2 = 0 a part
+     * next piece of its part from a device counter (one per part, in a.work).  With PFAC_FRONT_LOG2 = -1 a part
      * is a contiguous 1/parts of the input: all waves of a part work inside a window of a few hundred KiB that
      * moves linearly through its part.  With G > 0 granules of 2^G pieces are dealt round-robin to the parts,
      * so the whole grid works inside ONE window that sweeps the input once.  Either way it is what the hardware
      * does for a grid of small blocks, worth ~10 % of HBM throughput over a static grid-stride assignment
      * (profiles/r01_stream_probe2_ordering.txt), and it balances the load.  (Workgroups are dealt round-robin
-     * to the 8 XCDs, so the blocks that share a counter share an L2.)
+     * to the 8 XCDs; with two parts a counter is shared by the blocks of four XCDs.)
      * A piece is a span of kSpanChunks chunks claimed by a writer wave (kWriters > 0), or a single chunk claimed
      * by the scanning wave itself (kWriters == 0). */
     const uint32_t numChunks = n / kChunkBytes;
     const uint32_t numPieces = kWriters ? (numChunks + kSpanChunks - 1) >> kSpanLog2 : numChunks;
-    /* parts: few for the full-result kernel (a narrow front: 16 parts ran 1 % (Snort-style) to 4 % (random patterns)
-     * faster than 32, 64 were 2..4 % slower), more for the compacted-output kernel, whose waves claim single chunks
-     * and would queue up at the counters */
+    /* parts: TWO for the full-result kernel, with granules of 16 spans: the narrowest front that two claim counters can
+     * still serve (one counter saturates: ~90 atomics per microsecond; 512 writer waves ask 146 times per microsecond).
+     * 16 parts x 4 spans (round 2) -> 2 x 16: C3 -6 %, C2 -9 %, and the buffer-placement classes disappear
+     * (profiles/r03_experiments.md, section 4).  More for the compacted-output kernel, whose waves claim granules of
+     * chunks themselves and would queue up at the counters */
     constexpr uint32_t kParts = REDUCE ? (uint32_t)PFAC_REDUCE_PARTS : (uint32_t)pfac::kWorkParts;
     const uint32_t parts = gridDim.x < kParts ? gridDim.x : kParts;
     const uint32_t part = blockIdx.x % parts;

@@ -70,7 +70,7 @@
  *   wave returns).
  *
  *   The kernel never checks a bound: the launcher gives it whole chunks that start at
- *   a 16-byte aligned input byte and end at least maxPatternLen + 32 bytes before the
+ *   a 16-byte aligned input byte and end at least maxPatternLen + 64 bytes before the
  *   end of the input.  The <= 15 positions in front, the end, and the dense list go to
  *   pfac_scan_naive (one thread per byte, reference-layout tables), which
  *   is also the independent second implementation the tests cross-check against.
@@ -147,7 +147,7 @@ struct ScanArgs {
     /* pattern-dense chunks (full-result path): the filter kernel lists the chunks in which most positions pass level 1
      * instead of filtering them; the simple kernel that follows it (the launch that also scans the end of the input)
      * walks their positions one per thread.  denseIn / denseOut / denseReadable describe the filter launch the chunk
-     * numbers refer to.  The list's length is a.work[kDenseCountWord]; a wave appends 16 chunks at a time (one device
+     * numbers refer to.  The list's length is a.work[kDenseCountWord]; a wave appends 8 chunks at a time (one device
      * counter answers ~90 atomics per microsecond: an append per chunk cost 1.5 ms for 256 MiB of pattern-dense input). */
     unsigned int *denseList;
     const unsigned char *denseIn;
@@ -156,7 +156,7 @@ struct ScanArgs {
 };
 constexpr int kDenseCountWord = 32 * 32;                /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
                                                           line 32 counts the dense chunks (zeroed with the rest before every launch) */
-constexpr uint32_t kDenseStage = 16;                    /* dense chunks a wave collects in LDS before it appends them to the list */
+constexpr uint32_t kDenseStage = 8;                     /* dense chunks a wave collects in LDS before it appends them to the list */
 constexpr uint32_t kDenseHits = 1843;                  /* of the 2048 positions of a chunk: above 90 % the prefilter only adds work.  (Input in which every
                                                           position matches: 40 GB/s through the filter kernel, 80-118 through the simple one; text in which a
                                                           third of the positions match and two thirds pass level 1 is still faster through the filter kernel,
@@ -265,7 +265,7 @@ __device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos
  * What is scarce on pattern-dense input is gathered loads, then instruction issue:
  * a step is written as straight-line selects (every early `return` costs exec-mask bookkeeping for
  * the whole wave), positions are 32-bit, and nothing checks a bound -- the launcher hands the last
- * maxPatternLen + 32 bytes of the input to the simple kernel, so a walk that starts in this kernel's
+ * maxPatternLen + 64 bytes of the input to the simple kernel, so a walk that starts in this kernel's
  * range can neither run past the input nor load past it.
  *
  * Both table modes walk the CHAINED table (tables.cpp: buildChainedHashTable): a device-only copy of the
@@ -299,10 +299,13 @@ __device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
     return min(r, r + (uint32_t)pfac::kHashP) & (ks >> 9);      /* a negative r is huge as unsigned: picks r + 257 */
 }
 
-constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brings along */
+constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brings along: compacted-output kernel (what the prefix ladder looks at) */
+constexpr uint32_t kEntryBytesFull = 36;       /* ... full-result kernel: 16 more, so that a walk 21..36 bytes deep (near misses of long patterns) needs no
+                                                * gathered input load: those were 40 % of the gathered loads of BASELINE config 5 */
 
-template <bool TEX> struct ChainLane {
+template <bool TEX, uint32_t ENTRY> struct ChainLane {
     using Ctx = ChainCtx<TEX>;
+    static constexpr bool kDeep = ENTRY > kEntryBytes;          /* 36-byte entries: the window is nine dwords, re-fetched 32 bytes at a time */
     uint32_t pos = 0;
     uint32_t row = 0;                          /* first slot of the current state's bucket */
     int match = 0;
@@ -313,6 +316,7 @@ template <bool TEX> struct ChainLane {
     u32x4 t = {0, 0, 0, 0};
     uint32_t W0 = 0;
     u32x4 W = {0, 0, 0, 0};                    /* W1..W4 as one register quad: the destination of the window load itself */
+    u32x4 V = {0, 0, 0, 0};                    /* kDeep: W5..W8 */
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
     bool first = false;                        /* the slot in flight comes from the jump table */
@@ -323,14 +327,24 @@ template <bool TEX> struct ChainLane {
      * branches -- as a `switch` this is a dozen exec-mask regions. */
     __device__ __forceinline__ void windowBytes(uint32_t q, uint32_t &x0, uint32_t &x1) const
     {
-        const uint32_t o = q - (wend - kEntryBytes);
+        const uint32_t o = q - (wend - ENTRY);
         const bool b1 = (o & 4u) != 0, b2 = (o & 8u) != 0, b4 = (o & 16u) != 0;
         const uint32_t W1 = W.x, W2 = W.y, W3 = W.z, W4 = W.w;
-        const uint32_t T0 = b1 ? W1 : W0, T1 = b1 ? W2 : W1, T2 = b1 ? W3 : W2, T3 = b1 ? W4 : W3, T4 = b1 ? 0u : W4;
-        const uint32_t U0 = b2 ? T2 : T0, U1 = b2 ? T3 : T1, U2 = b2 ? T4 : T2;
-        const uint32_t lo = b4 ? W4 : U0;
-        x0 = __builtin_amdgcn_alignbyte(U1, lo, o & 3u);
-        x1 = __builtin_amdgcn_alignbyte(U2, U1, o & 3u);
+        if (!kDeep) {
+            const uint32_t T0 = b1 ? W1 : W0, T1 = b1 ? W2 : W1, T2 = b1 ? W3 : W2, T3 = b1 ? W4 : W3, T4 = b1 ? 0u : W4;
+            const uint32_t U0 = b2 ? T2 : T0, U1 = b2 ? T3 : T1, U2 = b2 ? T4 : T2;
+            const uint32_t lo = b4 ? W4 : U0;
+            x0 = __builtin_amdgcn_alignbyte(U1, lo, o & 3u);
+            x1 = __builtin_amdgcn_alignbyte(U2, U1, o & 3u);
+        } else {                                           /* nine dwords W0..W8, dword number 0..8: shifts by 4, 2, 1 (8 = W8 alone) */
+            const bool b8 = (o & 32u) != 0;
+            const uint32_t W5 = V.x, W6 = V.y, W7 = V.z, W8 = V.w;
+            const uint32_t E0 = b8 ? W8 : (b4 ? W4 : W0), E1 = b4 ? W5 : W1, E2 = b4 ? W6 : W2, E3 = b4 ? W7 : W3, E4 = b4 ? W8 : W4, E5 = W5;
+            const uint32_t F0 = b2 ? E2 : E0, F1 = b2 ? E3 : E1, F2 = b2 ? E4 : E2, F3 = b2 ? E5 : E3;
+            const uint32_t G0 = b1 ? F1 : F0, G1 = b1 ? F2 : F1, G2 = b1 ? F3 : F2;
+            x0 = __builtin_amdgcn_alignbyte(G1, G0, o & 3u);
+            x1 = __builtin_amdgcn_alignbyte(G2, G1, o & 3u);
+        }
     }
 
     /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0, given the input
@@ -359,11 +373,12 @@ template <bool TEX> struct ChainLane {
      * and the prefilter has just found its first four bytes to be -- probably -- a pattern prefix, so the slot at
      * hash(those four bytes) takes it four or more bytes deep with its first gathered load (ks = 0: the bucket is
      * the slot itself).  If the slot is somebody else's, consume() restarts the walk in the initial state's bucket. */
-    __device__ __forceinline__ void start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1, const uint32_t *shortBits)
+    __device__ __forceinline__ void start(const Ctx &c, const u32x4 &ea, const uint32_t eb0, const uint32_t eb1, const u32x4 &ec, const uint32_t *shortBits)
     {
         pos = ea.x; match = 0; depth = 0; b0 = ea.y & 0xFF;
         W0 = ea.y; W.x = ea.z; W.y = ea.w; W.z = eb0; W.w = eb1;
-        wend = pos + kEntryBytes;
+        if (kDeep) V = ec;
+        wend = pos + ENTRY;
         needWin = false; needSlot = true; longWalk = false;
         /* a pattern of one or two bytes matches here (shortBits: the exact 2-byte bitmap, only given when the set has
          * such patterns): the prefix passes a final state, so it has no jump slot -- straight to the initial state's
@@ -384,9 +399,10 @@ template <bool TEX> struct ChainLane {
             if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, PFAC_SLOT_AUX);
             else t = c.slots[idx];
         }
-        if (needWin) {                                         /* rare: the walk is more than 20 bytes deep */
+        if (needWin) {                                         /* rare: the walk is deeper than its entry */
             W = loadWindow16(c.in32, pos + depth + 1);                 /* pos + depth = position of the edge byte b0 */
-            wend = ((pos + depth + 1) & ~3u) + 16u;
+            if (kDeep) V = loadWindow16(c.in32, pos + depth + 17);
+            wend = ((pos + depth + 1) & ~3u) + (kDeep ? 32u : 16u);
         }
     }
     __device__ __forceinline__ bool consume(const Ctx &c)
@@ -411,7 +427,9 @@ template <bool TEX> struct ChainLane {
         b0 = restart ? (W0 & 0xFFu) : b0;
         cont |= restart;
         first = false;
-        needWin |= longWalk;                                   /* long walks (adversarial input): no more retry rounds */
+        /* long walks (adversarial input): no more retry rounds -- a new window with every step, or, with the wide window,
+         * whenever fewer than nine bytes (the most a step consumes) are left of it */
+        needWin |= kDeep ? (longWalk & (wend < pos + depth + 10u)) : longWalk;
         return cont;
     }
 };
@@ -430,7 +448,7 @@ template <bool TEX> struct ChainLane {
  * queue -- one entry per lane. */
 constexpr int kGroupTiles = pfac::kChunkTiles;
 constexpr int kGroupBytes = kGroupTiles * kTileBytes;
-constexpr int kStageWords = (kGroupBytes + 32) / 4;      /* the chunk + the 32 bytes behind it: an entry is cut 20 bytes deep */
+constexpr int kStageWords = (kGroupBytes + 48) / 4;      /* the chunk + the 48 bytes behind it: an entry is cut up to 36 bytes deep */
 #ifndef PFAC_REFILL_MIN
 #define PFAC_REFILL_MIN 16                     /* queue entries are handed out only when at least this many lanes of a walk set are idle:
                                                 * a refill costs the whole wave ~40 instructions however few lanes it fills
@@ -523,7 +541,7 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
  * in flight (prefetchChunk). */
 constexpr int kCompilerVgprs = 59;
 
-/* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 32 readable input bytes follow it */
+/* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 64 readable input bytes follow it */
 template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(kCompilerVgprs)))
 void pfac_scan_filter(ScanArgs a)
@@ -531,7 +549,8 @@ void pfac_scan_filter(ScanArgs a)
     constexpr int kTilesPerIter = kGroupTiles;
     constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
     using WCtx = ChainCtx<TEX>;
-    using WLane = ChainLane<TEX>;
+    constexpr uint32_t kEntry = REDUCE ? kEntryBytes : kEntryBytesFull;
+    using WLane = ChainLane<TEX, kEntry>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words3 = 1 << (a.log2Bits - 5), wordsLad = 1 << (a.log2BitsLad - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
@@ -545,7 +564,8 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t *sQueueAll = reinterpret_cast<uint32_t *>(ctl) + kControlWords;           /* 16-byte aligned */
     constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
     uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * 4;            /* ... second part of the entries: input bytes 12..19 */
-    uint32_t *sStageAll = sQueueBAll + kScanners * kQCap * 2;            /* per scanning wave: the chunk being filtered + the 32 bytes behind it */
+    uint32_t *sQueueCAll = sQueueBAll + kScanners * kQCap * 2;           /* ... full-result kernel: input bytes 20..35 */
+    uint32_t *sStageAll = sQueueCAll + (REDUCE ? 0 : kScanners * kQCap * 4);   /* per scanning wave: the chunk being filtered + the 48 bytes behind it */
     uint32_t *sListAll = sStageAll + kScanners * kStageWords;            /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
     uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
     uint32_t *sDenseAll = sReduceAll + ((REDUCE || kStagedPatch) ? kScanners * 2 * kReduceCap : 0);   /* full-result kernel: per-wave staging of dense chunk numbers */
@@ -574,6 +594,7 @@ void pfac_scan_filter(ScanArgs a)
     u32x4 *queue = reinterpret_cast<u32x4 *>(sQueueAll) + wave * kQCap;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 *queueB = reinterpret_cast<u32x2 *>(sQueueBAll) + wave * kQCap;
+    u32x4 *queueC = reinterpret_cast<u32x4 *>(sQueueCAll) + wave * kQCap;
     uint32_t *stage = sStageAll + wave * kStageWords;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
@@ -715,7 +736,9 @@ void pfac_scan_filter(ScanArgs a)
                 if (take) {
                     const uint32_t qi = (qh + rank) & kMask;
                     const u32x2 eb = queueB[qi];
-                    walk[s].start(wctx, queue[qi], eb.x, eb.y, HAS_SHORT ? sShort : nullptr);
+                    u32x4 ec = {0, 0, 0, 0};
+                    if (!REDUCE) ec = queueC[qi];
+                    walk[s].start(wctx, queue[qi], eb.x, eb.y, ec, HAS_SHORT ? sShort : nullptr);
                 }
                 alive[s] = alive[s] | take;
                 const uint32_t idleLanes = (uint32_t)__popcll(idle);
@@ -859,7 +882,7 @@ void pfac_scan_filter(ScanArgs a)
     };
     /* The chunk in flight lives in nine vector registers that the COMPILER DOES NOT KNOW ABOUT (v119..v127: the
      * kernel is compiled for fewer registers, kCompilerVgprs): two tiles, 1 KiB per load instruction, and the 32
-     * bytes behind the chunk, one dword in each of the lanes 0..7.  Left to the register allocator they were
+     * bytes (48 of them are used) behind the chunk, one dword in each of the lanes 0..15.  Left to the register allocator they were
      * copied between two register sets on every trip of the loop that did not stage a chunk, and a copy of the
      * destination of a load in flight waits for it -- and, the wait counter being in-order, for the walkers'
      * loads just issued: a third of a scanning wave's time (PFAC_TIMING build).  Issued and read through inline
@@ -871,7 +894,7 @@ void pfac_scan_filter(ScanArgs a)
          * from -- registers that the walkers' state needs) */
         uint32_t off, offHalo;
         asm volatile("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(off) : "v"(lane), "s"(c * (uint32_t)kChunkBytes));
-        asm volatile("v_and_b32 %0, 7, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
+        asm volatile("v_and_b32 %0, 15, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
         static_assert(kTilesPerIter == 2, "two tile registers are reserved");
         asm volatile("global_load_dwordx4 v[120:123], %0, %2\n\t"
                      "global_load_dwordx4 v[124:127], %0, %2 offset:1024\n\t"
@@ -980,7 +1003,7 @@ void pfac_scan_filter(ScanArgs a)
                     for (int k = 0; k < 4 * kTilesPerIter; k++) __builtin_nontemporal_store(zero, &o4[k * 64 + lane]);
                 }
                 /* filter level 1: lane l owns bytes 16l..16l+15 of each tile, one LDS bit test per position.
-                 * The chunk also goes to LDS (lane l -> bytes 16l.. of its tile, lanes 0..7 also the 32 bytes behind
+                 * The chunk also goes to LDS (lane l -> bytes 16l.. of its tile, lanes 0..11 also the 48 bytes behind
                  * it): an entry of the walk queue needs 20 bytes from an arbitrary offset. */
 #pragma unroll
                 for (int tt = 0; tt < kTilesPerIter; tt++) {
@@ -994,7 +1017,7 @@ void pfac_scan_filter(ScanArgs a)
                         asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(at16) : "v"(lane), "s"(tileBase));
                         *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(at16) = dt;
                     }
-                    if (tt == kTilesPerIter - 1 && lane < 8) {
+                    if (tt == kTilesPerIter - 1 && lane < 12) {
                         /* the address is computed on the spot (volatile: not hoisted out of the loop into a register
                          * that lives -- or is spilled -- across it) */
                         uint32_t at;
@@ -1178,6 +1201,12 @@ void pfac_scan_filter(ScanArgs a)
                 const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
                 queue[qi] = entry;
                 queueB[qi] = entryB;
+                if (!REDUCE) {                                  /* bytes 20..35: read now, for the few that are kept */
+                    const uint32_t e6 = stage[at + 6], e7 = stage[at + 7], e8 = stage[at + 8], e9 = stage[at + 9];
+                    const u32x4 entryC = {__builtin_amdgcn_alignbyte(e6, e5, sh), __builtin_amdgcn_alignbyte(e7, e6, sh),
+                                          __builtin_amdgcn_alignbyte(e8, e7, sh), __builtin_amdgcn_alignbyte(e9, e8, sh)};
+                    queueC[qi] = entryC;
+                }
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
             listAt = uni(listAt + take);
@@ -1272,7 +1301,7 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 /* the CU's 160 KiB: the prefilter bitmaps (<= kFilterLdsBudget, pattern_compiler.cpp) + control block + per scanning wave a
  * walk queue (24 B per entry), the staged chunk and the hit list (+ the pair staging of the compacted-output variant) */
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * 24 + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
+constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
 constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
 static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + (kScannerLdsFull > kScannerLdsReduce ? kScannerLdsFull : kScannerLdsReduce) <= kLdsPerCu,
               "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
@@ -1283,7 +1312,7 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
-    bytes += scanners * ((reduce ? kReduceQueueCap : kQueueCap) * 6 + kStageWords + kListCap / 2) * sizeof(uint32_t);
+    bytes += scanners * ((reduce ? kReduceQueueCap * (4 + kEntryBytes) : kQueueCap * (4 + kEntryBytesFull)) + (kStageWords + kListCap / 2) * sizeof(uint32_t));
     if (reduce || kStagedPatch) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     if (!reduce) bytes += scanners * kDenseStage * sizeof(uint32_t);
     return bytes;
@@ -1432,17 +1461,18 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
 constexpr size_t kSmallInput = size_t(1) << 20;
 
 /* Launch plan for positions [first, ownEnd) of an input of inputSize readable bytes:
- *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 32 bytes inside the input
- *                              (a walk is at most maxPatternLen deep, a window load reads <= 19 bytes on)
- *   [first + mainLen, ownEnd)  simple kernel (bounds-checked byte loads): the end of the input, and
- *                              everything when the pointers are not 16-byte aligned                    */
+ *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 64 bytes inside the input
+ *                              (a walk is at most maxPatternLen deep, a window load reads <= 35 bytes on, the
+ *                              prefetch of a chunk the 64 bytes behind it)
+ *   [first + mainLen, ownEnd)  simple kernel (bounds-checked byte loads): the end of the input
+ * (`first` is the first 16-byte aligned input byte: scan() and reduceScan() peel the positions in front of it) */
 size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
 {
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
         if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
     }
-    const size_t margin = (size_t)c->fa.maxPatternLen + 32;
+    const size_t margin = (size_t)c->fa.maxPatternLen + 64;   /* a window load reads up to 35 bytes beyond a walk's deepest byte; the prefetch of a chunk reads the 64 bytes behind it */
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
     const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;
     return end > first ? (end - first) / chunkBytes(c) * chunkBytes(c) : 0;

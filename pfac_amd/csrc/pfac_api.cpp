@@ -78,7 +78,6 @@ void freeResources(PFAC_context *c)
     devFree(c->d_gram3);
     devFree(c->d_shortBits);
     devFree(c->d_ladder);
-    devFree(c->d_reduceCount);
     devFree(c->d_workCounters);
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
@@ -176,8 +175,6 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_ladder, c->filter.ladder.data(), c->filter.ladder.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
-    const unsigned int zero = 0;
-    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_reduceCount, &zero, 1);
     if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
         const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
         st = upload(c->d_workCounters, zeros.data(), zeros.size());

@@ -35,7 +35,8 @@ struct Int2 { int x, y; };                    /* device layout of the hashed tab
 #define PFAC_WORK_PARTS 2
 #endif
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
-constexpr int kWorkCounterWords = 64 * 32 + 64;   /* up to 64 part counters, one per 128-byte line, + the launch statistics */
+constexpr int kWorkCounterWords = 64 * 32 + 64;   /* 64 counters, one per 128-byte line (0..31 the parts of the input, 32 the dense-chunk list, 40 the pairs of a
+                                                     compacted-output call), + the launch statistics */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
@@ -172,8 +173,7 @@ struct PFAC_context {
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_ladder = nullptr;
-    unsigned int *d_reduceCount = nullptr;    /* device counter of the compacted-output path */
-    /* grow-only scratch of the compacted-output path (sort buffers), owned by the handle so that a
+    /* grow-only scratch of the compacted-output path (the arrays the pairs are ordered through), owned by the handle so that a
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;
     size_t reduceScratchBytes = 0;

@@ -85,7 +85,6 @@
 #include <cstring>
 #include <mutex>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
 #include <vector>
@@ -1272,7 +1271,13 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
                 if (state <= a.numFinal) match = state;
             }
         }
-        a.out[j] = match;
+        if (a.reducePos == nullptr) {
+            a.out[j] = match;
+        } else if (match > 0) {                             /* compacted output: a pair behind the others, any order (orderPairs) */
+            const unsigned int at = atomicAdd(a.reduceCount, 1u);
+            a.out[at] = match;
+            a.reducePos[at] = (int)(a.reduceBase + (unsigned int)j);
+        }
     }
     /* the chunks the filter kernel in front of this launch found pattern-dense (ScanArgs::denseList): every position of
      * a listed chunk, one per thread; walks read on into whatever follows the chunk */
@@ -1555,20 +1560,223 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
 }
 
-/*
- * Compacted output (ref PFAC_reduce_kernel / PFAC_reduce_inplace_kernel, PFAC_reduce_kernel.cu:172-295,
- * PFAC_reduce_inplace_kernel.cu:155-323): the first *h_num_matched entries of d_match_result / d_pos
- * receive the non-zero results and their positions in ascending position order.
- *
- * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
- * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
- * device counter, and the (usually short) list is then sorted by position with rocPRIM's radix sort.
- * The end of the input (and everything, for odd pointers) goes through the simple kernel into a
- * scratch vector that is compacted on the host and appended -- its positions follow all others.
- * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
- * (PFAC_reduce_kernel.cu:417-457) because it has no prefilter: every thread owns a result.
- * Synchronous, like the reference (the count goes back to the host).
+/* ------------------------------------------------- compacted output: the pairs in position order */
+
+/* The scan leaves (position, id) pairs in the order its walks finished.  Positions are DISTINCT keys below n, so they
+ * are ordered with a counting pass over position bins and a rank inside each bin -- four short launches over the pairs
+ * (~0.6 M for the bench stream, ~35 us together) instead of a general radix sort (rocPRIM Onesweep: a histogram and four
+ * digit passes with decoupled look-back, 0.12 ms for the same pairs).  The number of pairs is read from the device
+ * counter: the launches are queued behind the scan without the host knowing it.
+ *   pfac_order_count    pairs per bin (bin = position >> shift, at most 2^16 bins).  64 consecutive pairs of the list
+ *                       come from four flushes of scanning waves, i.e. from a handful of bins: one atomic per distinct
+ *                       bin and wave, not per pair (the part sustains ~25 atomics per ns)
+ *   pfac_order_offsets  exclusive prefix sum of the counters: block k sums everything in front of its 1024 counters
+ *                       itself (at most 252 KiB, coalesced, from L2) -- no pass between blocks; lists the bins with
+ *                       more than 64 pairs
+ *   pfac_order_scatter  pair -> its bin's range of the scratch arrays (any order inside the bin); the lanes of a wave
+ *                       that share a bin share one atomic, all of a wave's atomics are one instruction
+ *   pfac_order_rank     one thread per pair: final place = bin start + number of smaller positions in the bin; then
+ *                       the bins with more than 64 pairs, one block per listed bin: the bin's positions as a bitmap
+ *                       in LDS, rank = set bits below
+ * More pairs than the scratch arrays hold: every launch leaves at once, the host grows the scratch and queues them again.
  */
+constexpr unsigned kOrderMaxBinsLog2 = 16;
+constexpr unsigned kOrderMinShift = 6;           /* a bin of 64 positions holds at most 64 pairs */
+constexpr unsigned kOrderMaxShift = 15;          /* int input_size < 2^31 */
+constexpr unsigned kOrderBlockBins = 1024;       /* counters per block of pfac_order_offsets */
+constexpr unsigned kOrderCrowded = 64;
+constexpr int kReduceCountWord = 40 * 32;        /* the pair counter of a compacted-output call: a line of the launch counters the scan does not use
+                                                    (cleared with them) */
+
+struct OrderArgs {
+    const unsigned int *posIn;     /* the scan's pairs, any order */
+    const int *idIn;
+    const unsigned int *count;     /* device counter of the pairs */
+    unsigned int capacity;         /* pairs posTmp / idTmp hold */
+    unsigned int shift;
+    unsigned int bins;
+    unsigned int *counts;          /* bins rounded up to whole blocks (zeros), then the crowded bins' counter */
+    unsigned int *cursor;          /* same length: start -> (after the scatter) end of each bin */
+    unsigned int *crowdedCount;
+    unsigned int *crowded;         /* bins */
+    unsigned int *posTmp;
+    int *idTmp;
+    unsigned int *posOut;
+    int *idOut;
+};
+
+__global__ __launch_bounds__(256) void pfac_order_count(OrderArgs o)
+{
+    const unsigned int count = *o.count;
+    if (count > o.capacity) return;
+    const unsigned int lane = threadIdx.x & 63u;
+    for (unsigned int first = blockIdx.x * 256u + (threadIdx.x & ~63u); first < count; first += gridDim.x * 256u) {
+        const bool has = first + lane < count;
+        const unsigned int b = has ? o.posIn[first + lane] >> o.shift : 0xFFFFFFFFu;
+        unsigned long long todo = __ballot(has);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned int b0 = (unsigned int)__builtin_amdgcn_readlane((int)b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            if ((int)lane == leader) atomicAdd(&o.counts[b0], (unsigned int)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+/* sum over the block's 256 threads (every thread gets it) and the exclusive prefix of `own` among them */
+__device__ __forceinline__ unsigned int blockScan256(unsigned int own, unsigned int *waveSum, unsigned int &total)
+{
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int up = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += up;
+    }
+    __syncthreads();                                    /* waveSum may still be read from the previous call */
+    if (lane == 63) waveSum[wave] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+    total = 0;
+    for (unsigned int w = 0; w < 4; w++) {
+        if (w < wave) before += waveSum[w];
+        total += waveSum[w];
+    }
+    return before + incl - own;
+}
+
+__global__ __launch_bounds__(256) void pfac_order_offsets(OrderArgs o)
+{
+    __shared__ unsigned int waveSum[4];
+    if (*o.count > o.capacity) return;
+    const unsigned int t = threadIdx.x;
+    const unsigned int firstQuad = blockIdx.x * (kOrderBlockBins / 4);
+    const u32x4 *all = reinterpret_cast<const u32x4 *>(o.counts);
+    unsigned int front = 0;
+    unsigned int q = t;
+    for (; q + 7u * 256u < firstQuad; q += 8u * 256u) {                 /* eight loads in flight: the last block reads 252 KiB */
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = all[q + k * 256u];
+#pragma unroll
+        for (int k = 0; k < 8; k++) front += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    for (; q < firstQuad; q += 256u) {
+        const u32x4 v = all[q];
+        front += v.x + v.y + v.z + v.w;
+    }
+    const u32x4 c = all[firstQuad + t];
+    unsigned int base = 0, ignored = 0;
+    (void)blockScan256(front, waveSum, base);
+    unsigned int run = base + blockScan256(c.x + c.y + c.z + c.w, waveSum, ignored);
+    const unsigned int bin = (firstQuad + t) * 4;
+    if (c.x > kOrderCrowded) o.crowded[atomicAdd(o.crowdedCount, 1u)] = bin;
+    if (c.y > kOrderCrowded) o.crowded[atomicAdd(o.crowdedCount, 1u)] = bin + 1;
+    if (c.z > kOrderCrowded) o.crowded[atomicAdd(o.crowdedCount, 1u)] = bin + 2;
+    if (c.w > kOrderCrowded) o.crowded[atomicAdd(o.crowdedCount, 1u)] = bin + 3;
+    u32x4 s;
+    s.x = run; run += c.x;
+    s.y = run; run += c.y;
+    s.z = run; run += c.z;
+    s.w = run;
+    reinterpret_cast<u32x4 *>(o.cursor)[firstQuad + t] = s;
+}
+
+__global__ __launch_bounds__(256) void pfac_order_scatter(OrderArgs o)
+{
+    const unsigned int count = *o.count;
+    if (count > o.capacity) return;
+    const unsigned int lane = threadIdx.x & 63u;
+    for (unsigned int first = blockIdx.x * 256u + (threadIdx.x & ~63u); first < count; first += gridDim.x * 256u) {
+        const bool has = first + lane < count;
+        const unsigned int p = has ? o.posIn[first + lane] : 0xFFFFFFFFu;
+        const int id = has ? o.idIn[first + lane] : 0;
+        const unsigned int b = has ? p >> o.shift : 0xFFFFFFFFu;
+        /* the lanes that share a bin: the first of them takes the bin's cursor forward for all */
+        unsigned int myLeader = lane, myRank = 0, groupSize = 0;
+        unsigned long long todo = __ballot(has);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned int b0 = (unsigned int)__builtin_amdgcn_readlane((int)b, leader);
+            const unsigned long long same = __ballot(b == b0);
+            if (b == b0) {
+                myLeader = (unsigned int)leader;
+                myRank = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+                groupSize = (unsigned int)__popcll(same);
+            }
+            todo &= ~same;
+        }
+        unsigned int base = 0;
+        if (has && lane == myLeader) base = atomicAdd(&o.cursor[b], groupSize);
+        base = (unsigned int)__shfl((int)base, (int)myLeader);
+        if (has) { o.posTmp[base + myRank] = p; o.idTmp[base + myRank] = id; }
+    }
+}
+
+__global__ __launch_bounds__(256) void pfac_order_rank(OrderArgs o)
+{
+    __shared__ unsigned int bits[1u << (kOrderMaxShift - 5)];      /* the positions of one crowded bin */
+    __shared__ unsigned int below[1u << (kOrderMaxShift - 5)];     /* set bits in front of each word */
+    __shared__ unsigned int waveSum[4];
+    const unsigned int count = *o.count;
+    if (count > o.capacity) return;
+    const unsigned int listed = *o.crowdedCount;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const unsigned int p = o.posTmp[i];
+        const int id = o.idTmp[i];
+        const unsigned int b = p >> o.shift;
+        const unsigned int end = o.cursor[b], start = b ? o.cursor[b - 1] : 0u;
+        if (end - start > kOrderCrowded) continue;                       /* placed below */
+        unsigned int rank = 0;
+        for (unsigned int j = start; j < end; j++) rank += o.posTmp[j] < p ? 1u : 0u;
+        o.posOut[start + rank] = p;
+        o.idOut[start + rank] = id;
+    }
+    /* bins with more than 64 pairs, one block per listed bin (the same trip count for every thread of the block) */
+    const unsigned int t = threadIdx.x;
+    const unsigned int words = 1u << (o.shift - 5), mask = (1u << o.shift) - 1u;
+    for (unsigned int k = blockIdx.x; k < listed; k += gridDim.x) {
+        const unsigned int b = o.crowded[k];
+        const unsigned int end = o.cursor[b], start = b ? o.cursor[b - 1] : 0u, c = end - start;
+        for (unsigned int w = t; w < words; w += 256u) bits[w] = 0;
+        __syncthreads();
+        for (unsigned int e = t; e < c; e += 256u) {
+            const unsigned int p = o.posTmp[start + e] & mask;
+            atomicOr(&bits[p >> 5], 1u << (p & 31u));
+        }
+        __syncthreads();
+        /* exclusive prefix of the words' population counts: `per` consecutive words per thread */
+        const unsigned int per = words > 256u ? words / 256u : 1u;
+        unsigned int own = 0;
+        for (unsigned int j = 0; j < per; j++) {
+            const unsigned int w = t * per + j;
+            if (w < words) own += (unsigned int)__popc(bits[w]);
+        }
+        unsigned int ignored = 0;
+        unsigned int run = blockScan256(own, waveSum, ignored);
+        for (unsigned int j = 0; j < per; j++) {
+            const unsigned int w = t * per + j;
+            if (w < words) { below[w] = run; run += (unsigned int)__popc(bits[w]); }
+        }
+        __syncthreads();
+        for (unsigned int e = t; e < c; e += 256u) {
+            const unsigned int pos = o.posTmp[start + e], p = pos & mask;
+            const unsigned int rank = below[p >> 5] + (unsigned int)__popc(bits[p >> 5] & ((1u << (p & 31u)) - 1u));
+            o.posOut[start + rank] = pos;
+            o.idOut[start + rank] = o.idTmp[start + e];
+        }
+        __syncthreads();
+    }
+}
+
+unsigned int gridFor(const PFAC_context *c, size_t items)
+{
+    const size_t cap = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * 8;
+    const size_t blocks = (items + 255) / 256;
+    return (unsigned int)(blocks < 1 ? 1 : blocks > cap ? cap : blocks);
+}
+
 /* grow-only device scratch of the compacted-output path, owned by the handle (the caller holds its lock) */
 PFAC_status_t reduceScratch(PFAC_context *mc, size_t need, char **base)
 {
@@ -1584,98 +1792,124 @@ PFAC_status_t reduceScratch(PFAC_context *mc, size_t need, char **base)
     return PFAC_STATUS_SUCCESS;
 }
 
+/* The ordering of a compacted-output call over n input bytes: the handle's scratch cut into the arrays of OrderArgs
+ * (room for at least `pairs` pairs; all the scratch there is), then clearCounters() in front of the scan and order()
+ * behind it, both asynchronous on the null stream. */
+struct PairOrder {
+    OrderArgs o{};
+    size_t counterBytes = 0;
+
+    PFAC_status_t plan(PFAC_context *mc, size_t n, size_t pairs, int *d_ids, int *d_pos, const unsigned int *d_count)
+    {
+        unsigned int log2n = 1;
+        while (log2n < 32 && (n - 1) >> log2n) log2n++;
+        o.shift = log2n > kOrderMaxBinsLog2 + kOrderMinShift ? log2n - kOrderMaxBinsLog2 : kOrderMinShift;
+        if (o.shift > kOrderMaxShift) return PFAC_STATUS_INTERNAL_ERROR;
+        o.bins = (unsigned int)(((n - 1) >> o.shift) + 1);
+        const size_t padded = ((size_t)o.bins + kOrderBlockBins - 1) / kOrderBlockBins * kOrderBlockBins;
+        counterBytes = (padded * sizeof(unsigned int) + sizeof(unsigned int) + 255) / 256 * 256;
+        const size_t cursorBytes = padded * sizeof(unsigned int);
+        const size_t listBytes = ((size_t)o.bins * sizeof(unsigned int) + 255) / 256 * 256;
+        const size_t fixed = counterBytes + cursorBytes + listBytes;
+        const size_t arrayBytes = (pairs * sizeof(int) + 255) / 256 * 256;
+        char *base = nullptr;
+        const PFAC_status_t st = reduceScratch(mc, fixed + 2 * arrayBytes, &base);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+        const size_t perArray = (mc->reduceScratchBytes - fixed) / 2 / 256 * 256;
+        o.capacity = perArray / sizeof(int) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)(perArray / sizeof(int));
+        o.counts = reinterpret_cast<unsigned int *>(base);
+        o.crowdedCount = o.counts + padded;
+        o.cursor = reinterpret_cast<unsigned int *>(base + counterBytes);
+        o.crowded = reinterpret_cast<unsigned int *>(base + counterBytes + cursorBytes);
+        o.posTmp = reinterpret_cast<unsigned int *>(base + fixed);
+        o.idTmp = reinterpret_cast<int *>(base + fixed + perArray);
+        o.posIn = o.posOut = reinterpret_cast<unsigned int *>(d_pos);
+        o.idIn = o.idOut = d_ids;
+        o.count = d_count;
+        return PFAC_STATUS_SUCCESS;
+    }
+    hipError_t clearCounters() const { return hipMemsetAsync(o.counts, 0, counterBytes, 0); }
+    hipError_t order(const PFAC_context *c) const
+    {
+        const unsigned int grid = gridFor(c, o.capacity);
+        hipLaunchKernelGGL(pfac_order_count, dim3(grid), dim3(256), 0, 0, o);
+        hipLaunchKernelGGL(pfac_order_offsets, dim3((o.bins + kOrderBlockBins - 1) / kOrderBlockBins), dim3(256), 0, 0, o);
+        hipLaunchKernelGGL(pfac_order_scatter, dim3(grid), dim3(256), 0, 0, o);
+        hipLaunchKernelGGL(pfac_order_rank, dim3(grid), dim3(256), 0, 0, o);
+        return hipGetLastError();
+    }
+};
+
+/*
+ * Compacted output (ref PFAC_reduce_kernel / PFAC_reduce_inplace_kernel, PFAC_reduce_kernel.cu:172-295,
+ * PFAC_reduce_inplace_kernel.cu:155-323): the first *h_num_matched entries of d_match_result / d_pos
+ * receive the non-zero results and their positions in ascending position order.
+ *
+ * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
+ * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
+ * device counter.  The end of the input (and the <= 15 positions in front of the first aligned byte; everything, for
+ * a small input) goes through the simple kernel, which appends to the same list.  The list is then put in position
+ * order (PairOrder) by launches queued behind the scan; the host reads the count once, at the end (synchronous, like
+ * the reference's call).
+ * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
+ * (PFAC_reduce_kernel.cu:417-457) because it has no prefilter: every thread owns a result.
+ */
 PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_size, int *d_match_result, int *d_pos,
                          int *h_num_matched, int *h_match_result, int *h_pos, bool hashed)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (!d_input_string || !d_match_result || !d_pos || !h_num_matched || input_size <= 0) return PFAC_STATUS_INVALID_PARAMETER;
     const PFAC_context *c = handle;
-    if (!c->d_reduceCount) return PFAC_STATUS_INTERNAL_ERROR;
     const size_t n = (size_t)input_size;
     ScanArgs a;
     PFAC_status_t st = fillArgs(c, hashed, reinterpret_cast<const char *>(d_input_string), n, d_match_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
-    unsigned int count = 0;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
+    unsigned int *d_count = c->d_workCounters + kReduceCountWord;
+    const bool ordered = !c->reduceUnordered;              /* PFAC_matchFromHost scatters the pairs: any order */
 
-    /* positions [first, first + len) through the simple kernel: full results into the handle's scratch, compacted on
-     * the host and appended to the caller's arrays (the <= 15 positions in front of the first 16-byte aligned input
-     * byte, and the end of the input) */
-    auto simpleRange = [&](size_t first, size_t len) -> PFAC_status_t {
-        if (!len) return PFAC_STATUS_SUCCESS;
-        char *scratch = nullptr;
-        PFAC_status_t s2 = reduceScratch(handle, len * sizeof(int), &scratch);
-        if (s2 != PFAC_STATUS_SUCCESS) return s2;
-        int *d_full = reinterpret_cast<int *>(scratch);
-        ScanArgs part = a;
-        part.in = a.in + first;
-        part.out = d_full;
-        part.owned = len;
-        part.n = n - first;
-        if (launchNaiveFor(c, hashed, tex, part, 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        std::vector<int> full(len), ids, pos;
-        if (hipMemcpy(full.data(), d_full, len * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        for (size_t i = 0; i < len; i++)
-            if (full[i] > 0) { ids.push_back(full[i]); pos.push_back((int)(first + i)); }
-        if (!ids.empty() && (hipMemcpy(d_match_result + count, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                             hipMemcpy(d_pos + count, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
-            return PFAC_STATUS_INTERNAL_ERROR;
-        count += (unsigned int)ids.size();
-        return PFAC_STATUS_SUCCESS;
-    };
-
+    PairOrder order;
+    if (ordered) {
+        const size_t expected = n / 128 > 65536 ? n / 128 : 65536;       /* room for one match per 128 bytes before the first call has been seen */
+        st = order.plan(handle, n, expected, d_match_result, d_pos, d_count);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+        if (order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    }
     const size_t head = headPositions(a.in, n);
-    try {
-        st = simpleRange(0, head);
-    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
-    if (st != PFAC_STATUS_SUCCESS) return st;
     const size_t mainLen = filterLength(c, head, n, n, true);
+    a.reducePos = d_pos;
+    a.reduceCount = d_count;
     if (mainLen) {
         ScanArgs part = a;
         part.in = a.in + head;
         part.n = part.owned = mainLen;
-        part.reducePos = d_pos;
-        part.reduceCount = c->d_reduceCount;
         part.reduceBase = (unsigned int)head;
-        /* the kernel appends behind the matches of the head */
-        if (hipMemcpyAsync(c->d_reduceCount, &count, sizeof(unsigned int), hipMemcpyHostToDevice, 0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        hipError_t e;
-        e = launchChained<true>(c, part, tex);
-        if (e != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        if (hipMemcpy(&count, c->d_reduceCount, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        if (count > 1 && !c->reduceUnordered) {            /* order by position (PFAC_matchFromHost scatters the pairs: any order) */
-            size_t tempBytes = 0;
-            unsigned int *keysIn = reinterpret_cast<unsigned int *>(d_pos);
-            unsigned int *nullKeys = nullptr;
-            int *nullVals = nullptr;
-            unsigned int keyBits = 1;                      /* positions are below n: fewer digits to sort */
-            while (keyBits < 32 && (n - 1) >> keyBits) keyBits++;
-            /* rocPRIM sorts fewer than 2^20 items with a merge sort: a block sort and ten merge passes, 0.14 ms for the
-             * 583 K pairs of the bench stream.  Onesweep from 2^16 items on: four digit passes */
-            using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
-            if (rocprim::radix_sort_pairs<SortConfig>(nullptr, tempBytes, keysIn, nullKeys, d_match_result, nullVals, count, 0, keyBits, 0) != hipSuccess)
-                return PFAC_STATUS_INTERNAL_ERROR;
-            /* scratch = sorted keys | sorted values | rocPRIM workspace, each 256-byte aligned */
-            const size_t arrayBytes = ((size_t)count * sizeof(int) + 255) / 256 * 256;
-            const size_t need = 2 * arrayBytes + (tempBytes ? tempBytes : 4);
-            char *base = nullptr;
-            st = reduceScratch(handle, need, &base);
-            if (st != PFAC_STATUS_SUCCESS) return st;
-            unsigned int *keysOut = reinterpret_cast<unsigned int *>(base);
-            int *valuesOut = reinterpret_cast<int *>(base + arrayBytes);
-            void *temp = base + 2 * arrayBytes;
-            hipError_t se = rocprim::radix_sort_pairs<SortConfig>(temp, tempBytes, keysIn, keysOut, d_match_result, valuesOut, count, 0, keyBits, 0);
-            if (se == hipSuccess) se = hipMemcpyAsync(d_pos, keysOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
-            if (se == hipSuccess) se = hipMemcpyAsync(d_match_result, valuesOut, count * sizeof(int), hipMemcpyDeviceToDevice, 0);
-            if (se == hipSuccess) se = hipStreamSynchronize(0);
-            if (se != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-        }
+        if (launchChained<true>(c, part, tex) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;      /* clears the launch counters, d_count with them */
+    } else if (hipMemsetAsync(d_count, 0, sizeof(unsigned int), 0) != hipSuccess) {
+        return PFAC_STATUS_INTERNAL_ERROR;
     }
-    /* the rest: its positions follow all others (the sort above is finished: same scratch) */
-    try {
-        st = simpleRange(head + mainLen, n - head - mainLen);
-    } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    /* positions [first, first + len) through the simple kernel, which appends its matches to the list */
+    auto simpleRange = [&](size_t first, size_t len) -> PFAC_status_t {
+        if (!len) return PFAC_STATUS_SUCCESS;
+        ScanArgs part = a;
+        part.in = a.in + first;
+        part.owned = len;
+        part.n = n - first;
+        part.reduceBase = (unsigned int)first;
+        return launchNaiveFor(c, hashed, tex, part, 0) == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
+    };
+    st = simpleRange(0, head);
+    if (st == PFAC_STATUS_SUCCESS) st = simpleRange(head + mainLen, n - head - mainLen);
     if (st != PFAC_STATUS_SUCCESS) return st;
+    if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    unsigned int count = 0;
+    if (hipMemcpy(&count, d_count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    if (count > (unsigned int)input_size) return PFAC_STATUS_INTERNAL_ERROR;
+    if (ordered && count > order.o.capacity) {             /* more pairs than the scratch held: the launches left at once */
+        st = order.plan(handle, n, count, d_match_result, d_pos, d_count);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+        if (order.clearCounters() != hipSuccess || order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    }
     *h_num_matched = (int)count;
     if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;

@@ -169,3 +169,44 @@ def test_misaligned_pointers_stay_on_the_vector_kernel(workdir, capsys):
     with capsys.disabled():
         print("\n[64 MiB Snort-style, (input byte offset, result int offset) -> input GB/s]", rates)
     assert min(rates.values()) >= 0.8 * rates[(0, 0)], rates
+
+
+@pytest.mark.parametrize("n,everywhere", [((3 << 20) + 77, False), ((48 << 20) + 5, False), ((300 << 20) + 1, False), ((1 << 30) + 4097, False),
+                                          ((3 << 29) + 123, False), ((4 << 20) + 9, True), ((96 << 20) + 1, True)])
+def test_compacted_output_is_in_position_order_at_every_bin_shape(workdir, n, everywhere):
+    """PFAC_matchFromDeviceReduce orders its pairs with position bins (scan_gfx950.hip: orderPairs): the bin width follows
+    the input size (64 positions ... 32 Ki positions), a bin with more than 64 pairs is ranked through a bitmap in LDS.
+    Inputs with crowded stretches (one position in eight matches) between sparse ones, at sizes that take every bin
+    width class -- and crowded everywhere: more pairs than the handle's scratch holds on a first call, the launches leave
+    and are queued again behind a larger one; expected = the non-zero entries of the full result of the same handle (itself checked against the
+    oracle in test_gpu_parity.py), which is the reference's definition of the compacted output
+    (PFAC_reduce_kernel.cu:417-457: a stable compaction of the full result)."""
+    pats = [b"h", b"ab", b"abc", b"gfe", b"mnop", b"xyzzy", b"qq", b"nopqrstu"]
+    pf = wl.write_pattern_file(os.path.join(workdir, f"order{n}.pat"), pats)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(n & 0xFFFF)
+    crowded = torch.randint(97, 105, (n,), dtype=torch.uint8, device="cuda:0", generator=g)       # 'a'..'h'
+    d_in = torch.randint(105, 123, (n,), dtype=torch.uint8, device="cuda:0", generator=g)         # 'i'..'z'
+    for lo, hi in (((0, n),) if everywhere else ((0, 70_000), (n // 3, n // 3 + (n >> 5)), (n - 50_000, n))):   # start, a stretch inside, the very end
+        d_in[lo:hi] = crowded[lo:hi]
+    del crowded
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC, api.PFACX_KERNEL_AUTO)
+    try:
+        d_full = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        h.matchFromDevice(d_in.data_ptr(), n, d_full.data_ptr())
+        want_pos = torch.nonzero(d_full).flatten()
+        want_ids = d_full[want_pos]
+        del d_full
+        d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+        d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+        for _ in range(2):                                       # the second call finds the scratch of the first
+            st, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+            torch.cuda.synchronize()
+            assert count == want_pos.numel() and count > n >> 9
+            assert torch.equal(d_pos[:count].to(torch.int64), want_pos), "positions"
+            assert torch.equal(d_res[:count], want_ids), "pattern IDs"
+            assert int(d_pos[count:].max()) == -5 and int(d_res[count:].max()) == -5, "wrote behind the pairs"
+            d_res.fill_(-5)
+            d_pos.fill_(-5)
+    finally:
+        h.destroy()

@@ -13,7 +13,7 @@ for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json
     cp(a, b)
 for w in ("c3", "c2"):
     rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
-    keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "radix" in r[0] or "fillBuffer" in r[0]]
+    keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "pfac_order" in r[0] or "fillBuffer" in r[0]]
     csv.writer(open(os.path.join("profiles", f"{tag}_{w}_rocprofv3_kernel_stats.csv"), "w")).writerows(keep)
     cp(os.path.join(f"traffic_{w}", "summary.json"), f"hbm_traffic_{w}.json")
     d = json.load(open(os.path.join("profiles", f"{tag}_hbm_traffic_{w}.json")))

@@ -668,7 +668,15 @@ def rank_main(args):
                 eb.record(0)
             torch.cuda.synchronize()
             tr = (time.perf_counter() - t0r) / 5
-            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel + sort + copies, on the launch stream
+            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel + simple kernel + ordering launches + the count's copy, on the launch stream
+            # the scan kernel alone: the library brackets its launch with HIP events when asked (two more calls, not in the figures above)
+            run.handle.setKernelTiming(True)
+            kms = []
+            for _ in range(3):
+                run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
+                kms.append(run.handle.scanStats().get("filterKernelMs"))
+            run.handle.setKernelTiming(False)
+            kernel_ms_reduce = float(np.median([k for k in kms if k is not None])) if any(k is not None for k in kms) else None
             rp = d_pos[:rcount].cpu().numpy().astype(np.int64)
             ri = run.d_out[:rcount].cpu().numpy()
             keep = rp < n
@@ -676,13 +684,16 @@ def rank_main(args):
             algo = int(run.n_read + 8 * rcount)
             out["reduce_api"] = {"value": round(run.n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
                                  "gpu_ms": round(gpu_ms, 4), "host_overhead_ms": round(tr * 1e3 - gpu_ms, 4),
+                                 "kernel_ms": None if kernel_ms_reduce is None else round(kernel_ms_reduce, 4),
+                                 "behind_the_kernel_ms": None if kernel_ms_reduce is None else round(gpu_ms - kernel_ms_reduce, 4),
                                  "matches": int(rcount), "same_result_as_full_vector": same,
                                  "pairs_checksum": int(sharding.position_checksum(rp[keep], ri[keep])), "full_vector_checksum": int(checksum),
                                  "algorithmic_bytes_per_call": algo,
                                  "roofline": {"bound": "hbm", "achieved": round(algo / (gpu_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(algo / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: scan kernel, sort by position, copies); "
-                                                      "the scan kernel alone is in profiles/ (rocprofv3 kernel stats); this path is bound by the scanning waves' instruction issue, not by HBM"},
+                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: scan kernel, simple kernel over the input's end, four ordering launches, "
+                                                      "the count's copy); kernel_ms = the scan kernel alone (PFACX_setKernelTiming; rocprofv3 kernel stats in profiles/ agree); this path is "
+                                                      "bound by the scanning waves' instruction issue, not by HBM"},
                                  "note": "PFAC_matchFromDeviceReduce, synchronous (the match count returns to the host); ~1 B of HBM traffic per input byte"}
             if not same:
                 all_ok = False

@@ -143,9 +143,16 @@ typedef struct {
                                              pattern): what the prefix ladder was asked about                  */
     unsigned long long denseChunks;       /* 2 KiB chunks in which more than 90 % of the positions passed level 1:
                                              left to the simple kernel that follows the filter kernel          */
+    double filterKernelMs;                /* GPU time of that launch of the filter kernel alone (HIP events around it);
+                                             -1 unless PFACX_setKernelTiming(handle, 1) was in force           */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);
+
+/* Measurement aid: with `on` != 0 every launch of the filter kernel on this handle is bracketed by two HIP events on
+ * the default stream (a few microseconds per call); PFACX_getScanStats then reports the kernel's own time -- inside
+ * PFAC_matchFromDeviceReduce, say, whose other launches a caller's events cannot tell apart. */
+PFAC_status_t PFACX_setKernelTiming(PFAC_handle_t handle, int on);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ class PFACX_info(C.Structure):
 class PFACX_scan_stats(C.Structure):
     _fields_ = [("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
                 ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
-                ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong)]
+                ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong), ("filterKernelMs", C.c_double)]
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = (
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
     "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
+    "PFACX_setKernelTiming",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -128,6 +129,7 @@ def load_library() -> C.CDLL:
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
     lib.PFACX_trim.argtypes = [H]
+    lib.PFACX_setKernelTiming.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromFileEx.argtypes = [H, C.c_char_p, C.c_uint]
     lib.PFACX_readPatternFromMemoryEx.argtypes = [H, C.c_char_p, C.c_size_t, C.c_uint]
     lib.PFACX_getScanStats.argtypes = [H, C.POINTER(PFACX_scan_stats)]
@@ -233,6 +235,10 @@ class PFAC:
         """``PFACX_trim``: free the handle's grow-only device temporaries."""
         return self._ret(self._lib.PFACX_trim(self._h), "PFACX_trim", check)
 
+    def setKernelTiming(self, on: bool, check: bool = True) -> int:
+        """``PFACX_setKernelTiming``: HIP events around the filter kernel's launch; ``scanStats().filterKernelMs``."""
+        return self._ret(self._lib.PFACX_setKernelTiming(self._h, 1 if on else 0), "PFACX_setKernelTiming", check)
+
     def readPatternFromFileEx(self, filename, flags: int, check: bool = True) -> int:
         """``PFACX_readPatternFromFileEx``: flags = PFACX_READ_STRICT | PFACX_READ_STRIP_CR."""
         name = None if filename is None else os.fsencode(filename)
@@ -307,7 +313,9 @@ class PFAC:
         (`positions` = input bytes of that launch)."""
         st = PFACX_scan_stats()
         self._ret(self._lib.PFACX_getScanStats(self._h, C.byref(st)), "PFACX_getScanStats", True)
-        d = {name: int(getattr(st, name)) for name, _ in PFACX_scan_stats._fields_}
+        d = {name: int(getattr(st, name)) for name, _ in PFACX_scan_stats._fields_ if name != "filterKernelMs"}
+        if st.filterKernelMs >= 0:
+            d["filterKernelMs"] = float(st.filterKernelMs)
         if d["walkerRounds"]:
             d["avg_table_steps_per_walk"] = round(d["laneSteps"] / max(1, d["walksStarted"]), 3)
             d["lane_utilisation"] = round(d["laneSteps"] / (d["walkerRounds"] * 64.0 * d["walksPerLane"]), 4)

@@ -84,6 +84,8 @@ void freeResources(PFAC_context *c)
     devFree(c->d_hostReduce);
     c->hostReduceBytes = 0;
     freeHostStage(c);
+    for (auto &e : c->evTime) { if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e)); e = nullptr; }
+    c->kernelTiming = c->evTimeRecorded = false;
     devFree(c->d_final3);
     devFree(c->d_denseList);
     c->denseListEntries = 0;
@@ -1093,8 +1095,32 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     unsigned int dense = 0;                                  /* scan_gfx950.hip kDenseCountWord: counter line 32 */
     if (hipMemcpy(&dense, handle->d_workCounters + 32 * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     stats->denseChunks = dense;
+    stats->filterKernelMs = -1.0;
+    if (handle->kernelTiming && handle->evTimeRecorded && handle->evTime[0] && handle->evTime[1]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, static_cast<hipEvent_t>(handle->evTime[0]), static_cast<hipEvent_t>(handle->evTime[1])) == hipSuccess) stats->filterKernelMs = ms;
+        else (void)hipGetLastError();
+    }
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = PFAC_WALK_SETS_FULL;        /* of the full-result kernel; the compacted-output kernel runs PFAC_WALK_SETS */
+    return PFAC_STATUS_SUCCESS;
+}
+
+PFAC_status_t PFACX_setKernelTiming(PFAC_handle_t handle, int on)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    std::lock_guard<std::mutex> guard(handle->lock);
+    if (!handle->hasDevice) return PFAC_STATUS_LIB_NOT_EXIST;
+    handle->evTimeRecorded = false;
+    if (on) {
+        for (auto &e : handle->evTime)
+            if (!e) {
+                hipEvent_t ev = nullptr;
+                if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return PFAC_STATUS_INTERNAL_ERROR; }
+                e = ev;
+            }
+    }
+    handle->kernelTiming = on != 0;
     return PFAC_STATUS_SUCCESS;
 }
 

@@ -189,6 +189,10 @@ struct PFAC_context {
     int *d_stagePos[2] = {nullptr, nullptr};  /* positions of the compacted results of a piece (PFAC_matchFromHost) */
     size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
     void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */
+    /* PFACX_setKernelTiming: HIP events around the launch of the filter kernel (PFACX_getScanStats reports the time) */
+    bool kernelTiming = false;
+    void *evTime[2] = {nullptr, nullptr};                          /* hipEvent_t */
+    mutable bool evTimeRecorded = false;
     void *evUp[2] = {nullptr, nullptr}, *evScan[2] = {nullptr, nullptr}, *evDown[2] = {nullptr, nullptr};   /* hipEvent_t */
     unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
     uint32_t *d_final3 = nullptr;

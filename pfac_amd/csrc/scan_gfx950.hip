@@ -1365,8 +1365,11 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     if (blocks > resident) blocks = resident;
     hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
+    const bool timed = c->kernelTiming && c->evTime[0] && c->evTime[1];
+    if (timed) (void)hipEventRecord(static_cast<hipEvent_t>(c->evTime[0]), 0);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     e = hipGetLastError();
+    if (timed) c->evTimeRecorded = hipEventRecord(static_cast<hipEvent_t>(c->evTime[1]), 0) == hipSuccess;
 #if PFAC_TIMING
     {
         unsigned long long t[18];

@@ -210,3 +210,35 @@ def test_compacted_output_is_in_position_order_at_every_bin_shape(workdir, n, ev
             d_pos.fill_(-5)
     finally:
         h.destroy()
+
+
+def test_kernel_timing_reports_the_filter_kernel_alone(workdir):
+    """PFACX_setKernelTiming: HIP events around the filter kernel's launch; PFACX_getScanStats reports its time
+    (bench.py: reduce_api.kernel_ms).  Off by default; results do not change."""
+    cfg = wl.make_config("c3")
+    pf = wl.write_pattern_file(os.path.join(workdir, "timing.pat"), cfg.patterns)
+    n = 8 << 20
+    d_in = torch.from_numpy(cfg.input_slice(n, 0)).to("cuda:0")
+    d_res = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    d_pos = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC, api.PFACX_KERNEL_AUTO)
+    try:
+        _, count0 = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+        assert "filterKernelMs" not in h.scanStats()
+        first = (d_res[:count0].clone(), d_pos[:count0].clone())
+        h.setKernelTiming(True)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+        b.record()
+        torch.cuda.synchronize()
+        ms = h.scanStats()["filterKernelMs"]
+        assert count == count0 and torch.equal(d_res[:count], first[0]) and torch.equal(d_pos[:count], first[1])
+        assert 0.0 < ms < a.elapsed_time(b), (ms, a.elapsed_time(b))
+        h.matchFromDevice(d_in.data_ptr(), n, d_res.data_ptr())              # the full-result launch is bracketed too
+        assert 0.0 < h.scanStats()["filterKernelMs"] < 5.0
+        h.setKernelTiming(False)
+        h.matchFromDevice(d_in.data_ptr(), n, d_res.data_ptr())
+        assert "filterKernelMs" not in h.scanStats()
+    finally:
+        h.destroy()

@@ -35,8 +35,7 @@ struct Int2 { int x, y; };                    /* device layout of the hashed tab
 #define PFAC_WORK_PARTS 2
 #endif
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
-constexpr int kWorkCounterWords = 64 * 32 + 64;   /* 64 counters, one per 128-byte line (0..31 the parts of the input, 32 the dense-chunk list, 40 the pairs of a
-                                                     compacted-output call), + the launch statistics */
+constexpr int kWorkCounterWords = 64 * 32 + 64;   /* 64 counters, one per 128-byte line (0..31 the parts of the input, 32 the dense-chunk list), + the launch statistics */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */

@@ -1498,8 +1498,7 @@ size_t headPositions(const unsigned char *in, size_t input_size)
     return head < input_size ? head : input_size;
 }
 
-template <class Launch>
-hipError_t launchNaiveFor(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part, Launch &&)
+hipError_t launchNaiveFor(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part)
 {
     if (hashed) return tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
     return tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
@@ -1520,7 +1519,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         ScanArgs part = a;
         part.owned = head;
         part.n = input_size;
-        e = launchNaiveFor(c, hashed, tex, part, 0);
+        e = launchNaiveFor(c, hashed, tex, part);
     }
     for (size_t first = head; first < input_size && e == hipSuccess; first += kMaxLaunchBytes) {
         const size_t ownEnd = input_size - first < kMaxLaunchBytes ? input_size : first + kMaxLaunchBytes;
@@ -1557,7 +1556,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             rest.out = part.out + mainLen;
             rest.owned = ownEnd - first - mainLen;
             rest.n = input_size - first - mainLen;
-            e = launchNaiveFor(c, hashed, tex, rest, 0);
+            e = launchNaiveFor(c, hashed, tex, rest);
         }
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
@@ -1588,17 +1587,15 @@ constexpr unsigned kOrderMinShift = 6;           /* a bin of 64 positions holds 
 constexpr unsigned kOrderMaxShift = 15;          /* int input_size < 2^31 */
 constexpr unsigned kOrderBlockBins = 1024;       /* counters per block of pfac_order_offsets */
 constexpr unsigned kOrderCrowded = 64;
-constexpr int kReduceCountWord = 40 * 32;        /* the pair counter of a compacted-output call: a line of the launch counters the scan does not use
-                                                    (cleared with them) */
 
 struct OrderArgs {
     const unsigned int *posIn;     /* the scan's pairs, any order */
     const int *idIn;
-    const unsigned int *count;     /* device counter of the pairs */
+    unsigned int *count;           /* device counter of the pairs (behind crowdedCount: one memset clears all counters of a call) */
     unsigned int capacity;         /* pairs posTmp / idTmp hold */
     unsigned int shift;
     unsigned int bins;
-    unsigned int *counts;          /* bins rounded up to whole blocks (zeros), then the crowded bins' counter */
+    unsigned int *counts;          /* bins rounded up to whole blocks (zeros), then the crowded bins' counter and the pairs' counter */
     unsigned int *cursor;          /* same length: start -> (after the scatter) end of each bin */
     unsigned int *crowdedCount;
     unsigned int *crowded;         /* bins */
@@ -1802,7 +1799,7 @@ struct PairOrder {
     OrderArgs o{};
     size_t counterBytes = 0;
 
-    PFAC_status_t plan(PFAC_context *mc, size_t n, size_t pairs, int *d_ids, int *d_pos, const unsigned int *d_count)
+    PFAC_status_t plan(PFAC_context *mc, size_t n, size_t pairs, int *d_ids, int *d_pos)
     {
         unsigned int log2n = 1;
         while (log2n < 32 && (n - 1) >> log2n) log2n++;
@@ -1810,7 +1807,7 @@ struct PairOrder {
         if (o.shift > kOrderMaxShift) return PFAC_STATUS_INTERNAL_ERROR;
         o.bins = (unsigned int)(((n - 1) >> o.shift) + 1);
         const size_t padded = ((size_t)o.bins + kOrderBlockBins - 1) / kOrderBlockBins * kOrderBlockBins;
-        counterBytes = (padded * sizeof(unsigned int) + sizeof(unsigned int) + 255) / 256 * 256;
+        counterBytes = (padded * sizeof(unsigned int) + 2 * sizeof(unsigned int) + 255) / 256 * 256;
         const size_t cursorBytes = padded * sizeof(unsigned int);
         const size_t listBytes = ((size_t)o.bins * sizeof(unsigned int) + 255) / 256 * 256;
         const size_t fixed = counterBytes + cursorBytes + listBytes;
@@ -1822,13 +1819,13 @@ struct PairOrder {
         o.capacity = perArray / sizeof(int) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)(perArray / sizeof(int));
         o.counts = reinterpret_cast<unsigned int *>(base);
         o.crowdedCount = o.counts + padded;
+        o.count = o.crowdedCount + 1;
         o.cursor = reinterpret_cast<unsigned int *>(base + counterBytes);
         o.crowded = reinterpret_cast<unsigned int *>(base + counterBytes + cursorBytes);
         o.posTmp = reinterpret_cast<unsigned int *>(base + fixed);
         o.idTmp = reinterpret_cast<int *>(base + fixed + perArray);
         o.posIn = o.posOut = reinterpret_cast<unsigned int *>(d_pos);
         o.idIn = o.idOut = d_ids;
-        o.count = d_count;
         return PFAC_STATUS_SUCCESS;
     }
     hipError_t clearCounters() const { return hipMemsetAsync(o.counts, 0, counterBytes, 0); }
@@ -1868,29 +1865,18 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     PFAC_status_t st = fillArgs(c, hashed, reinterpret_cast<const char *>(d_input_string), n, d_match_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
-    unsigned int *d_count = c->d_workCounters + kReduceCountWord;
     const bool ordered = !c->reduceUnordered;              /* PFAC_matchFromHost scatters the pairs: any order */
 
+    /* the handle's scratch: the counters of this call (pairs, pairs per position bin), room to order the pairs through */
     PairOrder order;
-    if (ordered) {
-        const size_t expected = n / 128 > 65536 ? n / 128 : 65536;       /* room for one match per 128 bytes before the first call has been seen */
-        st = order.plan(handle, n, expected, d_match_result, d_pos, d_count);
-        if (st != PFAC_STATUS_SUCCESS) return st;
-        if (order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-    }
+    const size_t expected = n / 128 > 65536 ? n / 128 : 65536;       /* room for one match per 128 bytes before the first call has been seen */
+    st = order.plan(handle, n, expected, d_match_result, d_pos);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    if (order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     const size_t head = headPositions(a.in, n);
     const size_t mainLen = filterLength(c, head, n, n, true);
     a.reducePos = d_pos;
-    a.reduceCount = d_count;
-    if (mainLen) {
-        ScanArgs part = a;
-        part.in = a.in + head;
-        part.n = part.owned = mainLen;
-        part.reduceBase = (unsigned int)head;
-        if (launchChained<true>(c, part, tex) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;      /* clears the launch counters, d_count with them */
-    } else if (hipMemsetAsync(d_count, 0, sizeof(unsigned int), 0) != hipSuccess) {
-        return PFAC_STATUS_INTERNAL_ERROR;
-    }
+    a.reduceCount = order.o.count;
     /* positions [first, first + len) through the simple kernel, which appends its matches to the list */
     auto simpleRange = [&](size_t first, size_t len) -> PFAC_status_t {
         if (!len) return PFAC_STATUS_SUCCESS;
@@ -1899,19 +1885,30 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         part.owned = len;
         part.n = n - first;
         part.reduceBase = (unsigned int)first;
-        return launchNaiveFor(c, hashed, tex, part, 0) == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
+        return launchNaiveFor(c, hashed, tex, part) == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
     };
+    if (mainLen) {
+        ScanArgs part = a;
+        part.in = a.in + head;
+        part.n = part.owned = mainLen;
+        part.reduceBase = (unsigned int)head;
+        if (launchChained<true>(c, part, tex) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    }
+    /* (on a second stream, beside the start of the scan kernel, the simple kernel's 15 us are hidden -- and the two event
+     * waits that takes cost 10 us each: no gain, profiles/r03_experiments.md section 6) */
     st = simpleRange(0, head);
     if (st == PFAC_STATUS_SUCCESS) st = simpleRange(head + mainLen, n - head - mainLen);
     if (st != PFAC_STATUS_SUCCESS) return st;
     if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     unsigned int count = 0;
-    if (hipMemcpy(&count, d_count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    if (hipMemcpy(&count, order.o.count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     if (count > (unsigned int)input_size) return PFAC_STATUS_INTERNAL_ERROR;
     if (ordered && count > order.o.capacity) {             /* more pairs than the scratch held: the launches left at once */
-        st = order.plan(handle, n, count, d_match_result, d_pos, d_count);
+        st = order.plan(handle, n, count, d_match_result, d_pos);
         if (st != PFAC_STATUS_SUCCESS) return st;
-        if (order.clearCounters() != hipSuccess || order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        if (order.clearCounters() != hipSuccess || hipMemcpyAsync(order.o.count, &count, sizeof(count), hipMemcpyHostToDevice, 0) != hipSuccess ||
+            order.order(c) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)      /* `count` is read by that copy */
+            return PFAC_STATUS_INTERNAL_ERROR;
     }
     *h_num_matched = (int)count;
     if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)

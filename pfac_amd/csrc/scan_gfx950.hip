@@ -472,6 +472,12 @@ constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more
                                                 * (C3 0.97 / 0.96 / 0.93 / 0.90 ms per call with 8 / 4 / 2 / 0 levels, C5 1.37 / 1.28 / 1.22 / 1.16) */
 #endif
 constexpr int kReduceLadderLevels = PFAC_REDUCE_LADDER_LEVELS;
+#ifndef PFAC_APPEND_MIN
+#define PFAC_APPEND_MIN 48                     /* a ladder / append batch that the walk queue's room cuts short takes at least this many candidates (or waits
+                                                * for room): on walk-bound input the queue is always nearly full and batches of 16 cost as many instructions as
+                                                * full ones (C5 1.559 / 1.545 / 1.532 ms with 16 / 32 / 48; 64 = 48; C3 unchanged) */
+#endif
+constexpr uint32_t kAppendMin = PFAC_APPEND_MIN;
 #ifndef PFAC_PATCH_STAGED
 #define PFAC_PATCH_STAGED 0                    /* full-result kernel: 1 = finished matches are staged per wave in LDS and stored kReduceCap at a time */
 #endif
@@ -1143,7 +1149,7 @@ void pfac_scan_filter(ScanArgs a)
         for (;;) {
             const uint32_t left = listEnd - listAt, room = kQCap - (qv - qh);
             const uint32_t want = left < 64u ? left : 64u, take = room < want ? room : want;
-            if (left == 0 || (take != want && take < 16u)) break;
+            if (left == 0 || (take != want && take < kAppendMin)) break;
             const bool act = (uint32_t)lane < take;
             const uint32_t code = act ? listCode(listAt) : 0u;
             const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);

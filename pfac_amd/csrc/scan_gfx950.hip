@@ -152,6 +152,15 @@ struct ScanArgs {
     const unsigned char *denseIn;
     int *denseOut;
     size_t denseReadable;
+    /* the ends of the input, which the filter kernel's unchecked loads must not come near (the <= 15 positions in front
+     * of the first 16-byte aligned byte, and the last partial chunk + maxPatternLen + 64 bytes): positions [endsA0, endsA1)
+     * and [endsB0, endsB1) of endsIn (endsReadable bytes can be read), results to endsOut -- walked with bounds, one
+     * position per lane, by the first scanning wave of the first blocks BEFORE it starts scanning, so that their chain
+     * of dependent loads (15 us as a launch of its own behind the filter kernel: 2 % of a call) hides behind the scan */
+    const unsigned char *endsIn;
+    int *endsOut;
+    size_t endsReadable;
+    uint32_t endsA0, endsA1, endsB0, endsB1;
 };
 constexpr int kDenseCountWord = 32 * 32;                /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
                                                           line 32 counts the dense chunks (zeroed with the rest before every launch) */
@@ -432,6 +441,39 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         return cont;
     }
 };
+
+/* The longest pattern that starts at in[p], walked through the chained table from the initial state's bucket with every
+ * read checked against `readable` (a pattern that would run past the input does not match: ref PFAC_CPU.cpp:60-100, the
+ * walk stops at the last byte).  Same transition rule as ChainLane::advance, one byte compare at a time: for the few
+ * thousand positions at the ends of an input. */
+template <bool TEX>
+__device__ int boundedWalk(const ChainCtx<TEX> &c, const unsigned char *in, size_t p, size_t readable)
+{
+    uint32_t row = c.rootRow, ks = kRootKs;
+    size_t at = p;                                   /* position of the edge byte */
+    int match = 0;
+    while (at < readable) {
+        const uint32_t b0 = in[at];
+        const uint32_t idx = row + chainHashSlot(ks, b0);
+        u32x4 t;
+        if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
+        else t = c.slots[idx];
+        if ((t.x & (pfac::kSlotEmpty | 0xFFu)) != b0) break;
+        const uint32_t len = (t.x >> 8) & 0xFu;
+        if (at + len >= readable) break;             /* the chain's bytes at+1 .. at+len must exist */
+        const uint64_t chain = ((uint64_t)t.w << 32) | t.z;
+        bool ok = true;
+        for (uint32_t k = 0; k < len; k++) ok &= in[at + 1 + k] == (uint32_t)((chain >> (8u * k)) & 0xFFu);
+        if (!ok) break;
+        const bool leaf = (t.x & pfac::kSlotLeaf) != 0;
+        if (t.x & pfac::kSlotFinal) match = (int)(leaf ? t.y : t.w);
+        if (leaf) break;
+        row = t.y;
+        ks = t.x >> 15;
+        at += 1 + len;
+    }
+    return match;
+}
 
 /* --------------------------------------------------------- filter kernel */
 
@@ -849,6 +891,26 @@ void pfac_scan_filter(ScanArgs a)
 #endif
     } else {
     /* ---- scanning wave */
+    /* the ends of the input first (ScanArgs::endsIn), 64 positions per block: this wave then joins the scan a few
+     * microseconds late, which the others make up for -- chunks are claimed, not assigned */
+    if (wave == kWriters && a.endsIn != nullptr) {
+        const uint32_t lenA = a.endsA1 - a.endsA0, total = lenA + (a.endsB1 - a.endsB0);
+        const WCtx ends(a);
+        for (uint32_t first = blockIdx.x * 64u; first < total; first += gridDim.x * 64u) {
+            const uint32_t i = first + (uint32_t)lane;
+            if (i < total) {
+                const uint32_t p = i < lenA ? a.endsA0 + i : a.endsB0 + (i - lenA);
+                const int m = boundedWalk<TEX>(ends, a.endsIn, p, a.endsReadable);
+                if (!REDUCE) {
+                    a.endsOut[p] = m;
+                } else if (m > 0) {
+                    const unsigned int at = atomicAdd(a.reduceCount, 1u);
+                    a.out[at] = m;
+                    a.reducePos[at] = (int)p;        /* endsIn is the caller's first byte */
+                }
+            }
+        }
+    }
     /* ticket for the next chunk (lane 0 holds the answer): cheap, asked for one chunk ahead ... */
     /* Without writer waves the tickets come from the part's device counter, a granule of the front (adjacent chunks)
      * per atomic: the wave waits for the atomic's answer -- and, the counter being in-order, for its own loads in
@@ -1261,6 +1323,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 {
     __shared__ int sInit[pfac::kCharSet];
+    if (a.owned == 0 && (a.denseList == nullptr || a.work[kDenseCountWord] == 0)) return;      /* behind a filter launch that listed no dense chunk */
     sInit[threadIdx.x] = a.initialRow[threadIdx.x];
     __syncthreads();
     const Lookup<MODE> lookup(a);
@@ -1521,12 +1584,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     const bool vectorOk = (reinterpret_cast<uintptr_t>(a.out) & 3u) == 0;       /* an int vector that is not int-aligned: simple kernel only */
     hipError_t e = hipSuccess;
     const size_t head = vectorOk ? headPositions(a.in, input_size) : 0;
-    if (head) {
-        ScanArgs part = a;
-        part.owned = head;
-        part.n = input_size;
-        e = launchNaiveFor(c, hashed, tex, part);
-    }
+    bool headDone = head == 0;
     for (size_t first = head; first < input_size && e == hipSuccess; first += kMaxLaunchBytes) {
         const size_t ownEnd = input_size - first < kMaxLaunchBytes ? input_size : first + kMaxLaunchBytes;
         const size_t mainLen = filterLength(c, first, ownEnd, input_size, vectorOk);
@@ -1550,20 +1608,46 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             }
             part.denseList = handle->d_denseList;
             part.n = part.owned = mainLen;
+            /* the ends of this window ride along: the positions in front of the first aligned byte (first window only)
+             * and what is left behind the last whole chunk */
+            const size_t back = headDone ? 0 : head;
+            part.endsIn = part.in - back;
+            part.endsOut = part.out - back;
+            part.endsReadable = input_size - first + back;
+            part.endsA0 = 0;
+            part.endsA1 = (uint32_t)back;
+            part.endsB0 = (uint32_t)(back + mainLen);
+            part.endsB1 = (uint32_t)(back + (ownEnd - first));
+            headDone = true;
             e = launchChained<false>(c, part, tex);
-        }
-        if (e == hipSuccess && (mainLen || first + mainLen < ownEnd)) {
-            /* the end of the input (bounds-checked), and the chunks the filter launch listed as pattern-dense */
+            if (e == hipSuccess) {
+                /* the chunks the filter launch listed as pattern-dense (a launch that finds none leaves at once) */
+                ScanArgs rest = part;
+                rest.endsIn = nullptr;
+                rest.denseIn = part.in;
+                rest.denseOut = part.out;
+                rest.denseReadable = input_size - first;
+                rest.owned = 0;
+                rest.n = input_size - first;
+                e = launchNaiveFor(c, hashed, tex, rest);
+            }
+        } else {
+            /* no filter launch (a small call, PFACX_KERNEL_NAIVE, an odd result pointer): the simple kernel does it all */
+            const size_t back = headDone ? 0 : head;
             ScanArgs rest = part;
-            rest.denseIn = part.in;
-            rest.denseOut = part.out;
-            rest.denseReadable = input_size - first;
-            rest.in = part.in + mainLen;
-            rest.out = part.out + mainLen;
-            rest.owned = ownEnd - first - mainLen;
-            rest.n = input_size - first - mainLen;
+            rest.in = part.in - back;
+            rest.out = part.out - back;
+            rest.owned = ownEnd - first + back;
+            rest.n = input_size - first + back;
+            headDone = true;
             e = launchNaiveFor(c, hashed, tex, rest);
         }
+    }
+    if (e == hipSuccess && !headDone) {                 /* the whole input is in front of the first aligned byte */
+        ScanArgs part = a;
+        part.owned = head;
+        part.n = input_size;
+        e = launchNaiveFor(c, hashed, tex, part);
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
 }
@@ -1853,8 +1937,8 @@ struct PairOrder {
  *
  * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
  * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
- * device counter.  The end of the input (and the <= 15 positions in front of the first aligned byte; everything, for
- * a small input) goes through the simple kernel, which appends to the same list.  The list is then put in position
+ * device counter.  The ends of the input (ScanArgs::endsIn) are walked with bounds by the first blocks of the same
+ * launch and join the list through the same counter (a small input: the simple kernel appends).  The list is then put in position
  * order (PairOrder) by launches queued behind the scan; the host reads the count once, at the end (synchronous, like
  * the reference's call).
  * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
@@ -1883,28 +1967,26 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     const size_t mainLen = filterLength(c, head, n, n, true);
     a.reducePos = d_pos;
     a.reduceCount = order.o.count;
-    /* positions [first, first + len) through the simple kernel, which appends its matches to the list */
-    auto simpleRange = [&](size_t first, size_t len) -> PFAC_status_t {
-        if (!len) return PFAC_STATUS_SUCCESS;
-        ScanArgs part = a;
-        part.in = a.in + first;
-        part.owned = len;
-        part.n = n - first;
-        part.reduceBase = (unsigned int)first;
-        return launchNaiveFor(c, hashed, tex, part) == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
-    };
     if (mainLen) {
         ScanArgs part = a;
         part.in = a.in + head;
         part.n = part.owned = mainLen;
         part.reduceBase = (unsigned int)head;
+        /* the ends of the input ride along (ScanArgs::endsIn): their matches join the list through the same counter */
+        part.endsIn = a.in;
+        part.endsReadable = n;
+        part.endsA0 = 0;
+        part.endsA1 = (uint32_t)head;
+        part.endsB0 = (uint32_t)(head + mainLen);
+        part.endsB1 = (uint32_t)n;
         if (launchChained<true>(c, part, tex) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    } else {
+        /* a small input (or PFACX_KERNEL_NAIVE): positions [0, n) through the simple kernel, which appends its matches to the list */
+        ScanArgs part = a;
+        part.owned = n;
+        part.reduceBase = 0;
+        if (launchNaiveFor(c, hashed, tex, part) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     }
-    /* (on a second stream, beside the start of the scan kernel, the simple kernel's 15 us are hidden -- and the two event
-     * waits that takes cost 10 us each: no gain, profiles/r03_experiments.md section 6) */
-    st = simpleRange(0, head);
-    if (st == PFAC_STATUS_SUCCESS) st = simpleRange(head + mainLen, n - head - mainLen);
-    if (st != PFAC_STATUS_SUCCESS) return st;
     if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     unsigned int count = 0;
     if (hipMemcpy(&count, order.o.count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;

@@ -129,9 +129,9 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle);
 PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size,
                                           int *h_matched_result, int numDevices, const int *devices);
 
-/* Counters of the most recent PFAC_matchFromDevice / ...Reduce launch of the filter kernel on this handle
- * (configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
- * stream.  All zero if the last call did not run the filter kernel. */
+/* Counters of the most recent launch of the filter kernel on this handle (PFAC_matchFromDevice / ...Reduce of
+ * 1 MiB or more; SURVEY 8d, configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
+ * stream.  All zero before the first such launch. */
 typedef struct {
     unsigned long long walkerRounds;      /* wave-wide walker rounds (one table step for every live walk)      */
     unsigned long long laneSteps;         /* table steps taken, summed over lanes                              */

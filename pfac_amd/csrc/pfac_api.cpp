@@ -1086,14 +1086,13 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     std::lock_guard<std::mutex> guard(handle->lock);
     if (!handle->hasDevice || !handle->d_workCounters) return PFAC_STATUS_LIB_NOT_EXIST;
-    unsigned long long v[pfac::kStatsCount];
+    unsigned long long v[pfac::kStatsCount + 1];             /* published by the last block of the launch: scan_gfx950.hip, the kernel's end */
     if (hipStreamSynchronize(nullptr) != hipSuccess ||
-        hipMemcpy(v, handle->d_workCounters + pfac::kStatsWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(v, handle->d_workCounters + pfac::kStatsPublishedWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;
     stats->walkerRounds = v[0]; stats->laneSteps = v[1]; stats->walksStarted = v[2]; stats->level1Hits = v[3];
     stats->ladderCandidates = v[5];
-    unsigned int dense = 0;                                  /* scan_gfx950.hip kDenseCountWord: counter line 32 */
-    if (hipMemcpy(&dense, handle->d_workCounters + 32 * 32, sizeof(dense), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    const unsigned long long dense = v[pfac::kStatsCount];
     stats->denseChunks = dense;
     stats->filterKernelMs = -1.0;
     if (handle->kernelTiming && handle->evTimeRecorded && handle->evTime[0] && handle->evTime[1]) {

@@ -35,7 +35,12 @@ struct Int2 { int x, y; };                    /* device layout of the hashed tab
 #define PFAC_WORK_PARTS 2
 #endif
 constexpr int kWorkParts = PFAC_WORK_PARTS;                /* the scan kernel hands out chunks in order within each of these input parts */
-constexpr int kWorkCounterWords = 64 * 32 + 64;   /* 64 counters, one per 128-byte line (0..31 the parts of the input, 32 the dense-chunk list), + the launch statistics */
+constexpr int kWorkCounterWords = 64 * 32 + 64;   /* 64 counters, one per 128-byte line (0..31 the parts of the input; 32..34, 48: see below), + the launch statistics */
+constexpr int kDenseCountWord = 32 * 32;         /* line 32 / 34: dense chunks listed by a filter launch, for the simple kernel behind it; launches alternate */
+constexpr int kDenseCountWordB = 34 * 32;
+constexpr int kDoneWord = 33 * 32;               /* blocks of the running filter launch that have finished: the last one publishes the statistics and leaves
+                                                    every counter zero for the next launch (no memset in front of a launch) */
+constexpr int kStatsPublishedWord = 48 * 32;     /* 64-bit: the kStatsCount statistics of the last finished filter launch, then its dense chunks */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
 /* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
@@ -188,6 +193,7 @@ struct PFAC_context {
     int *d_stagePos[2] = {nullptr, nullptr};  /* positions of the compacted results of a piece (PFAC_matchFromHost) */
     size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
     void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */
+    unsigned int denseParity = 0;                                  /* which of the two dense-chunk counters the next filter launch uses */
     /* PFACX_setKernelTiming: HIP events around the launch of the filter kernel (PFACX_getScanStats reports the time) */
     bool kernelTiming = false;
     void *evTime[2] = {nullptr, nullptr};                          /* hipEvent_t */

@@ -149,6 +149,7 @@ struct ScanArgs {
      * numbers refer to.  The list's length is a.work[kDenseCountWord]; a wave appends 8 chunks at a time (one device
      * counter answers ~90 atomics per microsecond: an append per chunk cost 1.5 ms for 256 MiB of pattern-dense input). */
     unsigned int *denseList;
+    uint32_t denseWord, denseWordOther;                /* a.work[denseWord] counts this launch's dense chunks; the other one is left zero for the next launch */
     const unsigned char *denseIn;
     int *denseOut;
     size_t denseReadable;
@@ -162,8 +163,8 @@ struct ScanArgs {
     size_t endsReadable;
     uint32_t endsA0, endsA1, endsB0, endsB1;
 };
-constexpr int kDenseCountWord = 32 * 32;                /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
-                                                          line 32 counts the dense chunks (zeroed with the rest before every launch) */
+using pfac::kDenseCountWord;                            /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
+                                                          line 32 or 34 (ScanArgs::denseWord) counts the dense chunks */
 constexpr uint32_t kDenseStage = 8;                     /* dense chunks a wave collects in LDS before it appends them to the list */
 constexpr uint32_t kDenseHits = 1843;                  /* of the 2048 positions of a chunk: above 90 % the prefilter only adds work.  (Input in which every
                                                           position matches: 40 GB/s through the filter kernel, 80-118 through the simple one; text in which a
@@ -1007,7 +1008,7 @@ void pfac_scan_filter(ScanArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(a.work + kDenseCountWord, nDense);
+        if (lane == 0) base = atomicAdd(a.work + a.denseWord, nDense);
         base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
         if ((uint32_t)lane < nDense) {
             uint32_t at;                                   /* computed on the spot: not an address the compiler keeps (or spills) across the scan loop */
@@ -1306,7 +1307,25 @@ void pfac_scan_filter(ScanArgs a)
     __syncthreads();
     if (tid < 4) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
     if (tid == 5) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 5, (unsigned long long)sGram3[4]);
-    if (tid == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord)[4] = a.n;
+    /* The last block out leaves the counters as the next launch needs them -- zero -- and publishes the statistics: a
+     * memset in front of every launch was 5 us of a call (profiles/r03_experiments.md section 7).  Every block counts
+     * itself out after its own atomics have been performed; whoever counts last knows that all the others are done. */
+    if (wave == 0) {
+        __threadfence();
+        unsigned int before = 0;
+        if (lane == 0) before = atomicAdd(a.work + pfac::kDoneWord, 1u);
+        before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+        if (before == gridDim.x - 1u) {
+            __threadfence();
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord);
+            unsigned long long *published = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsPublishedWord);
+            if (lane < 32) atomicExch(a.work + lane * 32, 0u);                              /* the parts' claim counters */
+            if (lane < pfac::kStatsCount) published[lane] = lane == 4 ? (unsigned long long)a.n : atomicExch(acc + lane, 0ull);
+            if (lane == pfac::kStatsCount) published[lane] = atomicAdd(a.work + a.denseWord, 0u);   /* stays: the simple kernel behind this launch reads it */
+            if (lane == 32) atomicExch(a.work + a.denseWordOther, 0u);
+            if (lane == 33) atomicExch(a.work + pfac::kDoneWord, 0u);
+        }
+    }
 #if PFAC_STATS
     if (lane == 0 && (blockIdx.x % 32) == 0 && wave == 0)
         printf("STATS block %d wave0 fullRounds %u slotGathers %u winLoads %u startDead %u\n", (int)blockIdx.x, stFullRounds, stSlotGathers, stWinLoads, stStartDead);
@@ -1323,7 +1342,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 {
     __shared__ int sInit[pfac::kCharSet];
-    if (a.owned == 0 && (a.denseList == nullptr || a.work[kDenseCountWord] == 0)) return;      /* behind a filter launch that listed no dense chunk */
+    if (a.owned == 0 && (a.denseList == nullptr || a.work[a.denseWord] == 0)) return;      /* behind a filter launch that listed no dense chunk */
     sInit[threadIdx.x] = a.initialRow[threadIdx.x];
     __syncthreads();
     const Lookup<MODE> lookup(a);
@@ -1351,7 +1370,7 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
     /* the chunks the filter kernel in front of this launch found pattern-dense (ScanArgs::denseList): every position of
      * a listed chunk, one per thread; walks read on into whatever follows the chunk */
     if (a.denseList == nullptr) return;
-    const unsigned int listed = a.work[kDenseCountWord];
+    const unsigned int listed = a.work[a.denseWord];
     for (unsigned int i = blockIdx.x; i < listed; i += gridDim.x) {
         const size_t base = (size_t)a.denseList[i] * kChunkBytesDev;
         for (size_t j = base + threadIdx.x; j < base + kChunkBytesDev; j += 256) {
@@ -1432,8 +1451,11 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     size_t blocks = (numChunks + scanners - 1) / scanners;
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
-    hipError_t e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
+    hipError_t e = hipSuccess;
+#if PFAC_TIMING     /* the stage timers are only ever added to (the counters proper are left zero by the launch before: see the kernel's end) */
+    e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
     if (e != hipSuccess) return e;
+#endif
     const bool timed = c->kernelTiming && c->evTime[0] && c->evTime[1];
     if (timed) (void)hipEventRecord(static_cast<hipEvent_t>(c->evTime[0]), 0);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
@@ -1523,6 +1545,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.work = c->d_workCounters;
+    a.denseWord = (uint32_t)pfac::kDenseCountWord;
+    a.denseWordOther = (uint32_t)pfac::kDenseCountWordB;
     a.initialState = c->fa.initialState;
     /* the buffer-resource ("texture") path addresses the table with 32-bit byte offsets; the
      * reference fails the texture bind for an oversized table the same way (PFAC_kernel.cu:139-142) */
@@ -1607,6 +1631,9 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
                 handle->denseListEntries = chunks;
             }
             part.denseList = handle->d_denseList;
+            part.denseWord = (uint32_t)(handle->denseParity ? pfac::kDenseCountWordB : pfac::kDenseCountWord);
+            part.denseWordOther = (uint32_t)(handle->denseParity ? pfac::kDenseCountWord : pfac::kDenseCountWordB);
+            handle->denseParity ^= 1u;
             part.n = part.owned = mainLen;
             /* the ends of this window ride along: the positions in front of the first aligned byte (first window only)
              * and what is left behind the last whole chunk */

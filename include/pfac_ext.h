@@ -101,7 +101,7 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 #define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
 #define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic)           */
 #define PFACX_KERNEL_AUTO   2   /* default: FILTER, except that calls of less than 1 MiB take NAIVE
-                                   alone (lower latency: the filter kernel has a ~35 us floor).  Either way
+                                   alone (lower latency: the filter kernel has a ~19 us floor).  Either way
                                    the filter kernel hands pattern-dense 2 KiB chunks (most positions pass
                                    its first level) to the simple kernel that follows it.              */
 

@@ -892,12 +892,13 @@ void pfac_scan_filter(ScanArgs a)
 #endif
     } else {
     /* ---- scanning wave */
-    /* the ends of the input first (ScanArgs::endsIn), 64 positions per block: this wave then joins the scan a few
-     * microseconds late, which the others make up for -- chunks are claimed, not assigned */
-    if (wave == kWriters && a.endsIn != nullptr) {
+    /* the ends of the input first (ScanArgs::endsIn), 64 positions per wave, dealt to the first scanning wave of every
+     * block, then the second, ...: such a wave joins the scan a few microseconds late, which the others make up for --
+     * chunks are claimed, not assigned */
+    if (a.endsIn != nullptr) {
         const uint32_t lenA = a.endsA1 - a.endsA0, total = lenA + (a.endsB1 - a.endsB0);
         const WCtx ends(a);
-        for (uint32_t first = blockIdx.x * 64u; first < total; first += gridDim.x * 64u) {
+        for (uint32_t first = ((uint32_t)wave * gridDim.x + blockIdx.x) * 64u; first < total; first += gridDim.x * (uint32_t)kScanners * 64u) {
             const uint32_t i = first + (uint32_t)lane;
             if (i < total) {
                 const uint32_t p = i < lenA ? a.endsA0 + i : a.endsB0 + (i - lenA);
@@ -1557,8 +1558,9 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     return PFAC_STATUS_SUCCESS;
 }
 
-/* below this many positions a call takes the simple kernel alone: ~8 us + 1 us per 60..200 KiB instead of the
- * filter kernel's ~35 us floor (tools/small_input_latency.py) */
+/* below this many positions a call takes the simple kernel alone: ~8 us + 1 us per 60 KiB instead of the filter
+ * kernel's ~19 us floor (filling ~100 KiB of LDS per block; tools/small_input_latency.py: 1 MiB takes 25 us through the
+ * simple kernel, 20 us through the filter kernel) */
 constexpr size_t kSmallInput = size_t(1) << 20;
 
 /* Launch plan for positions [first, ownEnd) of an input of inputSize readable bytes:

@@ -668,7 +668,7 @@ def rank_main(args):
                 eb.record(0)
             torch.cuda.synchronize()
             tr = (time.perf_counter() - t0r) / 5
-            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel + simple kernel + ordering launches + the count's copy, on the launch stream
+            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel (the input's ends ride along in it) + ordering launches + the count's copy, on the launch stream
             # the scan kernel alone: the library brackets its launch with HIP events when asked (two more calls, not in the figures above)
             run.handle.setKernelTiming(True)
             kms = []
@@ -691,7 +691,7 @@ def rank_main(args):
                                  "algorithmic_bytes_per_call": algo,
                                  "roofline": {"bound": "hbm", "achieved": round(algo / (gpu_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(algo / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: scan kernel, simple kernel over the input's end, four ordering launches, "
+                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: the ordering counters' memset, scan kernel, four ordering launches, "
                                                       "the count's copy); kernel_ms = the scan kernel alone (PFACX_setKernelTiming; rocprofv3 kernel stats in profiles/ agree); this path is "
                                                       "bound by the scanning waves' instruction issue, not by HBM"},
                                  "note": "PFAC_matchFromDeviceReduce, synchronous (the match count returns to the host); ~1 B of HBM traffic per input byte"}

@@ -965,8 +965,11 @@ void pfac_scan_filter(ScanArgs a)
         asm volatile("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(off) : "v"(lane), "s"(c * (uint32_t)kChunkBytes));
         asm volatile("v_and_b32 %0, 15, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
         static_assert(kTilesPerIter == 2, "two tile registers are reserved");
-        asm volatile("global_load_dwordx4 v[120:123], %0, %2\n\t"
-                     "global_load_dwordx4 v[124:127], %0, %2 offset:1024\n\t"
+#ifndef PFAC_INPUT_POLICY
+#define PFAC_INPUT_POLICY ""                   /* cache policy of the chunk loads (" nt", " sc1", ...): measurement builds */
+#endif
+        asm volatile("global_load_dwordx4 v[120:123], %0, %2" PFAC_INPUT_POLICY "\n\t"
+                     "global_load_dwordx4 v[124:127], %0, %2 offset:1024" PFAC_INPUT_POLICY "\n\t"
                      "global_load_dword v119, %1, %2"
                      :: "v"(off), "v"(offHalo), "s"(a.in)
                      : "memory", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");

@@ -271,7 +271,10 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
             }
         }
         jumpLog2 = kJumpLog2Min;
-        while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < 8 * prefixes.size()) jumpLog2++;
+#ifndef PFAC_JUMP_SPARSITY
+#define PFAC_JUMP_SPARSITY 8                   /* jump slots per 4-byte pattern prefix (a prefix that finds its slot taken walks from the initial state) */
+#endif
+        while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < (size_t)PFAC_JUMP_SPARSITY * prefixes.size()) jumpLog2++;
         ChainBuilder b(fa, slots);
         std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
         /* the top of the trie first: what the initial state's transitions land in, then what the jump slots land in,

@@ -193,6 +193,7 @@ struct PFAC_context {
     int *d_stagePos[2] = {nullptr, nullptr};  /* positions of the compacted results of a piece (PFAC_matchFromHost) */
     size_t hostStagePositions = 0;            /* capacity of each staging buffer, in positions */
     void *stageUp = nullptr, *stageDown = nullptr;                 /* hipStream_t */
+    mutable bool countersDirty = false;                            /* a filter launch failed: the next one clears the launch counters itself */
     unsigned int denseParity = 0;                                  /* which of the two dense-chunk counters the next filter launch uses */
     /* PFACX_setKernelTiming: HIP events around the launch of the filter kernel (PFACX_getScanStats reports the time) */
     bool kernelTiming = false;

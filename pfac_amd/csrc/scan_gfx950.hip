@@ -1456,14 +1456,18 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     const size_t resident = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * perCU;
     if (blocks > resident) blocks = resident;
     hipError_t e = hipSuccess;
-#if PFAC_TIMING     /* the stage timers are only ever added to (the counters proper are left zero by the launch before: see the kernel's end) */
-    e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
-    if (e != hipSuccess) return e;
-#endif
+    /* the launch counters are left zero by the launch before (see the kernel's end) -- unless that one failed; the stage
+     * timers of the profile build are only ever added to */
+    if (PFAC_TIMING || c->countersDirty) {
+        e = hipMemsetAsync(c->d_workCounters, 0, pfac::kWorkCounterWords * sizeof(unsigned int), 0);
+        if (e != hipSuccess) return e;
+        c->countersDirty = false;
+    }
     const bool timed = c->kernelTiming && c->evTime[0] && c->evTime[1];
     if (timed) (void)hipEventRecord(static_cast<hipEvent_t>(c->evTime[0]), 0);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlockThreads), lds, 0, a);
     e = hipGetLastError();
+    if (e != hipSuccess) c->countersDirty = true;
     if (timed) c->evTimeRecorded = hipEventRecord(static_cast<hipEvent_t>(c->evTime[1]), 0) == hipSuccess;
 #if PFAC_TIMING
     {

@@ -53,8 +53,9 @@
  *      successor bytes; the load of a step is issued in one trip of the loop and
  *      consumed in the next.  A walk starts in a JUMP table keyed by its first four
  *      bytes and restarts in the initial state's bucket if its prefix is not there.  The
- *      input window stays in registers: the entry's 20 bytes end practically every walk
- *      of text without an input load.  "Texture" mode = buffer-resource loads.
+ *      input window stays in registers: the entry's bytes (36 in the full-result kernel,
+ *      20 in the compacted-output one) end practically every walk without an input load.
+ *      "Texture" mode = buffer-resource loads.
  *   6. PATCH.  A non-zero result overwrites its zero, which the writer wave had in
  *      L2 before the chunk was handed out (same CU, same L2: ordered).
  *   The loop has ONE copy of every stage and ONE wait for vector memory: a trip is
@@ -63,17 +64,24 @@
  *   one after it -> list + level-4 test -> ladder batches while the queue has room.
  *
  *   The compacted-output variant (REDUCE) has no zeros to write and no writer waves;
- *   its scanning waves claim chunks from the device counters themselves.  So do the
+ *   its scanning waves claim chunks from the device counters themselves and append
+ *   (id, position) pairs to one list, which four short launches behind the scan put in
+ *   position order (bins of positions, rank inside the bin: PairOrder).  So do the
  *   scanning waves of a -DPFAC_WRITERS=0 build, which then issue the zero stores of
  *   their own chunks: there the patch relies on the single in-order vmcnt counter of
  *   gfx9-family hardware (zero store acknowledged before a later load of the same
  *   wave returns).
  *
- *   The kernel never checks a bound: the launcher gives it whole chunks that start at
+ *   The scan never checks a bound: the launcher gives it whole chunks that start at
  *   a 16-byte aligned input byte and end at least maxPatternLen + 64 bytes before the
- *   end of the input.  The <= 15 positions in front, the end, and the dense list go to
- *   pfac_scan_naive (one thread per byte, reference-layout tables), which
- *   is also the independent second implementation the tests cross-check against.
+ *   end of the input.  The <= 15 positions in front and the few thousand behind ride
+ *   along in the same launch (ScanArgs::endsIn): scanning waves of the first blocks walk
+ *   them with bounds (boundedWalk) before they start scanning.  A call is ONE launch of
+ *   this kernel -- no memset in front (the last block out leaves the launch counters
+ *   zero and publishes the statistics) -- plus a launch of pfac_scan_naive that looks at
+ *   the dense list (empty: it leaves at once).  pfac_scan_naive (one thread per byte,
+ *   reference-layout tables) also serves calls of less than 1 MiB and is the independent
+ *   second implementation the tests cross-check against.
  *   No MFMA: nothing here is a contraction.
  */
 #if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
@@ -84,7 +92,6 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
-
 
 #include <cstdint>
 #include <vector>

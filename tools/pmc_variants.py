@@ -38,7 +38,7 @@ def main():
             cmd = ["rocprofv3", "--pmc"] + a.counters.split(",") + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--worker", "pmc", "--workload", a.workload, "--no-verify"]
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             except subprocess.TimeoutExpired:
                 table[spec] = {"FAILED": 1}
                 continue

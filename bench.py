@@ -660,15 +660,17 @@ def rank_main(args):
             run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
             torch.cuda.synchronize()
             from pfac_amd import hiprt
-            rev = [(hiprt.Event(), hiprt.Event()) for _ in range(5)]
-            t0r = time.perf_counter()
+            rev = [(hiprt.Event(), hiprt.Event()) for _ in range(10)]
+            walls = []
             for ea, eb in rev:
+                t0r = time.perf_counter()
                 ea.record(0)
                 _, rcount = run.handle.matchFromDeviceReduce(run.d_in.data_ptr(), run.n_read, run.d_out.data_ptr(), d_pos.data_ptr())
                 eb.record(0)
+                walls.append(time.perf_counter() - t0r)             # the call is synchronous: the count is back
             torch.cuda.synchronize()
-            tr = (time.perf_counter() - t0r) / 5
-            gpu_ms = float(np.mean([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel (the input's ends ride along in it) + ordering launches + the count's copy, on the launch stream
+            tr = float(np.median(walls))                            # medians of 10 calls: one slow call (a clock dip, a host hiccup) is not the figure
+            gpu_ms = float(np.median([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel (the input's ends ride along in it) + ordering launches + the count's copy, on the launch stream
             # the scan kernel alone: the library brackets its launch with HIP events when asked (two more calls, not in the figures above)
             run.handle.setKernelTiming(True)
             kms = []
@@ -682,7 +684,7 @@ def rank_main(args):
             keep = rp < n
             same = bool(np.array_equal(rp[keep], pos) and np.array_equal(ri[keep], ids))
             algo = int(run.n_read + 8 * rcount)
-            out["reduce_api"] = {"value": round(run.n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4),
+            out["reduce_api"] = {"value": round(run.n_read / tr / 1e9, 2), "unit": "GB/s", "ms_per_call": round(tr * 1e3, 4), "calls": len(rev), "statistic": "median",
                                  "gpu_ms": round(gpu_ms, 4), "host_overhead_ms": round(tr * 1e3 - gpu_ms, 4),
                                  "kernel_ms": None if kernel_ms_reduce is None else round(kernel_ms_reduce, 4),
                                  "behind_the_kernel_ms": None if kernel_ms_reduce is None else round(gpu_ms - kernel_ms_reduce, 4),

@@ -7,7 +7,7 @@ cfg = wl.make_config("c3"); f = tempfile.mktemp(); wl.write_pattern_file(f, cfg.
 h = api.PFAC.create(); h.setPerfMode(cfg.perf_mode); h.readPatternFromFile(f)
 for variant, vname in ((api.PFACX_KERNEL_AUTO, "auto"), (api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")):
   h.setKernelVariant(variant)
-  for n in (4096, 65536, 1 << 20, 4 << 20, 16 << 20):
+  for n in (4096, 65536, 256 << 10, 512 << 10, 768 << 10, 1 << 20, 4 << 20, 16 << 20):
       d_in = torch.from_numpy(cfg.input_slice(n, 0).copy()).to("cuda:0"); d_out = torch.empty(n, dtype=torch.int32, device="cuda:0")
       for _ in range(5): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
       torch.cuda.synchronize()

@@ -164,6 +164,14 @@ def test_misaligned_pointers_stay_on_the_vector_kernel(workdir, capsys):
                 ref = got
             else:
                 assert np.array_equal(got, ref), (in_off, out_off)
+            # the compacted-output call on the same (misaligned) input: the positions in front of the first aligned byte
+            # and the end of the input are walked inside the launch and join the list of pairs
+            d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+            d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+            _, count = h.matchFromDeviceReduce(pi, n, d_res.data_ptr(), d_pos.data_ptr())
+            nz = np.nonzero(ref)[0]
+            assert count == nz.size and np.array_equal(d_pos[:count].cpu().numpy(), nz) and np.array_equal(d_res[:count].cpu().numpy(), ref[nz]), (in_off, "reduce")
+            del d_res, d_pos
     finally:
         h.destroy()
     with capsys.disabled():

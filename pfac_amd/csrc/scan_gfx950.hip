@@ -1663,6 +1663,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             part.endsB1 = (uint32_t)(back + (ownEnd - first));
             headDone = true;
             e = launchChained<false>(c, part, tex);
+#if !defined(PFAC_EXP_NO_DENSE_LAUNCH)    /* timing experiment: what the second launch of a call costs (results are wrong if a chunk is dense) */
             if (e == hipSuccess) {
                 /* the chunks the filter launch listed as pattern-dense (a launch that finds none leaves at once) */
                 ScanArgs rest = part;
@@ -1674,6 +1675,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
                 rest.n = input_size - first;
                 e = launchNaiveFor(c, hashed, tex, rest);
             }
+#endif
         } else {
             /* no filter launch (a small call, PFACX_KERNEL_NAIVE, an odd result pointer): the simple kernel does it all */
             const size_t back = headDone ? 0 : head;

@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--size-mib", type=int, default=1024, help="input bytes per GPU, MiB")
-    ap.add_argument("--variant", default="auto", choices=["auto", "filter", "naive"],
+    ap.add_argument("--variant", default="auto", choices=["auto", "filter", "naive", "reftable"],
                     help="auto = the library default (PFACX_KERNEL_AUTO: what a drop-in PFAC.h caller gets; the filter kernel at bench sizes)")
     ap.add_argument("--texture", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--perf-mode", default=None, choices=[None, "dense", "hash"])
@@ -350,7 +350,8 @@ class Run:
             self.handle.setPlatform(api.PFAC_PLATFORM_CPU_OMP)
         self.handle.setPerfMode(self.perf_mode)
         self.handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[texture])
-        self.variant = {"auto": api.PFACX_KERNEL_AUTO, "filter": api.PFACX_KERNEL_FILTER, "naive": api.PFACX_KERNEL_NAIVE}[args.variant]
+        self.variant = {"auto": api.PFACX_KERNEL_AUTO, "filter": api.PFACX_KERNEL_FILTER, "naive": api.PFACX_KERNEL_NAIVE,
+                        "reftable": api.PFACX_KERNEL_REFTABLE}[args.variant]
         if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
             self.handle.setKernelVariant(self.variant)
         self.handle.readPatternFromFile(self.pattern_file)
@@ -447,15 +448,17 @@ class Run:
 
 def kernel_name(args, run):
     """The kernel a launch of this run goes to (the library default takes the filter kernel from 1 MiB up)."""
-    if args.variant == "naive" or (args.variant == "auto" and run.n_read < (1 << 20)):
+    if args.variant == "reftable":
         return "pfac_scan_naive"
+    if args.variant == "naive" or (args.variant == "auto" and run.n_read < (1 << 20)):
+        return "pfac_scan_tiled"
     return "pfac_scan_filter"
 
 
 def walker_table(args, run):
-    """What the kernel walks: the filter kernel walks the device-only chained table in BOTH perf modes; only the simple
-    kernel walks the reference-layout table that `table` names."""
-    return "chained (device-only, both perf modes)" if kernel_name(args, run) == "pfac_scan_filter" else ("hashed" if run.perf_mode else "dense")
+    """What the kernel walks: the filter kernel and the tiled kernel walk the device-only chained table in BOTH perf modes;
+    only the reference-shaped kernel (--variant reftable) walks the reference-layout table that `table` names."""
+    return "chained (device-only, both perf modes)" if kernel_name(args, run) != "pfac_scan_naive" else ("hashed" if run.perf_mode else "dense")
 
 
 _BUILD = None
@@ -853,7 +856,7 @@ def orchestrate(args, argv):
                 rc = rc or 1
         except Exception:
             log(f"[bench] CPU baseline worker failed (rc {p.returncode})")
-    if single and args.pmc == "auto" and args.variant != "naive":
+    if single and args.pmc == "auto" and args.variant not in ("naive", "reftable"):
         common = ["--workload", args.workload, "--size-mib", str(args.size_mib), "--texture", args.texture, "--no-verify"]
         if args.perf_mode:
             common += ["--perf-mode", args.perf_mode]
@@ -866,7 +869,7 @@ def orchestrate(args, argv):
             out["roofline"]["traffic_detail"] = traffic
         else:
             out["roofline"]["traffic_note"] = src
-    if single and args.pmc == "auto" and args.variant != "naive" and out["roofline"]["traffic"] is None \
+    if single and args.pmc == "auto" and args.variant not in ("naive", "reftable") and out["roofline"]["traffic"] is None \
             and args.size_mib == 1024 and args.perf_mode is None:      # the PMC passes of this run failed: last committed profile
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = committed_traffic(args.workload, out["roofline"]["kernel"])
     print(json.dumps(out), flush=True)

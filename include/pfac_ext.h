@@ -44,6 +44,8 @@ PFAC_status_t PFACX_readPatternFromFileEx(PFAC_handle_t handle, const char *file
 PFAC_status_t PFACX_readPatternFromMemoryEx(PFAC_handle_t handle, const char *patterns, size_t size, unsigned int flags);
 
 typedef struct {
+    size_t structSize;        /* IN: sizeof(PFACX_info_t) of the caller's header; the library never writes past it (a
+                                 caller built against an older, shorter struct stays safe).  OUT: bytes filled in */
     int numOfPatterns;        /* F                                             */
     int numOfStates;          /* includes the unused state 0 (ref PFAC.cpp:704) */
     int numOfFinalStates;     /* == numOfPatterns                               */
@@ -73,6 +75,8 @@ typedef struct {
     int ladderThin;           /* nodes with at most this many patterns below them are stops ...             */
     int ladderExtend;         /* ... this many levels further down                                          */
     size_t trailingBytesIgnored; /* bytes behind the last '\n' of the pattern file that were ignored (0: none)  */
+    size_t deviceTableBytes;  /* device memory the pattern set holds: chained table, initial row, prefilter bitmaps,
+                                 launch counters; the reference-layout table only while PFACX_KERNEL_REFTABLE is selected */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -99,11 +103,16 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 
 /* Kernel variants of the GPU match path. */
 #define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
-#define PFACX_KERNEL_NAIVE  1   /* one thread per byte, no prefilter (alignment-agnostic)           */
-#define PFACX_KERNEL_AUTO   2   /* default: FILTER, except that calls of less than 1 MiB take NAIVE
-                                   alone (lower latency: the filter kernel has a ~19 us floor).  Either way
-                                   the filter kernel hands pattern-dense 2 KiB chunks (most positions pass
-                                   its first level) to the simple kernel that follows it.              */
+#define PFACX_KERNEL_NAIVE  1   /* the tiled kernel alone: one position per thread slot, tile + halo and the
+                                   hottest transition rows in LDS, coalesced result lines (any alignment)   */
+#define PFACX_KERNEL_AUTO   2   /* default: FILTER, except that small calls take the tiled kernel alone
+                                   (lower latency: the filter kernel has a ~19 us floor).  Either way the
+                                   filter kernel hands pattern-dense 2 KiB chunks (most positions pass its
+                                   first level) to the tiled kernel that follows it.                      */
+#define PFACX_KERNEL_REFTABLE 3 /* the reference-shaped kernel: one thread per byte through the REFERENCE-layout
+                                   table of the perf mode (dense int[S][256] / hashed int2 pair), which is built
+                                   and uploaded when this variant is selected (S KiB for the dense table).  An
+                                   independent second implementation for cross-checks; 6-20x slower.        */
 
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant);
 
@@ -133,16 +142,19 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
  * 1 MiB or more; SURVEY 8d, configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
  * stream.  All zero before the first such launch. */
 typedef struct {
+    size_t structSize;                    /* IN: sizeof(PFACX_scan_stats_t) of the caller's header; OUT: bytes filled in (see PFACX_info_t) */
     unsigned long long walkerRounds;      /* wave-wide walker rounds (one table step for every live walk)      */
     unsigned long long laneSteps;         /* table steps taken, summed over lanes                              */
     unsigned long long walksStarted;      /* positions that passed level 1 and the prefix ladder and were walked */
     unsigned long long level1Hits;        /* positions that passed filter level 1                              */
     int tilesPerChunk;                    /* KiB per chunk                                                     */
-    int walksPerLane;                     /* independent walks per lane                                        */
+    int walksPerLane;                     /* independent walks per lane in THAT launch (the full-result and the compacted-
+                                             output kernel differ)                                              */
     unsigned long long ladderCandidates;  /* level-1 hits whose first four bytes are a pattern prefix (or a short
                                              pattern): what the prefix ladder was asked about                  */
     unsigned long long denseChunks;       /* 2 KiB chunks in which more than 90 % of the positions passed level 1:
-                                             left to the simple kernel that follows the filter kernel          */
+                                             left to the tiled kernel that follows the filter kernel (0 for a
+                                             compacted-output launch, which lists none)                         */
     double filterKernelMs;                /* GPU time of that launch of the filter kernel alone (HIP events around it);
                                              -1 unless PFACX_setKernelTiming(handle, 1) was in force           */
 } PFACX_scan_stats_t;

@@ -24,7 +24,7 @@ PFAC_PLATFORM_GPU, PFAC_PLATFORM_CPU, PFAC_PLATFORM_CPU_OMP = 0, 1, 2
 PFAC_AUTOMATIC, PFAC_TEXTURE_ON, PFAC_TEXTURE_OFF = 0, 1, 2
 PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
-PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO = 0, 1, 2
+PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO, PFACX_KERNEL_REFTABLE = 0, 1, 2, 3
 PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
@@ -54,6 +54,7 @@ class PFACError(RuntimeError):
 
 class PFACX_info(C.Structure):
     _fields_ = [
+        ("structSize", C.c_size_t),
         ("numOfPatterns", C.c_int), ("numOfStates", C.c_int), ("numOfFinalStates", C.c_int),
         ("initialState", C.c_int), ("maxPatternLen", C.c_int), ("numOfLeaves", C.c_int),
         ("perfMode", C.c_int), ("textureMode", C.c_int), ("platform", C.c_int), ("hasDevice", C.c_int),
@@ -63,12 +64,12 @@ class PFACX_info(C.Structure):
         ("filterLog2BitsLadder", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSetLadder", C.c_size_t),
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
-        ("trailingBytesIgnored", C.c_size_t),
+        ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t),
     ]
 
 
 class PFACX_scan_stats(C.Structure):
-    _fields_ = [("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
+    _fields_ = [("structSize", C.c_size_t), ("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
                 ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
                 ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong), ("filterKernelMs", C.c_double)]
 
@@ -305,6 +306,7 @@ class PFAC:
     # -- extensions ----------------------------------------------------------------
     def info(self) -> PFACX_info:
         info = PFACX_info()
+        info.structSize = C.sizeof(PFACX_info)
         self._ret(self._lib.PFACX_getInfo(self._h, C.byref(info)), "PFACX_getInfo", True)
         return info
 
@@ -312,6 +314,7 @@ class PFAC:
         """``PFACX_getScanStats`` of the last filter-kernel launch, plus the derived SURVEY 8(d) C5 figures
         (`positions` = input bytes of that launch)."""
         st = PFACX_scan_stats()
+        st.structSize = C.sizeof(PFACX_scan_stats)
         self._ret(self._lib.PFACX_getScanStats(self._h, C.byref(st)), "PFACX_getScanStats", True)
         d = {name: int(getattr(st, name)) for name, _ in PFACX_scan_stats._fields_ if name != "filterKernelMs"}
         if st.filterKernelMs >= 0:

@@ -128,24 +128,40 @@ PFAC_status_t uploadChainedHashTable(PFAC_context *c)
     return st;
 }
 
+/* The reference-layout table of the perf mode on the HOST: the dense table is materialised on first use -- PFACX_getTable,
+ * the CPU platforms, PFACX_KERNEL_REFTABLE -- because neither GPU kernel of the product path reads it (both walk the
+ * chained table) and it is S KiB: 498 MB for a Snort-scale set.  The hashed tables (a few MB) are built with the set. */
+PFAC_status_t ensureHostRefTable(PFAC_context *c)
+{
+    if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) return pfac::buildDenseTable(c->fa, c->h_dense);
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* ... and on the DEVICE: only the reference-shaped kernel (PFACX_KERNEL_REFTABLE) reads it there */
+PFAC_status_t ensureDeviceRefTable(PFAC_context *c)
+{
+    if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
+    PFAC_status_t st = ensureHostRefTable(c);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    if (c->perfMode == PFAC_TIME_DRIVEN) {
+        if (!c->d_dense) st = upload(c->d_dense, c->h_dense.data(), c->h_dense.size());
+    } else if (!c->d_hashRow || !c->d_hashVal) {
+        devFree(c->d_hashRow);
+        devFree(c->d_hashVal);
+        st = upload(c->d_hashRow, c->h_hashRow.data(), c->h_hashRow.size());
+        if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_hashVal, c->h_hashVal.data(), c->h_hashVal.size());
+    }
+    return st;
+}
+
 /* ref PFAC_bindTable -> PFAC_create2DTable / PFAC_createHashTable, PFAC.cpp:321-648 */
 PFAC_status_t bindTable(PFAC_context *c)
 {
     if (!c->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     PFAC_status_t st;
     if (c->perfMode == PFAC_TIME_DRIVEN) {
-        if (c->h_dense.empty()) {
-            st = pfac::buildDenseTable(c->fa, c->h_dense);
-            if (st != PFAC_STATUS_SUCCESS) return st;
-        }
         c->numOfTableEntry = (size_t)pfac::kCharSet * (size_t)c->fa.numStates;
         c->sizeOfTableEntry = sizeof(int);
-        c->sizeOfTableInBytes = c->numOfTableEntry * c->sizeOfTableEntry;
-        if (c->hasDevice && !c->d_dense) {
-            st = upload(c->d_dense, c->h_dense.data(), c->h_dense.size());
-            if (st == PFAC_STATUS_SUCCESS) st = uploadChainedHashTable(c);
-            if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
-        }
     } else {
         if (c->h_hashRow.empty()) {
             st = pfac::buildHashTable(c->fa, c->h_hashRow, c->h_hashVal);
@@ -153,13 +169,12 @@ PFAC_status_t bindTable(PFAC_context *c)
         }
         c->numOfTableEntry = c->h_hashVal.size();
         c->sizeOfTableEntry = sizeof(Int2);
-        c->sizeOfTableInBytes = c->numOfTableEntry * c->sizeOfTableEntry;
-        if (c->hasDevice && !c->d_hashRow) {
-            st = upload(c->d_hashRow, c->h_hashRow.data(), c->h_hashRow.size());
-            if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_hashVal, c->h_hashVal.data(), c->h_hashVal.size());
-            if (st == PFAC_STATUS_SUCCESS) st = uploadChainedHashTable(c);
-            if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
-        }
+    }
+    c->sizeOfTableInBytes = c->numOfTableEntry * c->sizeOfTableEntry;
+    if (c->hasDevice && !c->d_chainSlots) {
+        st = uploadChainedHashTable(c);
+        if (st == PFAC_STATUS_SUCCESS && c->kernelVariant == PFACX_KERNEL_REFTABLE) st = ensureDeviceRefTable(c);
+        if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
     }
     return PFAC_STATUS_SUCCESS;
 }
@@ -224,6 +239,11 @@ PFAC_status_t loadModule(PFAC_context *c)
 /* ref the CPU branch of matchFromHost / matchFromHostReduce, PFAC.cpp:899-913 */
 PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, int *out)
 {
+    {   /* the dense table is built on first use (ensureHostRefTable) */
+        std::lock_guard<std::mutex> guard(c->lock);
+        const PFAC_status_t st = ensureHostRefTable(c);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+    }
     bool omp = false;
     if (c->platform == PFAC_PLATFORM_CPU_OMP) omp = (std::getenv("OMP_NUM_THREADS") != nullptr);
     return pfac::matchOnCpu(c, reinterpret_cast<const unsigned char *>(in), n, out, omp);
@@ -333,6 +353,7 @@ const char *PFAC_getErrorString(PFAC_status_t status)
 PFAC_status_t PFAC_dumpTransitionTable(PFAC_handle_t handle, FILE *fp)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    std::lock_guard<std::mutex> guard(handle->lock);
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     if (!fp) fp = stdout;
     const pfac::Automaton &fa = handle->fa;
@@ -675,7 +696,17 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
             child = {devs[i], h};
         }
         PFAC_context *w = child.second;
+        /* a child created by an earlier call: the parent's modes may have changed since */
+        if (w->perfMode != c->perfMode) {
+            const PFAC_status_t st = PFAC_setPerfMode(w, (PFAC_perfMode_t)c->perfMode);
+            if (st != PFAC_STATUS_SUCCESS) { status[i] = st; return; }
+        }
+        if (w->kernelVariant != c->kernelVariant) {
+            const PFAC_status_t st = PFACX_setKernelVariant(w, c->kernelVariant);
+            if (st != PFAC_STATUS_SUCCESS) { status[i] = st; return; }
+        }
         std::lock_guard<std::mutex> g(w->lock);
+        w->textureMode = c->textureMode;
         status[i] = matchHostOnGpu(w, h_inputString + bound[i], bound[i + 1] - bound[i], size - bound[i], h_matched_result + bound[i]);
     };
     int callerDevice = 0;
@@ -762,36 +793,57 @@ PFAC_status_t PFAC_matchFromHostReduce(PFAC_handle_t handle, char *h_inputString
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!info) return PFAC_STATUS_INVALID_PARAMETER;
-    std::memset(info, 0, sizeof(*info));
-    info->numOfPatterns = handle->fa.numPatterns;
-    info->numOfStates = handle->fa.numStates;
-    info->numOfFinalStates = handle->fa.numPatterns;
-    info->initialState = handle->fa.initialState;
-    info->maxPatternLen = handle->fa.maxPatternLen;
-    info->numOfLeaves = handle->fa.numLeaves;
-    info->perfMode = handle->perfMode;
-    info->textureMode = handle->textureMode;
-    info->platform = handle->platform;
-    info->hasDevice = handle->hasDevice ? 1 : 0;
-    info->numOfTableEntry = handle->numOfTableEntry;
-    info->sizeOfTableEntry = handle->sizeOfTableEntry;
-    info->sizeOfTableInBytes = handle->sizeOfTableInBytes;
-    info->filterLog2Bits = handle->filter.log2Bits;
-    info->filterHasShort = handle->filter.hasShort ? 1 : 0;
-    info->filterBitsSet = handle->filter.bitsSet;
-    info->kernelVariant = handle->kernelVariant;
-    info->filterLog2BitsLadder = handle->filter.log2BitsLad;
-    info->filterLog2BitsFinal3 = handle->filter.log2BitsF3;
-    info->filterBitsSetLadder = handle->filter.bitsSetLad;
-    info->ladderStops = handle->filter.ladderStops;
-    info->ladderGoOns = handle->filter.ladderGoOns;
-    info->ladderThin = handle->filter.ladderThin;
-    info->ladderExtend = handle->filter.ladderExtend;
-    info->trailingBytesIgnored = handle->fa.trailingBytes;
-    info->chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
-    info->chainSlots = handle->h_chainSlots.size();
-    info->multiProcessorCount = handle->multiProcessorCount;
+    if (!info || info->structSize < sizeof(size_t) || info->structSize > (size_t(1) << 16)) return PFAC_STATUS_INVALID_PARAMETER;
+    const size_t callerSize = info->structSize;              /* a caller built against an older header passes a shorter struct: never written past */
+    PFACX_info_t v;
+    std::memset(&v, 0, sizeof(v));
+    {
+        std::lock_guard<std::mutex> guard(handle->lock);      /* setters swap the vectors read here */
+        v.numOfPatterns = handle->fa.numPatterns;
+        v.numOfStates = handle->fa.numStates;
+        v.numOfFinalStates = handle->fa.numPatterns;
+        v.initialState = handle->fa.initialState;
+        v.maxPatternLen = handle->fa.maxPatternLen;
+        v.numOfLeaves = handle->fa.numLeaves;
+        v.perfMode = handle->perfMode;
+        v.textureMode = handle->textureMode;
+        v.platform = handle->platform;
+        v.hasDevice = handle->hasDevice ? 1 : 0;
+        v.numOfTableEntry = handle->numOfTableEntry;
+        v.sizeOfTableEntry = handle->sizeOfTableEntry;
+        v.sizeOfTableInBytes = handle->sizeOfTableInBytes;
+        v.filterLog2Bits = handle->filter.log2Bits;
+        v.filterHasShort = handle->filter.hasShort ? 1 : 0;
+        v.filterBitsSet = handle->filter.bitsSet;
+        v.kernelVariant = handle->kernelVariant;
+        v.filterLog2BitsLadder = handle->filter.log2BitsLad;
+        v.filterLog2BitsFinal3 = handle->filter.log2BitsF3;
+        v.filterBitsSetLadder = handle->filter.bitsSetLad;
+        v.ladderStops = handle->filter.ladderStops;
+        v.ladderGoOns = handle->filter.ladderGoOns;
+        v.ladderThin = handle->filter.ladderThin;
+        v.ladderExtend = handle->filter.ladderExtend;
+        v.trailingBytesIgnored = handle->fa.trailingBytes;
+        v.chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
+        v.chainSlots = handle->h_chainSlots.size();
+        v.multiProcessorCount = handle->multiProcessorCount;
+        /* what the pattern set holds on the device: the chained table, the initial row, the prefilter bitmaps, the launch
+         * counters -- and the reference-layout table only while PFACX_KERNEL_REFTABLE has asked for it */
+        size_t dev = 0;
+        if (handle->d_chainSlots) dev += handle->numChainSlots * sizeof(pfac::ChainSlot);
+        if (handle->d_dense) dev += handle->h_dense.size() * sizeof(int);
+        if (handle->d_hashRow) dev += handle->h_hashRow.size() * sizeof(Int2);
+        if (handle->d_hashVal) dev += handle->h_hashVal.size() * sizeof(Int2);
+        if (handle->d_initialRow) dev += handle->h_initialRow.size() * sizeof(int);
+        if (handle->d_gram3) dev += handle->filter.gram3.size() * sizeof(uint32_t);
+        if (handle->d_ladder) dev += handle->filter.ladder.size() * sizeof(uint32_t);
+        if (handle->d_final3) dev += handle->filter.final3.size() * sizeof(uint32_t);
+        if (handle->d_shortBits) dev += handle->filter.shortBits.size() * sizeof(uint32_t);
+        if (handle->d_workCounters) dev += pfac::kWorkCounterWords * sizeof(unsigned int);
+        v.deviceTableBytes = dev;
+    }
+    v.structSize = callerSize < sizeof(v) ? callerSize : sizeof(v);
+    std::memcpy(info, &v, v.structSize);
     return PFAC_STATUS_SUCCESS;
 }
 
@@ -799,11 +851,15 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (!ptr || !bytes) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);          /* setters free and rebuild what is handed out here */
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     *ptr = nullptr; *bytes = 0;
     switch (which) {
-    case PFACX_TABLE_DENSE:
+    case PFACX_TABLE_DENSE: {
+        const PFAC_status_t st = ensureHostRefTable(handle);      /* TIME_DRIVEN: materialised on first use */
+        if (st != PFAC_STATUS_SUCCESS) return st;
         *ptr = handle->h_dense.data(); *bytes = handle->h_dense.size() * sizeof(int); break;
+    }
     case PFACX_TABLE_HASH_ROWPTR:
         *ptr = handle->h_hashRow.data(); *bytes = handle->h_hashRow.size() * sizeof(Int2); break;
     case PFACX_TABLE_HASH_VALPTR:
@@ -820,7 +876,6 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
         if (handle->h_chainSlots.empty()) {
-            std::lock_guard<std::mutex> g(handle->lock);
             const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */
             if (st != PFAC_STATUS_SUCCESS) return st;
         }
@@ -839,12 +894,16 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
 namespace {
 
 constexpr char kCompiledMagic[8] = {'P', 'F', 'A', 'C', 'X', 'C', '1', 0};
-constexpr uint32_t kCompiledVersion = 6;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots;
-                                                     5: the prefix ladder replaces the 4-gram bitmap, the chained table has its own compact breadth-first layout */
+constexpr uint32_t kCompiledVersion = 7;          /* 2: patterns of 1-2 bytes are folded into the 3-gram bitmap; 3: root bucket + jump table behind the chained slots;
+                                                     5: the prefix ladder replaces the 4-gram bitmap, the chained table has its own compact breadth-first layout;
+                                                     6: 36-byte walk-queue entries (layout fingerprint); 7: no transition table is stored any more -- hashed and
+                                                     chained tables are rebuilt from the checked trie at load (a file cannot steer a device read) --, the scalars
+                                                     carry the pattern file's ignored trailing bytes */
 /* what the stored tables depend on besides the patterns: hash constants and slot layout */
 constexpr uint32_t kLayoutFingerprint = pfac::kGram3Mul ^ (pfac::kLadMul0 * 3u) ^ (pfac::kLadMul * 5u) ^ (pfac::kLadMulS * 11u) ^ (pfac::kLadMulG * 13u) ^ (pfac::kLadMulG2 * 17u) ^ (pfac::kFinal3Mul * 7u) ^ (pfac::kFinal3Mul2 * 19u) ^
                                         ((uint32_t)pfac::kLadderLevels << 12) ^
-                                        ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */;
+                                        ((uint32_t)sizeof(pfac::ChainSlot) << 24) ^ ((uint32_t)pfac::kChainMax << 20) ^ 0x20u /* entry bytes */ ^
+                                        0x4000u /* chained table: multiply-shift bucket hash */;
 struct CompiledHeader {
     char magic[8];
     uint32_t version, fingerprint, perfMode, jumpLog2;   /* jumpLog2: log2 of the jump-table slots at the end of the chained table */
@@ -892,19 +951,12 @@ PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
     std::lock_guard<std::mutex> guard(handle->lock);
     PFAC_context *c = handle;
     try {
-        if (c->h_chainSlots.empty()) {                         /* host-only handle: the chained table was never needed */
-            const bool dev = c->hasDevice;
-            c->hasDevice = false;
-            const PFAC_status_t st = uploadChainedHashTable(c);
-            c->hasDevice = dev;
-            if (st != PFAC_STATUS_SUCCESS) return st;
-        }
         const pfac::Automaton &fa = c->fa;
         const pfac::Filter &f = c->filter;
         std::vector<unsigned char> payload;
         putSection(payload, kSecFile, fa.file.data(), fa.file.size());
-        const int32_t scalars[5] = {fa.numPatterns, fa.maxPatternLen, fa.initialState, fa.numStates, fa.numLeaves};
-        putSection(payload, kSecScalars, scalars, 5);
+        const int64_t scalars[6] = {fa.numPatterns, fa.maxPatternLen, fa.initialState, fa.numStates, fa.numLeaves, (int64_t)fa.trailingBytes};
+        putSection(payload, kSecScalars, scalars, 6);
         putSection(payload, kSecPatOff, fa.patternOff.data(), fa.patternOff.size());
         putSection(payload, kSecPatLen, fa.patternLen.data(), fa.patternLen.size());
         putSection(payload, kSecSorted, fa.sortedId.data(), fa.sortedId.size());
@@ -918,17 +970,12 @@ PFAC_status_t PFACX_saveCompiled(PFAC_handle_t handle, const char *filename)
         putSection(payload, kSecLadder, f.ladder.data(), f.ladder.size());
         putSection(payload, kSecFinal3, f.final3.data(), f.final3.size());
         putSection(payload, kSecShort, f.shortBits.data(), f.shortBits.size());
-        if (c->perfMode == PFAC_SPACE_DRIVEN) {
-            putSection(payload, kSecHashRow, c->h_hashRow.data(), c->h_hashRow.size());
-            putSection(payload, kSecHashVal, c->h_hashVal.data(), c->h_hashVal.size());
-        }
-        putSection(payload, kSecChain, c->h_chainSlots.data(), c->h_chainSlots.size());
-        putSection(payload, kSecInitialRow, c->h_initialRow.data(), c->h_initialRow.size());
+        /* no transition table: dense, hashed and chained tables and the initial row are rebuilt from the edges at load */
         CompiledHeader h;
         std::memset(&h, 0, sizeof(h));
         std::memcpy(h.magic, kCompiledMagic, 8);
         h.version = kCompiledVersion; h.fingerprint = kLayoutFingerprint; h.perfMode = (uint32_t)c->perfMode;
-        h.jumpLog2 = (uint32_t)c->chainJumpLog2;
+        h.jumpLog2 = 0;                                        /* (was: log2 of the stored chained table's jump slots) */
         h.payloadBytes = payload.size(); h.payloadFnv1a = fnv1a64(payload.data(), payload.size());
         FILE *fp = std::fopen(filename, "wb");
         if (!fp) return PFAC_STATUS_FILE_OPEN_ERROR;
@@ -957,13 +1004,14 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     std::fclose(fp);
     if (!ok || fnv1a64(payload.data(), payload.size()) != h.payloadFnv1a) return PFAC_STATUS_INVALID_PARAMETER;   /* not a compiled set of this build, or damaged */
 
-    /* everything is parsed and checked in temporaries: a refused file leaves the handle as it was */
+    /* everything is parsed and checked in temporaries: a refused file leaves the handle as it was.  The checksum is no
+     * protection against a crafted file (FNV-1a is recomputed in a line), so nothing that a kernel indexes memory with is
+     * taken from the file: the trie is checked to BE a trie of the stored patterns' depth, and every transition table --
+     * hashed, chained, the initial row -- is rebuilt from it.  The prefilter bitmaps are taken as they are: they are read
+     * with masked LDS addresses, a wrong bit can cost a result, not a memory access. */
     pfac::Automaton fa;
     pfac::Filter f;
-    std::vector<Int2> hashRow, hashVal;
-    std::vector<pfac::ChainSlot> chain;
-    std::vector<int> initialRow;
-    std::vector<int32_t> scalars;
+    std::vector<int64_t> scalars;
     std::vector<uint64_t> filt;
     try {
         size_t at = 0;
@@ -987,57 +1035,62 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
             case kSecLadder: ok = takeSection(p, bytes, f.ladder); break;
             case kSecFinal3: ok = takeSection(p, bytes, f.final3); break;
             case kSecShort: ok = takeSection(p, bytes, f.shortBits); break;
-            case kSecHashRow: ok = takeSection(p, bytes, hashRow); break;
-            case kSecHashVal: ok = takeSection(p, bytes, hashVal); break;
-            case kSecChain: ok = takeSection(p, bytes, chain); break;
-            case kSecInitialRow: ok = takeSection(p, bytes, initialRow); break;
             default: break;                                    /* unknown section of a later writer: skipped */
             }
             at += (size_t)bytes;
         }
-        ok = ok && scalars.size() == 5 && filt.size() == 10;
+        ok = ok && scalars.size() == 6 && filt.size() == 10;
+        for (size_t i = 0; ok && i < scalars.size(); i++) ok = scalars[i] >= 0 && scalars[i] < (int64_t(1) << 31);
         if (ok) {
-            fa.numPatterns = scalars[0]; fa.maxPatternLen = scalars[1]; fa.initialState = scalars[2];
-            fa.numStates = scalars[3]; fa.numLeaves = scalars[4];
+            fa.numPatterns = (int)scalars[0]; fa.maxPatternLen = (int)scalars[1]; fa.initialState = (int)scalars[2];
+            fa.numStates = (int)scalars[3]; fa.numLeaves = (int)scalars[4]; fa.trailingBytes = (size_t)scalars[5];
             f.log2Bits = (int)filt[0]; f.log2BitsLad = (int)filt[1]; f.log2BitsF3 = (int)filt[2]; f.hasShort = filt[3] != 0;
             f.bitsSet = (size_t)filt[4]; f.bitsSetLad = (size_t)filt[5];
             f.ladderStops = (size_t)filt[6]; f.ladderGoOns = (size_t)filt[7]; f.ladderThin = (int)filt[8]; f.ladderExtend = (int)filt[9];
-            const size_t S = (size_t)(fa.numStates > 0 ? fa.numStates : 0), F = (size_t)(fa.numPatterns >= 0 ? fa.numPatterns : 0);
-            ok = fa.numStates > 0 && fa.numPatterns >= 0 && fa.initialState == fa.numPatterns + 1 && (size_t)fa.initialState < S &&
+            const size_t S = (size_t)fa.numStates, F = (size_t)fa.numPatterns;
+            ok = fa.numStates > 0 && fa.initialState == fa.numPatterns + 1 && (size_t)fa.initialState < S &&
                  fa.patternOff.size() == F + 1 && fa.patternLen.size() == F + 1 && fa.sortedId.size() == F &&
                  fa.edgeBegin.size() == S + 1 && fa.edgeCh.size() == fa.edgeNext.size() && !fa.edgeBegin.empty() &&
-                 (size_t)fa.edgeBegin.back() == fa.edgeCh.size() &&
+                 fa.edgeBegin[0] == 0 && (size_t)fa.edgeBegin.back() == fa.edgeCh.size() && fa.trailingBytes <= fa.file.size() &&
                  f.log2Bits >= 13 && f.log2Bits <= 18 && f.log2BitsLad >= 13 && f.log2BitsLad <= 19 && f.log2BitsF3 >= 10 && f.log2BitsF3 <= 13 &&
                  pfac::kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 8192u : 0u) <= pfac::kFilterLdsBudget &&
                  f.gram3.size() == (size_t(1) << f.log2Bits) / 32 && f.ladder.size() == (size_t(1) << f.log2BitsLad) / 32 &&
-                 f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32 &&
-                 initialRow.size() == (size_t)pfac::kCharSet &&
-                 h.jumpLog2 >= (uint32_t)pfac::kJumpLog2Min && h.jumpLog2 <= (uint32_t)pfac::kJumpLog2Max &&
-                 chain.size() >= (size_t)pfac::kCharSet + (size_t(1) << h.jumpLog2) &&
-                 (h.perfMode == PFAC_TIME_DRIVEN || hashRow.size() == S);
-            for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0;
-            for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S;
+                 f.final3.size() == (size_t(1) << f.log2BitsF3) / 32 && f.shortBits.size() == 65536 / 32;
+            for (size_t i = 0; ok && i + 1 < fa.edgeBegin.size(); i++) ok = fa.edgeBegin[i] <= fa.edgeBegin[i + 1] && fa.edgeBegin[i] >= 0 && fa.edgeBegin[i + 1] - fa.edgeBegin[i] <= pfac::kCharSet;
+            for (size_t i = 0; ok && i < fa.edgeNext.size(); i++) ok = fa.edgeNext[i] > 0 && (size_t)fa.edgeNext[i] < S && fa.edgeNext[i] != fa.initialState;
             /* what the kernels and the host path take on trust: the longest pattern (overlap of pieces and slices, the
-             * safety margin at the end of the input), the pattern lengths and offsets, the initial state's row */
+             * safety margin at the end of the input), the pattern lengths and offsets */
             int longest = 0;
             for (size_t id = 1; ok && id <= F; id++) {
                 ok = fa.patternLen[id] >= 1 && fa.patternOff[id] >= 0 && (size_t)fa.patternOff[id] + (size_t)fa.patternLen[id] <= fa.file.size();
                 longest = fa.patternLen[id] > longest ? fa.patternLen[id] : longest;
             }
             ok = ok && fa.maxPatternLen == longest;
-            for (size_t i = 0; ok && i < initialRow.size(); i++) ok = initialRow[i] == pfac::kTrapState || (initialRow[i] > 0 && (size_t)initialRow[i] < S);
-            /* a slot's bucket must lie inside the slot array (the walker indexes it without a bound on the global path),
-             * a final slot's pattern ID must be one */
-            const size_t slots = chain.size();
-            auto slotOk = [&](const pfac::ChainSlot &sl) {
-                if (sl.meta & pfac::kSlotEmpty) return true;
-                if (sl.meta & pfac::kSlotLeaf) return !(sl.meta & pfac::kSlotFinal) || (sl.endRow >= 1 && (size_t)sl.endRow <= F);
-                const size_t sizeMask = sl.meta >> 24;
-                int id = 1;
-                if (sl.meta & pfac::kSlotFinal) std::memcpy(&id, sl.chain + 4, sizeof(int));
-                return sl.endRow >= 0 && (size_t)sl.endRow + sizeMask < slots && id >= 1 && (size_t)id <= F;
-            };
-            for (size_t i = 0; ok && i < slots; i++) ok = slotOk(chain[i]);
+            /* the edges form a TREE below the initial state: every state is entered by at most one edge, the bytes of a
+             * state's edges are distinct, no state lies deeper than the longest pattern (so no walk is longer: a cycle would
+             * take a walk past the margin the kernels keep at the end of the input), and final state `id` lies exactly
+             * patternLen[id] deep */
+            if (ok) {
+                std::vector<int> depth(S, -1);
+                std::vector<int> order;
+                order.reserve(S);
+                depth[(size_t)fa.initialState] = 0;
+                order.push_back(fa.initialState);
+                for (size_t at2 = 0; ok && at2 < order.size(); at2++) {
+                    const int st = order[at2];
+                    uint64_t seen[4] = {0, 0, 0, 0};
+                    for (int e = fa.edgeBegin[(size_t)st]; ok && e < fa.edgeBegin[(size_t)st + 1]; e++) {
+                        const unsigned ch = fa.edgeCh[(size_t)e];
+                        const int nx = fa.edgeNext[(size_t)e];
+                        ok = !(seen[ch >> 6] & (uint64_t(1) << (ch & 63))) && depth[(size_t)nx] < 0 && depth[(size_t)st] < fa.maxPatternLen;
+                        seen[ch >> 6] |= uint64_t(1) << (ch & 63);
+                        if (ok) { depth[(size_t)nx] = depth[(size_t)st] + 1; order.push_back(nx); }
+                    }
+                }
+                for (size_t id = 1; ok && id <= F; id++) ok = depth[id] == fa.patternLen[id];
+                /* states the initial state does not reach must have no edges (state 0 is the unused one) */
+                for (size_t st = 0; ok && st < S; st++) ok = depth[st] >= 0 || fa.edgeBegin[st] == fa.edgeBegin[st + 1];
+            }
         }
     } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     if (!ok) return PFAC_STATUS_INVALID_PARAMETER;
@@ -1049,12 +1102,8 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     c->perfMode = (int)h.perfMode;
     c->fa = std::move(fa);
     c->filter = std::move(f);
-    c->h_hashRow = std::move(hashRow);
-    c->h_hashVal = std::move(hashVal);
-    c->h_chainSlots = std::move(chain);
-    c->h_initialRow = std::move(initialRow);
-    c->chainJumpLog2 = (int)h.jumpLog2;
     c->isPatternsReady = true;
+    pfac::buildInitialRow(c->fa, c->h_initialRow);
     PFAC_status_t st = bindCommon(c, /*build=*/false);
     if (st == PFAC_STATUS_SUCCESS) st = bindTable(c);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(c); return st; }
@@ -1081,12 +1130,19 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle)
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!stats) return PFAC_STATUS_INVALID_PARAMETER;
+    if (!stats || stats->structSize < sizeof(size_t) || stats->structSize > (size_t(1) << 16)) return PFAC_STATUS_INVALID_PARAMETER;
+    const size_t callerSize = stats->structSize < sizeof(PFACX_scan_stats_t) ? stats->structSize : sizeof(PFACX_scan_stats_t);
+    PFACX_scan_stats_t local;
+    struct CopyOut {                                          /* whatever the outcome: the caller's struct, as far as it reaches */
+        PFACX_scan_stats_t *dst, *src; size_t n;
+        ~CopyOut() { src->structSize = n; std::memcpy(dst, src, n); }
+    } copyOut{stats, &local, callerSize};
+    stats = &local;
     std::memset(stats, 0, sizeof(*stats));
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     std::lock_guard<std::mutex> guard(handle->lock);
     if (!handle->hasDevice || !handle->d_workCounters) return PFAC_STATUS_LIB_NOT_EXIST;
-    unsigned long long v[pfac::kStatsCount + 1];             /* published by the last block of the launch: scan_gfx950.hip, the kernel's end */
+    unsigned long long v[pfac::kStatsCount + 2];             /* published by the last block of the launch: scan_gfx950.hip, the kernel's end */
     if (hipStreamSynchronize(nullptr) != hipSuccess ||
         hipMemcpy(v, handle->d_workCounters + pfac::kStatsPublishedWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;
@@ -1101,7 +1157,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
         else (void)hipGetLastError();
     }
     stats->tilesPerChunk = pfac::kChunkTiles;
-    stats->walksPerLane = PFAC_WALK_SETS_FULL;        /* of the full-result kernel; the compacted-output kernel runs PFAC_WALK_SETS */
+    stats->walksPerLane = (int)v[pfac::kStatsCount + 1];     /* of the launch the counters describe: the full-result and the compacted-output kernel differ */
     return PFAC_STATUS_SUCCESS;
 }
 
@@ -1126,8 +1182,13 @@ PFAC_status_t PFACX_setKernelTiming(PFAC_handle_t handle, int on)
 PFAC_status_t PFACX_setKernelVariant(PFAC_handle_t handle, int variant)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (variant != PFACX_KERNEL_FILTER && variant != PFACX_KERNEL_NAIVE && variant != PFACX_KERNEL_AUTO) return PFAC_STATUS_INVALID_PARAMETER;
+    if (variant != PFACX_KERNEL_FILTER && variant != PFACX_KERNEL_NAIVE && variant != PFACX_KERNEL_AUTO && variant != PFACX_KERNEL_REFTABLE)
+        return PFAC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> guard(handle->lock);
+    if (variant == PFACX_KERNEL_REFTABLE && handle->isPatternsReady) {      /* the one kernel that reads the reference-layout table on the device */
+        const PFAC_status_t st = ensureDeviceRefTable(handle);
+        if (st != PFAC_STATUS_SUCCESS) return st;
+    }
     handle->kernelVariant = variant;
     return PFAC_STATUS_SUCCESS;
 }

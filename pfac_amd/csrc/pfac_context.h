@@ -53,8 +53,11 @@ constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, wa
 constexpr int kChunkTiles = 2;                 /* KiB of input a wave stages at a time */
 constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
 /* 16-byte device slot of the chained hashed table: one gathered 16-byte load per transition.
- * meta = edge byte | chain length << 8 | flags | k << 15 | (S-1) << 24, where {k, S} are the hash
- * parameters of the END state's bucket (hashRowPtr[end].y = (k << 16) | (S-1), k <= 256, S <= 256). */
+ * meta = edge byte | chain length << 8 | flags | k << 16 | (S-1) << 24, where {k, S} are the hash
+ * parameters of the END state's bucket: the successor on byte ch sits in slot ((k * ch) >> 7) & (S-1) of it
+ * (1 <= k <= 255, S a power of two <= 256, k the smallest multiplier without a collision; k = 128, S = 256 is the
+ * identity and always works).  The reference's hashed layout uses ((k * ch) mod 257) & (S-1) (PFAC.cpp:506-542); this
+ * table is device-only and its own: the multiply-shift costs a walk step four instructions instead of nine. */
 struct ChainSlot {
     uint32_t meta;
     int endRow;                               /* hashRowPtr[end].x (first slot of the end state's bucket);
@@ -69,6 +72,8 @@ constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state 
 constexpr uint32_t kSlotLeaf = 1u << 13;      /* the end state has no outgoing transition               */
 constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */
 static_assert(sizeof(ChainSlot) == 16, "ChainSlot is read as one 16-byte load");
+constexpr uint32_t kChainRootMeta = (128u << 16) | (255u << 24);   /* hash parameters of the initial state's bucket: slot of byte b = b */
+inline uint32_t chainSlotOf(uint32_t meta, uint32_t ch) { return ((((meta >> 16) & 0xFFu) * ch) >> 7) & (meta >> 24); }
 
 /* One compiled pattern set: patterns + trie.  Independent of perfMode. */
 struct Automaton {

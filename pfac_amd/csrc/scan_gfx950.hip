@@ -137,6 +137,9 @@ struct ScanArgs {
     uint32_t rootRow, jumpBase, jumpShift;             /* inside chainSlots: the initial state's bucket (256 slots, indexed by the byte)
                                                           and the jump table (2^(32 - jumpShift) slots): tables.cpp */
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
+    uint32_t maxWalk;                                  /* longest pattern: no walk reads further from its start position */
+    uint32_t hotSlots;                                 /* tiled kernel: the first hotSlots slots of chainSlots (the buckets the initial state's transitions land in,
+                                                          breadth first) are copied to LDS by every block */
     const int *initialRow;
     const uint32_t *gram3;
     const uint32_t *ladder;
@@ -304,15 +307,15 @@ template <bool TEX> struct ChainCtx {
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
           in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift) {}
 };
-constexpr uint32_t kRootKs = 1u | (255u << 9);         /* the initial state's bucket: k = 1, S = 256 -- the slot of byte b is b */
+constexpr uint32_t kRootKs = pfac::kChainRootMeta;      /* the initial state's bucket: k = 128, S = 256 -- the slot of byte b is b */
 
-/* slot of edge byte ch in the bucket described by ks = k | (S-1) << 9 (the slot's meta >> 15):
- * ((k*ch) mod 257) & (S-1), ref PFAC_kernel_spaceDriven.cu:76-124.  256 == -1 (mod 257), k*ch <= 65280. */
+/* slot of edge byte ch in the bucket described by the meta word `ks` of the slot that led to it (k = bits 16..23,
+ * S - 1 = bits 24..31): ((k * ch) >> 7) & (S - 1) -- pfac::chainSlotOf.  The reference's family, ((k*ch) mod 257) & (S-1)
+ * (PFAC_kernel_spaceDriven.cu:76-124), costs nine instructions a step without a divide; this one four, and a walk
+ * step is all instruction issue once the rows are in LDS or L2. */
 __device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
 {
-    const uint32_t x = __umul24(ks & 0x1FFu, ch);
-    const uint32_t r = (x & 0xFFu) - (x >> 8);                 /* in (-256, 256) */
-    return min(r, r + (uint32_t)pfac::kHashP) & (ks >> 9);      /* a negative r is huge as unsigned: picks r + 257 */
+    return ((uint32_t)__umul24(__builtin_amdgcn_ubfe(ks, 16u, 8u), ch) >> 7) & (ks >> 24);
 }
 
 constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brings along: compacted-output kernel (what the prefix ladder looks at) */
@@ -379,7 +382,7 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         const int id = (int)(leaf ? s.y : s.w);                /* kSlotFinal: see pfac::ChainSlot */
         match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
         row = s.y;
-        ks = meta >> 15;
+        ks = meta;
         depth += 1 + len;
         b0 = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * len)) & 0xFFu;   /* byte len (<= 7) behind the edge byte */
         return ok & !leaf;
@@ -477,7 +480,7 @@ __device__ int boundedWalk(const ChainCtx<TEX> &c, const unsigned char *in, size
         if (t.x & pfac::kSlotFinal) match = (int)(leaf ? t.y : t.w);
         if (leaf) break;
         row = t.y;
-        ks = t.x >> 15;
+        ks = t.x;
         at += 1 + len;
     }
     return match;
@@ -1332,7 +1335,8 @@ void pfac_scan_filter(ScanArgs a)
             unsigned long long *published = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsPublishedWord);
             if (lane < 32) atomicExch(a.work + lane * 32, 0u);                              /* the parts' claim counters */
             if (lane < pfac::kStatsCount) published[lane] = lane == 4 ? (unsigned long long)a.n : atomicExch(acc + lane, 0ull);
-            if (lane == pfac::kStatsCount) published[lane] = atomicAdd(a.work + a.denseWord, 0u);   /* stays: the simple kernel behind this launch reads it */
+            if (lane == pfac::kStatsCount) published[lane] = REDUCE ? 0ull : (unsigned long long)atomicAdd(a.work + a.denseWord, 0u);   /* stays: the tiled kernel behind this launch reads it */
+            if (lane == pfac::kStatsCount + 1) published[lane] = (unsigned long long)kWalkSets;
             if (lane == 32) atomicExch(a.work + a.denseWordOther, 0u);
             if (lane == 33) atomicExch(a.work + pfac::kDoneWord, 0u);
         }
@@ -1353,7 +1357,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
 {
     __shared__ int sInit[pfac::kCharSet];
-    if (a.owned == 0 && (a.denseList == nullptr || a.work[a.denseWord] == 0)) return;      /* behind a filter launch that listed no dense chunk */
+    if (a.owned == 0) return;
     sInit[threadIdx.x] = a.initialRow[threadIdx.x];
     __syncthreads();
     const Lookup<MODE> lookup(a);
@@ -1378,24 +1382,360 @@ __global__ __launch_bounds__(256) void pfac_scan_naive(ScanArgs a)
             a.reducePos[at] = (int)(a.reduceBase + (unsigned int)j);
         }
     }
-    /* the chunks the filter kernel in front of this launch found pattern-dense (ScanArgs::denseList): every position of
-     * a listed chunk, one per thread; walks read on into whatever follows the chunk */
-    if (a.denseList == nullptr) return;
-    const unsigned int listed = a.work[a.denseWord];
-    for (unsigned int i = blockIdx.x; i < listed; i += gridDim.x) {
-        const size_t base = (size_t)a.denseList[i] * kChunkBytesDev;
-        for (size_t j = base + threadIdx.x; j < base + kChunkBytesDev; j += 256) {
-            int state = sInit[a.denseIn[j]];
-            int match = 0;
-            if (state != kTrap) {
-                if (state <= a.numFinal) match = state;
-                for (size_t pos = j + 1; pos < a.denseReadable; pos++) {
-                    state = lookup(state, a.denseIn[pos]);
-                    if (state == kTrap) break;
-                    if (state <= a.numFinal) match = state;
+}
+
+/* ---------------------------------------------------------- tiled kernel */
+
+/*
+ * pfac_scan_tiled -- one position per thread-slot, everything a walk touches first in LDS.  The kernel of small calls
+ * (PFACX_KERNEL_AUTO below kSmallInput), of PFACX_KERNEL_NAIVE, and of the chunks the filter kernel found pattern-dense.
+ * Shape of the reference's kernel (PFAC/src/PFAC_kernel.cu:377-458): tile + halo staged in shared memory with wide
+ * coalesced loads (:405-417), positions walked out of LDS bytes (:255-299), results written as whole coalesced lines
+ * (:443-457) -- on the chained table (one 16-byte slot per transition + single-successor chain, tables.cpp) instead of
+ * one gathered table word per byte (dense) or two dependent loads (hashed, PFAC_kernel_spaceDriven.cu:76-124).
+ *
+ * A wave owns a GROUP of TILES x 1 KiB of input at a time; nothing is shared between waves after the block has filled
+ * its LDS tables, so the kernel has no barrier in its loop:
+ *   load     16 B per lane and tile (one 1 KiB-contiguous instruction each) + the 128 bytes behind the group (lanes
+ *            0..31, a dword each); group and halo go to the wave's LDS stage.
+ *   results  every result of the group is stored as zero straight away: 16 B per lane, 1 KiB contiguous per
+ *            instruction, non-temporal -- whole lines, nothing read.  A walk that ends in a match overwrites its zero
+ *            after an s_waitcnt vmcnt(0) (the zero is in L2 by then; same wave, same address: ordered).  With
+ *            ScanArgs::reducePos nothing is zeroed and the matches are appended to the pair list instead (one atomic
+ *            per wave and walk set).
+ *   rows     the initial state's 256-wide transition row (the chained root bucket, 4 KiB) and the buckets the initial
+ *            state's transitions land in, breadth first, as far as the CU's LDS reaches (ScanArgs::hotSlots), are in
+ *            LDS for the whole launch; a walk leaves LDS only for a bucket behind them.
+ *   early    before a position walks at all its first three bytes are looked up in the 3-gram bitmap (LDS; 1-2-byte
+ *            patterns are folded into it, so the bytes behind the end of the input may be anything): a miss proves
+ *            the result is 0 -- the dead state after at most three transitions, decided without taking them.
+ *   walk     the survivors of all 64 lanes and all tiles of the group are compacted into one list (prefix sum of the
+ *            lanes' hit counts), so a wave-wide step has up to 64 live walks however few positions survive; every lane
+ *            runs WALKS independent walks at a time (the loads of a step are issued for all of them before the first is
+ *            consumed: a step is a dependent round trip to LDS, L2 or beyond, and 4 KiB of text give ~200 survivors = one
+ *            full round), and a step loop ends when __ballot says no lane of the wave is alive (PFAC_kernel.cu:299 is
+ *            per thread).  Input bytes come from the stage; only a walk that runs more than 128 bytes past its group
+ *            reads global memory, with every read checked against the end of the input.
+ * Pointers may have any alignment: groups are cut at 16-byte aligned addresses and the positions in front of the first
+ * input byte / behind the last owned one are masked; aligned 16-byte loads that contain a valid byte cannot fault, all
+ * others are not issued.  64-bit positions.
+ */
+constexpr uint32_t kTiledTile = 1024;                  /* input bytes per load instruction of a wave */
+constexpr uint32_t kTiledHalo = 128;                   /* bytes behind the group that are staged with it */
+constexpr uint32_t kTiledList = 256;                   /* 16-bit codes of surviving positions per pass (a group with more takes another pass) */
+#ifndef PFAC_TILED_WALKS
+#define PFAC_TILED_WALKS 4
+#endif
+#ifndef PFAC_TILED_TILES
+#define PFAC_TILED_TILES 4
+#endif
+constexpr int kTiledWalks = PFAC_TILED_WALKS;          /* independent walks per lane */
+constexpr int kTiledTilesBig = PFAC_TILED_TILES;       /* tiles per group: launches with megabytes in front of them */
+constexpr uint32_t kTiledFar = 0x40000000u;            /* "the input ends nowhere near this group" */
+constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2; }   /* stage, list */
+
+template <bool TEX, int WALKS, int TILES, bool HOTALL>
+__global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
+{
+    constexpr uint32_t kGroup = (uint32_t)TILES * kTiledTile, kStage = kGroup + kTiledHalo;
+    static_assert(kGroup <= 4096, "a position's code is 12 bits of offset in 16");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool listMode = a.denseList != nullptr;
+    unsigned int listed = 0;
+    if (listMode) listed = a.work[a.denseWord];
+    if (a.owned == 0 && listed == 0) return;          /* behind a filter launch that listed no dense chunk: before anything is loaded */
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), waves = blockDim.x >> 6;
+    const int words3 = 1 << (a.log2Bits - 5);
+    uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);                     /* LDS address 0: level 1 addresses it by number */
+    u32x4 *sRoot = reinterpret_cast<u32x4 *>(sGram3 + words3);
+    u32x4 *sHot = sRoot + pfac::kCharSet;
+    unsigned char *waveBase = reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + wave * tiledWaveLds(TILES);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(waveBase);
+    uint16_t *list = reinterpret_cast<uint16_t *>(waveBase + kStage);
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+    {
+        const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.gram3);
+        u32x4 *s3 = reinterpret_cast<u32x4 *>(sGram3);
+        for (int i = tid; i < words3 / 4; i += (int)blockDim.x) s3[i] = g3[i];
+        for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) sRoot[i] = a.chainSlots[a.rootRow + (uint32_t)i];
+        for (uint32_t i = (uint32_t)tid; i < a.hotSlots; i += blockDim.x) sHot[i] = a.chainSlots[i];
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000);
+    const uint32_t shift3 = 35u - (uint32_t)a.log2Bits;
+    const uint32_t hot = a.hotSlots;
+    const bool reduce = a.reducePos != nullptr;
+
+    /* One group: g16 = its 16-byte aligned first byte; `span` bytes from there may be loaded (a multiple of 16: up to the
+     * end of the 16-byte block that holds the last input byte); positions [lo, hi) of the group get a result, written to
+     * outGroup[offset]; `limit` = group offset of the first byte behind the input (a pattern cannot reach it);
+     * posBase = position of the group's first byte in the caller's stream (compacted output) */
+    auto scanGroup = [&](const unsigned char *g16, uint64_t span, uint32_t lo, uint32_t hi, uint32_t limit, int *outGroup, uint32_t posBase) {
+        const uint32_t span32 = span > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)span;
+        const bool whole = lo == 0 && (hi & (kTiledTile - 1u)) == 0;      /* whole tiles: all of the group, or -- a dense chunk -- its first ones */
+        const bool bounded = limit < kGroup + a.maxWalk + 16u;           /* wave-uniform: a walk of this group can come near the end of the input */
+        u32x4 dt[TILES];
+        uint32_t follow = 0;
+#pragma unroll
+        for (int t = 0; t < TILES; t++) {
+            dt[t] = u32x4{0, 0, 0, 0};
+            const uint32_t off = (uint32_t)t * kTiledTile + (uint32_t)lane * 16u;
+            if (off < span32) dt[t] = *reinterpret_cast<const u32x4 *>(g16 + off);
+        }
+        if (lane < (int)(kTiledHalo / 4) && kGroup + (uint32_t)lane * 4u < span32) follow = *reinterpret_cast<const uint32_t *>(g16 + kGroup + lane * 4);
+#pragma unroll
+        for (int t = 0; t < TILES; t++) reinterpret_cast<u32x4 *>(stage)[t * 64 + lane] = dt[t];
+        if (lane < (int)(kTiledHalo / 4)) stage[kGroup / 4 + lane] = follow;
+        /* ---- early-out: the 3-gram bitmap, 16 positions per lane and tile (bytes 16 lane .. 16 lane + 15, + 2 of the next lane) */
+        uint32_t hits[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; t++) {
+            const uint32_t dw[4] = {dt[t].x, dt[t].y, dt[t].z, dt[t].w};
+            uint32_t nxtLane = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw[0], 0x130, 0xf, 0xf, false);   /* wave_shl:1 */
+            /* behind lane 63: the first dword of the next tile (lane 0 has it), or of the halo */
+            const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t + 1 < TILES ? dt[t + 1 < TILES ? t + 1 : t].x : follow));
+            if (lane == 63) nxtLane = wrap;
+            uint32_t h = 0;
+#pragma unroll
+            for (int b0 = 0; b0 < 16; b0 += 8) {
+                uint32_t word[8], xs[9];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = (b0 + q) >> 2, i = (b0 + q) & 3;
+                    const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
+                    const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
+                    const uint32_t product = (uint32_t)__umul24(x, pfac::kGram3Mul);
+                    word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> shift3) & ~3u);
+                    xs[q] = x;
+                }
+                xs[8] = b0 + 8 < 16 ? dw[(b0 + 8) >> 2] : nxtLane;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    h = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> (xs[q + 1] & 31u)), h, 1);
+            }
+            h >>= 16;                                              /* bit i: position 1024 t + 16 lane + i */
+            if (whole) {
+                if ((uint32_t)t * kTiledTile >= hi) h = 0;
+            } else {                                               /* a group at an end of the input: only positions [lo, hi) */
+                const int at = t * (int)kTiledTile + lane * 16;
+                const int first = (int)lo - at, last = (int)hi - at;
+                const uint32_t f = first < 0 ? 0u : first > 16 ? 16u : (uint32_t)first, l = last < 0 ? 0u : last > 16 ? 16u : (uint32_t)last;
+                h &= ((1u << l) - 1u) & ~((1u << f) - 1u);
+            }
+            hits[t] = h;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        /* bytes q .. q+7 of the group (q = offset from g16): from the stage, or -- a walk more than 128 bytes behind its
+         * group -- from global memory, loading only dwords of 16-byte blocks that hold input */
+        auto fetch = [&](uint32_t q, uint32_t &w0, uint32_t &w1) {
+            uint32_t e0, e1, e2;
+            if (q + 12u <= kStage) {
+                const uint32_t *p = stage + (q >> 2);
+                e0 = p[0]; e1 = p[1]; e2 = p[2];
+            } else {
+                const uint32_t at = q & ~3u;
+                e0 = at < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at) : 0u;
+                e1 = at + 4u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 4u) : 0u;
+                e2 = at + 8u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 8u) : 0u;
+            }
+            w0 = __builtin_amdgcn_alignbyte(e1, e0, q & 3u);
+            w1 = __builtin_amdgcn_alignbyte(e2, e1, q & 3u);
+        };
+
+        /* WALKS walks per lane from the group offsets o[] (alive[]: the lane has one), to the end: match[] = result */
+        auto runWalks = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
+            uint32_t q[WALKS], row[WALKS], ks[WALKS];
+            /* one transition through slot s on the edge byte at q, w0:w1 = bytes q .. q+7 (ChainLane::advance, with the
+             * end of the input checked: edge byte and chain must lie in front of `limit`) */
+            auto step = [&](int k, const u32x4 &s, uint32_t w0, uint32_t w1) {
+                const uint32_t meta = s.x, len = __builtin_amdgcn_ubfe(meta, 8u, 4u);
+                bool ok = alive[k] & ((meta & (pfac::kSlotEmpty | 0xFFu)) == (w0 & 0xFFu));
+                if (bounded) ok &= q[k] + len < limit;
+                if (__ballot(ok & (len != 0)) != 0) {              /* the top of a trie branches at every byte: no chain, nothing to compare */
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, 1), x1 = w1 >> 8;
+                    const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
+                    ok &= ((diff << 8) << (56u - 8u * len)) == 0;
+                }
+                const bool leaf = (meta & pfac::kSlotLeaf) != 0;
+                const int id = (int)(leaf ? s.y : s.w);
+                match[k] = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match[k];
+                row[k] = s.y;
+                ks[k] = meta;
+                q[k] += 1u + len;
+                alive[k] = ok & !leaf;
+            };
+            {   /* first transition: the initial state's row, in LDS, indexed by the byte itself */
+                u32x4 s[WALKS];
+                uint32_t w0[WALKS], w1[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    q[k] = o[k]; match[k] = 0; row[k] = 0; ks[k] = 0;
+                    w0[k] = w1[k] = 0; s[k] = u32x4{pfac::kSlotEmpty, 0, 0, 0};
+                    if (alive[k]) { fetch(q[k], w0[k], w1[k]); s[k] = sRoot[w0[k] & 0xFFu]; }
+                }
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) step(k, s[k], w0[k], w1[k]);
+            }
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) any |= alive[k];
+                if (__ballot(any) == 0) break;                 /* every walk of the wave is in the dead state (or matched at a leaf) */
+                u32x4 s[WALKS];
+                uint32_t w0[WALKS], w1[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    w0[k] = w1[k] = 0; s[k] = u32x4{pfac::kSlotEmpty, 0, 0, 0};
+                    if (alive[k]) {
+                        fetch(q[k], w0[k], w1[k]);
+                        const uint32_t at = row[k] + chainHashSlot(ks[k], w0[k] & 0xFFu);
+                        if (HOTALL || at < hot) s[k] = sHot[at];
+                        else if (TEX) s[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(at * 16u), 0, 0);
+                        else s[k] = a.chainSlots[at];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) step(k, s[k], w0[k], w1[k]);
+            }
+        };
+        /* compacted output: the matches of a walk set join the pair list, one atomic per set */
+        auto appendPairs = [&](const uint32_t (&o)[WALKS], const int (&match)[WALKS]) {
+#pragma unroll
+            for (int k = 0; k < WALKS; k++) {
+                const bool has = match[k] != 0;
+                const uint64_t m = __ballot(has);
+                if (m) {
+                    unsigned int at = 0;
+                    if (lane == 0) at = atomicAdd(a.reduceCount, (unsigned int)__popcll(m));
+                    at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + laneRankIn(m);
+                    if (has) { a.out[at] = match[k]; a.reducePos[at] = (int)(posBase + o[k]); }
                 }
             }
-            a.denseOut[j] = match;
+        };
+
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int t = 0; t < TILES; t++) cnt += (uint32_t)__builtin_popcount(hits[t]);
+        const uint32_t survivors = (uint32_t)__builtin_amdgcn_readlane((int)waveInclusiveScan(cnt), 63);
+        if (survivors * 2u >= hi - lo) {
+            /* ---- DENSE group (half of its positions or more survive: short patterns over text, runs of a pattern byte):
+             * compaction would cost more than idle lanes.  Position p = 256 r + 64 k + lane walks in round r, walk k: the
+             * lanes of a walk are 64 consecutive positions -- their stage bytes are 16 consecutive dwords, their results one
+             * 256-byte store, and nothing is zeroed first.  The hit masks go through LDS (the list's place). */
+#pragma unroll
+            for (int t = 0; t < TILES; t++) list[t * 64 + lane] = (uint16_t)hits[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t base = lo & ~255u; base < hi; base += 64u * (uint32_t)WALKS) {
+                uint32_t o[WALKS];
+                int match[WALKS];
+                bool alive[WALKS], mine[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    o[k] = base + (uint32_t)k * 64u + (uint32_t)lane;
+                    mine[k] = o[k] >= lo && o[k] < hi;
+                    alive[k] = mine[k] && (((uint32_t)list[o[k] >> 4] >> (o[k] & 15u)) & 1u) != 0;
+                }
+                runWalks(o, alive, match);
+                if (reduce) appendPairs(o, match);
+                else {
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++)
+                        if (mine[k]) __builtin_nontemporal_store(match[k], outGroup + o[k]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            return;
+        }
+        /* ---- SPARSE group: every result is stored as zero now -- 16 B per lane, 1 KiB contiguous per instruction, whole
+         * lines, nothing read; they are 80 % of the call's traffic -- and the few walks that end in a match overwrite theirs */
+        if (!reduce) {
+            const i32x4 zero = {0, 0, 0, 0};
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 4 * TILES; k++)
+                    if ((uint32_t)k * 256u < hi) __builtin_nontemporal_store(zero, reinterpret_cast<i32x4 *>(outGroup) + k * 64 + lane);
+            } else {
+                for (uint32_t p = lo + (uint32_t)lane; p < hi; p += 64u) outGroup[p] = 0;
+            }
+        }
+        /* the survivors, compacted: passes of up to kTiledList positions, each walked 64 x WALKS at a time */
+        for (;;) {
+            cnt = 0;
+#pragma unroll
+            for (int t = 0; t < TILES; t++) cnt += (uint32_t)__builtin_popcount(hits[t]);
+            if (__ballot(cnt != 0) == 0) break;
+            const uint32_t incl = waveInclusiveScan(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t idx = incl - cnt;
+#pragma unroll
+            for (int t = 0; t < TILES; t++) {
+                while (hits[t] != 0 && idx < kTiledList) {
+                    list[idx] = (uint16_t)(((uint32_t)t << 10) | ((uint32_t)lane << 4) | (uint32_t)__builtin_ctz(hits[t]));    /* = offset of the position in the group */
+                    idx++;
+                    hits[t] &= hits[t] - 1;
+                }
+            }
+            const uint32_t listedNow = total < kTiledList ? total : kTiledList;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t base = 0; base < listedNow; base += 64u * (uint32_t)WALKS) {
+                uint32_t o[WALKS];
+                int match[WALKS];
+                bool alive[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    const uint32_t e = base + (uint32_t)k * 64u + (uint32_t)lane;
+                    alive[k] = e < listedNow;
+                    o[k] = alive[k] ? (uint32_t)list[e] : 0u;
+                }
+                runWalks(o, alive, match);
+                if (reduce) appendPairs(o, match);
+                else {
+                    /* every load of these walks has been consumed; the wait is for the zero stores of a group none of whose
+                     * walks left LDS (vmcnt counts vector memory in issue order on gfx9): the zero is in L2 before its patch */
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++)
+                        if (match[k] != 0) outGroup[o[k]] = match[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    };
+
+    const uint64_t gid = (uint64_t)blockIdx.x * waves + wave, stride = (uint64_t)gridDim.x * waves;
+    if (a.owned != 0) {
+        /* positions [0, owned) of a.in; groups are cut from the 16-byte aligned address at or below a.in */
+        const uint64_t head = reinterpret_cast<uintptr_t>(a.in) & 15u;
+        const unsigned char *base16 = a.in - head;
+        const uint64_t spanAll = (head + a.n + 15u) & ~uint64_t(15), ownEnd = head + a.owned, readEnd = head + a.n;
+        const uint64_t groups = (ownEnd + kGroup - 1) / kGroup;
+        for (uint64_t g = gid; g < groups; g += stride) {
+            const uint64_t T = g * kGroup;
+            const uint32_t lo = T < head ? (uint32_t)(head - T) : 0u;
+            const uint32_t hi = ownEnd - T < kGroup ? (uint32_t)(ownEnd - T) : kGroup;
+            const uint32_t limit = readEnd - T < kTiledFar ? (uint32_t)(readEnd - T) : kTiledFar;
+            int *outGroup = reinterpret_cast<int *>(reinterpret_cast<uintptr_t>(a.out) + (T - head) * 4u);     /* T < head only in group 0, whose first `head` slots are never written */
+            scanGroup(base16 + T, spanAll - T, lo, hi, limit, outGroup, a.reduceBase + (uint32_t)(T - head));
+        }
+    }
+    if (listed != 0) {
+        /* the chunks the filter kernel in front of this launch left to this kernel (ScanArgs::denseList): denseIn is the
+         * 16-byte aligned first byte of that launch's input.  A chunk is smaller than a group: the rest of the group is masked */
+        constexpr uint32_t kChunk = (uint32_t)kChunkBytesDev;
+        constexpr uint32_t kPerChunk = kChunk > kGroup ? kChunk / kGroup : 1u, kTake = kChunk > kGroup ? kGroup : kChunk;
+        const uint64_t spanAll = (a.denseReadable + 15u) & ~uint64_t(15);
+        const uint64_t items = (uint64_t)listed * kPerChunk;
+        for (uint64_t it = gid; it < items; it += stride) {
+            const uint64_t T = (uint64_t)a.denseList[it / kPerChunk] * kChunk + (it % kPerChunk) * kGroup;
+            const uint32_t limit = a.denseReadable - T < kTiledFar ? (uint32_t)(a.denseReadable - T) : kTiledFar;
+            scanGroup(a.denseIn + T, spanAll - T, 0u, kTake, limit, a.denseOut + T, 0u);
         }
     }
 }
@@ -1501,14 +1841,63 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
     return e;
 }
 
+/* pfac_scan_tiled.  A launch that has whole megabytes in front of it -- or the dense-chunk list of a filter launch --
+ * runs one persistent 1024-thread block per CU, groups of kTiledTilesBig KiB per wave, and every LDS byte the waves'
+ * buffers leave as hot table rows; a small call runs 256-thread blocks, 1 KiB per wave, with the initial state's row
+ * only (filling LDS is what a call of a few KiB pays for). */
+constexpr size_t kTiledBigBytes = size_t(2) << 20;
+template <bool TEX>
+hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
+{
+    auto kernelBig = pfac_scan_tiled<TEX, kTiledWalks, kTiledTilesBig, false>;
+    auto kernelBigHot = pfac_scan_tiled<TEX, kTiledWalks, kTiledTilesBig, true>;     /* every bucket of the table fits the CU's LDS: no global path in the step */
+    auto kernelSmall = pfac_scan_tiled<TEX, kTiledWalks, 1, false>;
+    static ShapeCache cache;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidValue;
+    {
+        std::lock_guard<std::mutex> g(cache.lock);
+        if (cache.perCU[dev] == 0) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernelBig), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernelBigHot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernelSmall), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+            if (e != hipSuccess) return e;
+            cache.perCU[dev] = 1;
+        }
+    }
+    const size_t head = reinterpret_cast<uintptr_t>(a.in) & 15u;
+    const bool big = a.denseList != nullptr || a.owned >= kTiledBigBytes;
+    const size_t group = (big ? (size_t)kTiledTilesBig : 1) * kTiledTile;
+    const size_t groups = a.owned ? (head + a.owned + group - 1) / group : 0;
+    const unsigned threads = big ? 1024u : 256u;
+    const size_t waves = threads / 64;
+    const size_t cus = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256);
+    const size_t fixed = (size_t(1) << c->filter.log2Bits) / 8 + (size_t)pfac::kCharSet * sizeof(pfac::ChainSlot) + waves * tiledWaveLds(big ? kTiledTilesBig : 1);
+    if (fixed > kLdsPerCu) return hipErrorInvalidValue;
+    size_t hot = 0;
+    if (big) {
+        hot = (kLdsPerCu - fixed) / sizeof(pfac::ChainSlot);
+        if (hot > a.rootRow) hot = a.rootRow;            /* the buckets lie in front of the initial state's row */
+    }
+    a.hotSlots = (uint32_t)hot;
+    size_t blocks = (groups + waves - 1) / waves;
+    if (a.denseList != nullptr || blocks > (big ? cus : cus * 16)) blocks = big ? cus : cus * 16;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = fixed + hot * sizeof(pfac::ChainSlot);
+    if (big && hot == a.rootRow) hipLaunchKernelGGL(kernelBigHot, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+    else if (big) hipLaunchKernelGGL(kernelBig, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+    else hipLaunchKernelGGL(kernelSmall, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+    return hipGetLastError();
+}
+
 template <int MODE>
 hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
 {
     size_t blocks = (a.owned + 255) / 256;
     const size_t cap = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256) * 8;
     if (blocks > cap) blocks = cap;
-    if (a.denseList) blocks = cap;                                  /* a launch that may find a list of pattern-dense chunks: enough blocks to walk them
-                                                                       (they read the list's length and leave if it is empty) */
     hipLaunchKernelGGL(pfac_scan_naive<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
     return hipGetLastError();
 }
@@ -1533,8 +1922,9 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
                        int *d_matched_result, ScanArgs &a)
 {
     if (!c->d_initialRow || !c->d_gram3 || !c->d_ladder || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
-    if (!c->d_chainSlots || c->chainJumpLog2 <= 0 || (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense))
-        return PFAC_STATUS_INTERNAL_ERROR;
+    if (!c->d_chainSlots || c->chainJumpLog2 <= 0) return PFAC_STATUS_INTERNAL_ERROR;
+    /* the reference-layout tables are on the device only while PFACX_KERNEL_REFTABLE is selected (pfac_api.cpp uploads them) */
+    if (c->kernelVariant == PFACX_KERNEL_REFTABLE && (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense)) return PFAC_STATUS_INTERNAL_ERROR;
     a = ScanArgs{};
     a.in = reinterpret_cast<const unsigned char *>(d_input_string);
     a.out = d_matched_result;
@@ -1559,6 +1949,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.log2BitsLad = c->filter.log2BitsLad;
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
+    a.maxWalk = (uint32_t)c->fa.maxPatternLen;
     a.work = c->d_workCounters;
     a.denseWord = (uint32_t)pfac::kDenseCountWord;
     a.denseWordOther = (uint32_t)pfac::kDenseCountWordB;
@@ -1585,7 +1976,7 @@ constexpr size_t kSmallInput = size_t(1) << 20;
  * (`first` is the first 16-byte aligned input byte: scan() and reduceScan() peel the positions in front of it) */
 size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
 {
-    if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE) return 0;
+    if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE || c->kernelVariant == PFACX_KERNEL_REFTABLE) return 0;
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
         if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
     }
@@ -1611,6 +2002,14 @@ hipError_t launchNaiveFor(const PFAC_context *c, bool hashed, bool tex, const Sc
 {
     if (hashed) return tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
     return tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
+}
+
+/* what is not the filter kernel's: the tiled kernel (chained table, both perf modes), or -- PFACX_KERNEL_REFTABLE -- the
+ * reference-shaped kernel on the reference-layout table of the perf mode */
+hipError_t launchSimple(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part)
+{
+    if (c->kernelVariant == PFACX_KERNEL_REFTABLE) return launchNaiveFor(c, hashed, tex, part);
+    return tex ? launchTiled<true>(c, part) : launchTiled<false>(c, part);
 }
 
 PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size, int *d_matched_result, bool hashed)
@@ -1673,7 +2072,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
                 rest.denseReadable = input_size - first;
                 rest.owned = 0;
                 rest.n = input_size - first;
-                e = launchNaiveFor(c, hashed, tex, rest);
+                e = tex ? launchTiled<true>(c, rest) : launchTiled<false>(c, rest);
             }
 #endif
         } else {
@@ -1685,14 +2084,14 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             rest.owned = ownEnd - first + back;
             rest.n = input_size - first + back;
             headDone = true;
-            e = launchNaiveFor(c, hashed, tex, rest);
+            e = launchSimple(c, hashed, tex, rest);
         }
     }
     if (e == hipSuccess && !headDone) {                 /* the whole input is in front of the first aligned byte */
         ScanArgs part = a;
         part.owned = head;
         part.n = input_size;
-        e = launchNaiveFor(c, hashed, tex, part);
+        e = launchSimple(c, hashed, tex, part);
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
 }
@@ -2030,7 +2429,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         ScanArgs part = a;
         part.owned = n;
         part.reduceBase = 0;
-        if (launchNaiveFor(c, hashed, tex, part) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        if (launchSimple(c, hashed, tex, part) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     }
     if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     unsigned int count = 0;

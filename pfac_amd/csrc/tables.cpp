@@ -109,8 +109,9 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * Device-only "chained" transition table for the gfx950 walker (scan_gfx950.hip), used in BOTH perf modes.
  *
  * The reference's hashed layout (above) answers one transition with two dependent loads (rowPtr[state], then
- * valPtr[...], PFAC_kernel_spaceDriven.cu:76-124) and gives every state a bucket.  The walker's table keeps the
- * reference's hash family -- slot = ((k * ch) mod 257) & (S - 1), smallest collision-free k -- but
+ * valPtr[...], PFAC_kernel_spaceDriven.cu:76-124) and gives every state a bucket.  The walker's table is hashed per state
+ * like the reference's -- a power-of-two bucket, the smallest multiplier k without a collision -- with a cheaper family,
+ * slot = ((k * ch) >> 7) & (S - 1) (pfac_context.h: chainSlotOf), and
  *   - a slot carries the bucket {offset, k, S} of the state the walker will be in next, so a transition needs ONE
  *     dependent 16-byte load;
  *   - a slot carries the single-successor chain that follows `next`: while the current state is not final and has
@@ -120,7 +121,7 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  *     anywhere in the chain is the trap state (PFAC_CPU.cpp:76-96);
  *   - only states a walk can LAND in have a bucket (nine out of ten states of a Snort-scale set are inside chains),
  *     buckets are as small as the hash family allows (the smallest power of two >= the fan-out that has a
- *     collision-free k; the reference's ladder gives a state with nine successors 128 slots) and they are laid out
+ *     collision-free k <= 255; the reference's ladder gives a state with nine successors 128 slots) and they are laid out
  *     breadth first, the top of the trie -- where walks spend their time -- in one contiguous piece: the table of the
  *     30 k-pattern bench set shrinks from 11.9 MB to a few MB that stay in the 4 MiB L2 of an XCD next to the stream.
  * The end state's number is only needed when it is final (it is the pattern ID).  A final leaf keeps it in endRow (a
@@ -129,7 +130,7 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * from there).
  *
  * Behind the buckets the array carries two more regions:
- *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 1, S = 256);
+ *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 128, S = 256);
  *   [jumpBase, jumpBase + 2^J) the JUMP table: one slot per 4-byte pattern prefix whose first three states are not
  *                              final, at hash(prefix), encoded as a transition on the first byte with the other
  *                              three as the head of its chain.  A walk starts there -- the prefilter has just
@@ -146,6 +147,7 @@ struct ChainBuilder {
     std::vector<ChainSlot> &slots;                 /* the buckets; root row and jump table are appended at the end */
     std::vector<int> bucketOff;                    /* per state: first slot of its bucket, -1 = none yet */
     std::vector<uint32_t> bucketKS;                /* per state: k << 8 | (S - 1) */
+    static int chainSlotIn(int k, int ch, int S) { return ((k * ch) >> 7) & (S - 1); }     /* pfac::chainSlotOf */
     std::vector<int> pending;                      /* states whose bucket is allocated but not filled, in allocation order */
     bool failed = false;
 
@@ -171,11 +173,11 @@ struct ChainBuilder {
         while (S < fan) S *= 2;
         int k = -1;
         for (; S <= 256 && k < 0; S *= 2) {
-            for (int cand = 1; cand <= 256 && k < 0; cand++) {
+            for (int cand = 1; cand <= 255 && k < 0; cand++) {
                 uint64_t used[4] = {0, 0, 0, 0};
                 bool ok = true;
                 for (int i = b; i < e && ok; i++) {
-                    const int slot = slotOf(cand, fa.edgeCh[i], S);
+                    const int slot = chainSlotIn(cand, fa.edgeCh[i], S);
                     const uint64_t bit = uint64_t(1) << (slot & 63);
                     ok = !(used[slot >> 6] & bit);
                     used[slot >> 6] |= bit;
@@ -184,7 +186,7 @@ struct ChainBuilder {
             }
             if (k >= 0) break;
         }
-        if (k < 0) { failed = true; return; }      /* cannot happen: k = 1, S = 256 separates any 255 bytes */
+        if (k < 0) { failed = true; return; }      /* cannot happen: k = 128, S = 256 is the identity */
         bucketOff[state] = (int)slots.size();
         bucketKS[state] = ((uint32_t)k << 8) | (uint32_t)(S - 1);
         slots.resize(slots.size() + (size_t)S, emptySlot());
@@ -218,7 +220,7 @@ struct ChainBuilder {
         if (!leaf) needBucket(cur);
         const uint32_t hashK = leaf ? 0u : bucketKS[cur] >> 8;           /* 1..256 */
         const uint32_t sizeMask = leaf ? 0u : bucketKS[cur] & 0xFFu;     /* S-1 <= 255 */
-        s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 15) | (sizeMask << 24);
+        s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 16) | (sizeMask << 24);
         s.endRow = leaf ? (fin ? cur : -1) : bucketOff[cur];
         if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));
         return s;
@@ -232,7 +234,7 @@ struct ChainBuilder {
             const int k = (int)(bucketKS[state] >> 8), S = (int)(bucketKS[state] & 0xFFu) + 1;
             for (int e = fa.edgeBegin[state]; e < fa.edgeBegin[state + 1]; e++) {
                 const ChainSlot slot = makeSlot(fa.edgeCh[e], fa.edgeNext[e]);           /* may grow `slots` */
-                slots[(size_t)bucketOff[state] + (size_t)slotOf(k, fa.edgeCh[e], S)] = slot;
+                slots[(size_t)bucketOff[state] + (size_t)chainSlotIn(k, fa.edgeCh[e], S)] = slot;
             }
         }
         pending.clear();

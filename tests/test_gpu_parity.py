@@ -21,7 +21,8 @@ MODES = [
     (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF, "hash-global"),
     (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, "hash-buffer"),
 ]
-VARIANTS = [(api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto")]
+VARIANTS = [(api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto"),
+            (api.PFACX_KERNEL_REFTABLE, "reftable")]
 
 
 @pytest.fixture(scope="module", autouse=True)

@@ -188,7 +188,8 @@ def test_snort_length_distribution_with_1_and_2_byte_patterns(workdir, capsys):
     assert np.count_nonzero(want) > n // 64                     # the 1-byte patterns make matches dense
     rates = {}
     for perf, tex, mode_name in MODES:
-        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto")):
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto"),
+                               (api.PFACX_KERNEL_REFTABLE, "reftable")):
             h = make_handle(pf, perf, tex, variant)
             try:
                 got, rate = _timed_match(h, data)
@@ -253,7 +254,7 @@ def test_every_position_matches_256_mib(workdir, capsys):
     assert np.count_nonzero(want) == n - 1
     rates = {}
     for perf, tex, mode_name in (MODES[1], MODES[3]):
-        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")):
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_REFTABLE, "reftable")):
             h = make_handle(pf, perf, tex, variant)
             try:
                 got, rate = _timed_match(h, data, steps=2)

@@ -427,7 +427,7 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
             ok, leaf, ident, row, ks, used = step(slots[jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J))], data[i], i + 1)
             if ok:
                 used_jump += 1
-            else:                                  # restart in the initial state's bucket (k = 1, S = 256)
+            else:                                  # restart in the initial state's bucket (k = 128, S = 256: the byte itself)
                 fell_back += 1
                 ok, leaf, ident, row, ks, used = step(slots[root_row + data[i]], data[i], i + 1)
             depth = 0
@@ -438,11 +438,8 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
                 if leaf:
                     break
                 b0 = data[i + depth]
-                prod = (ks & 0x1FF) * b0
-                r = (prod & 0xFF) - (prod >> 8)
-                if r < 0:
-                    r += 257
-                ok, leaf, ident, row, ks, used = step(slots[row + (r & (ks >> 9))], b0, i + depth + 1)
+                r = ((((ks >> 16) & 0xFF) * b0) >> 7) & (ks >> 24)        # pfac_context.h: chainSlotOf
+                ok, leaf, ident, row, ks, used = step(slots[row + r], b0, i + depth + 1)
             assert match == int(expect[i]), (name, perf, i, match, int(expect[i]))
         return used_jump, fell_back
 
@@ -458,7 +455,7 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
         ident = 0
         if ok and meta & FINAL:
             ident = int(slot[1]) if leaf else int(slot[3])
-        return ok, leaf, ident, int(slot[1]), meta >> 15, 1 + ln
+        return ok, leaf, ident, int(slot[1]), meta, 1 + ln
 
     used_jump, fell_back = walk_all(w.data[:30000], oracle_results[name])
     if name in ("c2", "c3"):

@@ -61,7 +61,8 @@ def main():
                     sp = list((rf.get("placement_spread_kernel_ms") or {"x": rf["kernel_ms_avg"]}).values())
                     ws = d["config"].get("walk_stats") or {}
                     rows.setdefault((spec, w), []).append((rf["kernel_ms_avg"], d["config"]["bit_exact"], (d.get("reduce_api") or {}).get("ms_per_call"),
-                                                           min(sp), max(sp), ws.get("walksStarted"), (rf.get("bare_stream_1r4w") or {}).get("ms"), ws.get("walkerRounds"), ws.get("laneSteps"), ws.get("ladderCandidates")))
+                                                           min(sp), max(sp), ws.get("walksStarted"), (rf.get("bare_stream_1r4w") or {}).get("ms"), ws.get("walkerRounds"), ws.get("laneSteps"), ws.get("ladderCandidates"),
+                                                           (d.get("reduce_api") or {}).get("kernel_ms")))
     finally:
         for f in ("libpfac.so", "libpfac_gfx950.so"):
             shutil.copy2(os.path.join(keep, f), os.path.join(LIB, f))
@@ -74,9 +75,10 @@ def main():
         ms = [x[0] for x in ok]
         red = [x[2] for x in ok if x[2] is not None]
         stream = [x[6] for x in ok if x[6]]
-        lines.append("%-44s %-4s kernel ms min %.4f median %.4f max %.4f (n=%d%s) exact %s | reduce ms min %s | 4 buffer pairs %.4f .. %.4f | walks %s rounds %s lane steps %s candidates %s | bare stream %s" % (
+        redk = [x[10] for x in ok if x[10] is not None]
+        lines.append("%-44s %-4s kernel ms min %.4f median %.4f max %.4f (n=%d%s) exact %s | reduce call ms min %s kernel ms min/median %s | 4 buffer pairs %.4f .. %.4f | walks %s rounds %s lane steps %s candidates %s | bare stream %s" % (
             spec, w, min(ms), statistics.median(ms), max(ms), len(ok), ", %d failed" % (len(v) - len(ok)) if len(ok) < len(v) else "",
-            all(x[1] for x in ok), ("%.3f" % min(red)) if red else "-", min(x[3] for x in ok), max(x[4] for x in ok), ok[-1][5], ok[-1][7], ok[-1][8], ok[-1][9],
+            all(x[1] for x in ok), ("%.3f" % min(red)) if red else "-", ("%.4f/%.4f" % (min(redk), statistics.median(redk))) if redk else "-", min(x[3] for x in ok), max(x[4] for x in ok), ok[-1][5], ok[-1][7], ok[-1][8], ok[-1][9],
             ("%.4f" % min(stream)) if stream else "-"))
     text = "\n".join(lines)
     print(text)

@@ -176,10 +176,12 @@ struct ScanArgs {
 using pfac::kDenseCountWord;                            /* the launch counters are one 128-byte line each: lines 0..31 hand out the input (at most 32 parts),
                                                           line 32 or 34 (ScanArgs::denseWord) counts the dense chunks */
 constexpr uint32_t kDenseStage = 8;                     /* dense chunks a wave collects in LDS before it appends them to the list */
-constexpr uint32_t kDenseHits = 1843;                  /* of the 2048 positions of a chunk: above 90 % the prefilter only adds work.  (Input in which every
-                                                          position matches: 40 GB/s through the filter kernel, 80-118 through the simple one; text in which a
-                                                          third of the positions match and two thirds pass level 1 is still faster through the filter kernel,
-                                                          137-168 against 65-120 GB/s: profiles/r03_experiments.md) */
+#ifndef PFAC_DENSE_HITS
+#define PFAC_DENSE_HITS 1024
+#endif
+constexpr uint32_t kDenseHits = PFAC_DENSE_HITS;       /* of the 2048 positions of a chunk: above half, listing, testing and queueing the survivors costs more than the
+                                                          tiled kernel's dense mode, which walks every position of such a chunk in place (round 3, with the
+                                                          reference-shaped kernel behind the list, needed 90 %: profiles/r03_experiments.md) */
 
 /* ---------------------------------------------------------------- lookups */
 
@@ -1664,20 +1666,25 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                 for (uint32_t p = lo + (uint32_t)lane; p < hi; p += 64u) outGroup[p] = 0;
             }
         }
-        /* the survivors, compacted: passes of up to kTiledList positions, each walked 64 x WALKS at a time */
+        /* the survivors, compacted: passes of up to kTiledList positions, each walked 64 x WALKS at a time.  A group with
+         * more survivors than one pass takes lists at most kTiledList / 64 of every lane per pass: all lanes emit for a few
+         * trips, instead of the first few lanes for as many trips as they have hits. */
+        const bool crowded = survivors > kTiledList;           /* wave-uniform */
         for (;;) {
             cnt = 0;
 #pragma unroll
             for (int t = 0; t < TILES; t++) cnt += (uint32_t)__builtin_popcount(hits[t]);
             if (__ballot(cnt != 0) == 0) break;
-            const uint32_t incl = waveInclusiveScan(cnt);
+            uint32_t quota = crowded ? (cnt < kTiledList / 64u ? cnt : kTiledList / 64u) : cnt;
+            const uint32_t incl = waveInclusiveScan(quota);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t idx = incl - cnt;
+            uint32_t idx = incl - quota;
 #pragma unroll
             for (int t = 0; t < TILES; t++) {
-                while (hits[t] != 0 && idx < kTiledList) {
+                while (hits[t] != 0 && quota != 0 && idx < kTiledList) {
                     list[idx] = (uint16_t)(((uint32_t)t << 10) | ((uint32_t)lane << 4) | (uint32_t)__builtin_ctz(hits[t]));    /* = offset of the position in the group */
                     idx++;
+                    quota--;
                     hits[t] &= hits[t] - 1;
                 }
             }
@@ -1697,12 +1704,17 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                 runWalks(o, alive, match);
                 if (reduce) appendPairs(o, match);
                 else {
-                    /* every load of these walks has been consumed; the wait is for the zero stores of a group none of whose
-                     * walks left LDS (vmcnt counts vector memory in issue order on gfx9): the zero is in L2 before its patch */
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    bool found = false;
 #pragma unroll
-                    for (int k = 0; k < WALKS; k++)
-                        if (match[k] != 0) outGroup[o[k]] = match[k];
+                    for (int k = 0; k < WALKS; k++) found |= match[k] != 0;
+                    if (__ballot(found) != 0) {                /* one position in two thousand matches on the Snort-style stream: most sets store nothing */
+                        /* every load of these walks has been consumed; the wait is for the zero stores of a group none of whose
+                         * walks left LDS (vmcnt counts vector memory in issue order on gfx9): the zero is in L2 before its patch */
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < WALKS; k++)
+                            if (match[k] != 0) outGroup[o[k]] = match[k];
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

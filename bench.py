@@ -447,10 +447,10 @@ class Run:
 
 
 def kernel_name(args, run):
-    """The kernel a launch of this run goes to (the library default takes the filter kernel from 1 MiB up)."""
+    """The kernel a launch of this run goes to (the library default takes the filter kernel from 32 MiB up)."""
     if args.variant == "reftable":
         return "pfac_scan_naive"
-    if args.variant == "naive" or (args.variant == "auto" and run.n_read < (1 << 20)):
+    if args.variant == "naive" or (args.variant == "auto" and run.n_read < (32 << 20)):
         return "pfac_scan_tiled"
     return "pfac_scan_filter"
 

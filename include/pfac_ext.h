@@ -139,7 +139,7 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
                                           int *h_matched_result, int numDevices, const int *devices);
 
 /* Counters of the most recent launch of the filter kernel on this handle (PFAC_matchFromDevice / ...Reduce of
- * 1 MiB or more; SURVEY 8d, configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
+ * 32 MiB or more; SURVEY 8d, configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
  * stream.  All zero before the first such launch. */
 typedef struct {
     size_t structSize;                    /* IN: sizeof(PFACX_scan_stats_t) of the caller's header; OUT: bytes filled in (see PFACX_info_t) */

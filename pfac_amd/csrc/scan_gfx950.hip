@@ -1857,7 +1857,10 @@ hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
  * runs one persistent 1024-thread block per CU, groups of kTiledTilesBig KiB per wave, and every LDS byte the waves'
  * buffers leave as hot table rows; a small call runs 256-thread blocks, 1 KiB per wave, with the initial state's row
  * only (filling LDS is what a call of a few KiB pays for). */
-constexpr size_t kTiledBigBytes = size_t(2) << 20;
+#ifndef PFAC_TILED_BIG_MIB
+#define PFAC_TILED_BIG_MIB 8                    /* 2 MiB: 10.8 us through the small shape, 21.6 through the big one; 4 MiB 18.5 / 22.2; 8 MiB 28.4 / 23.1 */
+#endif
+constexpr size_t kTiledBigBytes = size_t(PFAC_TILED_BIG_MIB) << 20;
 template <bool TEX>
 hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
 {
@@ -1975,10 +1978,11 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     return PFAC_STATUS_SUCCESS;
 }
 
-/* below this many positions a call takes the simple kernel alone: ~8 us + 1 us per 60 KiB instead of the filter
- * kernel's ~19 us floor (filling ~100 KiB of LDS per block; tools/small_input_latency.py: 1 MiB takes 25 us through the
- * simple kernel, 20 us through the filter kernel) */
-constexpr size_t kSmallInput = size_t(1) << 20;
+/* below this many positions a call takes the tiled kernel alone: ~8 us + what the positions cost instead of the filter
+ * kernel's ~19 us floor (filling ~100 KiB of LDS tables per block, the ring of writer and scanning waves).  On the
+ * Snort-style stream the two cross between 32 and 64 MiB (tools/small_input_latency.py: 16 MiB 29.6 / 37.7 us, 32 MiB
+ * 50.7 / 53.5, 64 MiB 88 / 79; profiles/r04_small_input_latency.txt) */
+constexpr size_t kSmallInput = size_t(32) << 20;
 
 /* Launch plan for positions [first, ownEnd) of an input of inputSize readable bytes:
  *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 64 bytes inside the input

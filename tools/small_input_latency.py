@@ -7,11 +7,12 @@ cfg = wl.make_config("c3"); f = tempfile.mktemp(); wl.write_pattern_file(f, cfg.
 h = api.PFAC.create(); h.setPerfMode(cfg.perf_mode); h.readPatternFromFile(f)
 for variant, vname in ((api.PFACX_KERNEL_AUTO, "auto"), (api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive")):
   h.setKernelVariant(variant)
-  for n in (4096, 65536, 256 << 10, 512 << 10, 768 << 10, 1 << 20, 4 << 20, 16 << 20):
+  for n in [int(x) << 10 for x in os.environ.get('PFAC_LAT_KIB', '4,64,256,512,768,1024,4096,16384').split(',')]:
       d_in = torch.from_numpy(cfg.input_slice(n, 0).copy()).to("cuda:0"); d_out = torch.empty(n, dtype=torch.int32, device="cuda:0")
       for _ in range(5): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
       torch.cuda.synchronize()
+      reps = 200 if n <= (16 << 20) else 20
       t0 = time.perf_counter()
-      for _ in range(200): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+      for _ in range(reps): h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
       t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-      print(vname, "n=%9d: %.1f us per call (host-side enqueue %.1f us), %.2f GB/s" % (n, (t2 - t0) / 200 * 1e6, (t1 - t0) / 200 * 1e6, n * 200 / (t2 - t0) / 1e9))
+      print(vname, "n=%9d: %.1f us per call (host-side enqueue %.1f us), %.2f GB/s" % (n, (t2 - t0) / reps * 1e6, (t1 - t0) / reps * 1e6, n * reps / (t2 - t0) / 1e9))

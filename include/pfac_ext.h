@@ -92,6 +92,8 @@ typedef enum {
     PFACX_TABLE_FILTER_SHORT = 5,  /* uint32[2048] (65536 bits)                     */
     PFACX_TABLE_FILTER_LADDER = 6, /* uint32[2^filterLog2BitsLadder / 32]           */
     PFACX_TABLE_FILTER_FINAL3 = 7, /* uint32[2^filterLog2BitsFinal3 / 32]           */
+    PFACX_TABLE_FILTER_GRAM1 = 9,  /* uint32[2^19 / 32]: one-bit 3-gram bitmap of the compacted-output kernel       */
+    PFACX_TABLE_FILTER_PREFIX4 = 10, /* uint32[2^17 / 32]: the 4-byte pattern prefixes, two probes (same kernel)    */
     PFACX_TABLE_CHAIN        = 8   /* uint32[4] per slot: the device-only chained form of the hashed table that the
                                       filter kernel walks in both perf modes (slot i = reference hashValPtr[i]; then
                                       the 256 slots of the initial state; the last 2^chainJumpLog2 slots are the

@@ -29,6 +29,7 @@ PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
+PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4 = 9, 10
 
 
 class STATUS:

@@ -415,6 +415,40 @@ void buildFilter(const Automaton &fa, Filter &f)
     f.bitsSet = f.bitsSetLad = 0;
     for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
     for (uint32_t w : f.ladder) f.bitsSetLad += (size_t)__builtin_popcount(w);
+    buildReduceFilter(fa, f);
+}
+
+/* gram1 and prefix4 (struct Filter): the compacted-output kernel's level 1 -- every 3-byte prefix of a pattern, and every
+ * 3-gram that begins with a pattern of one or two bytes -- and its depth-4 test -- every 4-byte prefix.  Derived from the
+ * trie and shortBits alone (a compiled set on disk does not carry them). */
+void buildReduceFilter(const Automaton &fa, Filter &f)
+{
+    f.gram1.assign((size_t(1) << kGram1Log2) / 32, 0);
+    f.prefix4.assign((size_t(1) << kPrefix4Log2) / 32, 0);
+    const int init = fa.initialState;
+    if (fa.numStates <= init) return;
+    auto setGram1 = [&](uint32_t key3) { f.gram1[gram1Word(key3)] |= 1u << gram1Bit(key3); };
+    for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
+        const int s1 = fa.edgeNext[e1];
+        for (int e2 = fa.edgeBegin[s1]; e2 < fa.edgeBegin[s1 + 1]; e2++) {
+            const int s2 = fa.edgeNext[e2];
+            for (int e3 = fa.edgeBegin[s2]; e3 < fa.edgeBegin[s2 + 1]; e3++) {
+                const uint32_t key3 = (uint32_t)fa.edgeCh[e1] | ((uint32_t)fa.edgeCh[e2] << 8) | ((uint32_t)fa.edgeCh[e3] << 16);
+                setGram1(key3);
+                const int s3 = fa.edgeNext[e3];
+                for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++) {
+                    const uint32_t h = ladderStart(key3 | ((uint32_t)fa.edgeCh[e4] << 24));
+                    const uint32_t b1 = prefix4Bit1(h), b2 = prefix4Bit2(h);
+                    f.prefix4[b1 >> 5] |= 1u << (b1 & 31);
+                    f.prefix4[b2 >> 5] |= 1u << (b2 & 31);
+                }
+            }
+        }
+    }
+    if (f.hasShort && f.shortBits.size() == 65536 / 32)
+        for (uint32_t key2 = 0; key2 < 65536; key2++)
+            if ((f.shortBits[key2 >> 5] >> (key2 & 31)) & 1u)
+                for (uint32_t c2 = 0; c2 < 256; c2++) setGram1(key2 | (c2 << 16));
 }
 
 } // namespace pfac

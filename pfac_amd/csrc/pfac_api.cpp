@@ -78,6 +78,8 @@ void freeResources(PFAC_context *c)
     devFree(c->d_gram3);
     devFree(c->d_shortBits);
     devFree(c->d_ladder);
+    devFree(c->d_gram1);
+    devFree(c->d_prefix4);
     devFree(c->d_workCounters);
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
@@ -192,6 +194,8 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_shortBits, c->filter.shortBits.data(), c->filter.shortBits.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_ladder, c->filter.ladder.data(), c->filter.ladder.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram1, c->filter.gram1.data(), c->filter.gram1.size());
+    if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_prefix4, c->filter.prefix4.data(), c->filter.prefix4.size());
     if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
         const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
         st = upload(c->d_workCounters, zeros.data(), zeros.size());
@@ -839,6 +843,8 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         if (handle->d_ladder) dev += handle->filter.ladder.size() * sizeof(uint32_t);
         if (handle->d_final3) dev += handle->filter.final3.size() * sizeof(uint32_t);
         if (handle->d_shortBits) dev += handle->filter.shortBits.size() * sizeof(uint32_t);
+        if (handle->d_gram1) dev += handle->filter.gram1.size() * sizeof(uint32_t);
+        if (handle->d_prefix4) dev += handle->filter.prefix4.size() * sizeof(uint32_t);
         if (handle->d_workCounters) dev += pfac::kWorkCounterWords * sizeof(unsigned int);
         v.deviceTableBytes = dev;
     }
@@ -874,6 +880,10 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.ladder.data(); *bytes = handle->filter.ladder.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_FINAL3:
         *ptr = handle->filter.final3.data(); *bytes = handle->filter.final3.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_GRAM1:
+        *ptr = handle->filter.gram1.data(); *bytes = handle->filter.gram1.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_PREFIX4:
+        *ptr = handle->filter.prefix4.data(); *bytes = handle->filter.prefix4.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
         if (handle->h_chainSlots.empty()) {
             const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */
@@ -1104,6 +1114,7 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     c->filter = std::move(f);
     c->isPatternsReady = true;
     pfac::buildInitialRow(c->fa, c->h_initialRow);
+    try { pfac::buildReduceFilter(c->fa, c->filter); } catch (const std::bad_alloc &) { freeResources(c); return PFAC_STATUS_ALLOC_FAILED; }
     PFAC_status_t st = bindCommon(c, /*build=*/false);
     if (st == PFAC_STATUS_SUCCESS) st = bindTable(c);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(c); return st; }

@@ -120,7 +120,14 @@ struct Filter {
     std::vector<uint32_t> ladder;             /* 2^log2BitsLad bits                              */
     std::vector<uint32_t> final3;             /* 2^log2BitsF3 bits, 3-byte patterns              */
     std::vector<uint32_t> shortBits;          /* 65536 bits, index c0 | c1<<8                    */
+    /* The compacted-output kernel is bound by instruction issue and tests no ladder level behind depth 4, so it has its
+     * own pair of bitmaps in the LDS the ladder would take: gram1, a ONE-bit 3-gram filter of kGram1Log2 bits (as few
+     * positions pass as through the two-bit gram3 of half the size, for two instructions less per position), and
+     * prefix4, the trie's depth-4 nodes alone (two probes; what that kernel's level-4 test needs of the ladder). */
+    std::vector<uint32_t> gram1;              /* 2^kGram1Log2 bits */
+    std::vector<uint32_t> prefix4;            /* 2^kPrefix4Log2 bits */
 };
+constexpr int kGram1Log2 = 19, kPrefix4Log2 = 17;
 
 /* the ladder's hash: h(4) = (first four bytes, little endian) * kLadMul0; h(d) = (h(d-2) ^ (bytes d-2, d-1 as a 16-bit
  * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
@@ -147,6 +154,15 @@ constexpr uint32_t kGram3Mul = 0x8B92C5u;     /* 24-bit odd multiplier of the 3-
 inline uint32_t gram3Word(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits); }
 inline uint32_t gram3Bit1(uint32_t key24) { return key24 & 31u; }
 inline uint32_t gram3Bit2(uint32_t key24) { return (key24 >> 8) & 31u; }
+/* gram1: the dword from bits 18..31 of the 24 x 24 -> 32 bit product (the kernel gets its byte address with ONE instruction,
+ * an AND of the product's high half with 0xFFFC: SDWA), the bit from the low five bits of the gram's first byte (the
+ * implicit mod-32 of a shift by the gram itself) */
+inline uint32_t gram1Word(uint32_t key24) { return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> 18) & ((1u << (kGram1Log2 - 5)) - 1u); }
+inline uint32_t gram1Bit(uint32_t key24) { return key24 & 31u; }
+/* prefix4: keyed by the ladder's hash of the first four bytes, h = ladderStart(first4): bits h >> (32 - kPrefix4Log2) and
+ * (h * kLadMulS) >> (32 - kPrefix4Log2) */
+inline uint32_t prefix4Bit1(uint32_t h) { return h >> (32 - kPrefix4Log2); }
+inline uint32_t prefix4Bit2(uint32_t h) { return (uint32_t)(h * kLadMulS) >> (32 - kPrefix4Log2); }
 constexpr uint32_t kJumpMul = 0x9E3779B1u;    /* jump table of the chained walker (tables.cpp): slot of a 4-byte prefix */
 constexpr int kJumpLog2Min = 10, kJumpLog2Max = 20;
 inline uint32_t jumpHash(uint32_t key32, int log2Slots) { return (uint32_t)(key32 * kJumpMul) >> (32 - log2Slots); }
@@ -182,6 +198,7 @@ struct PFAC_context {
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_ladder = nullptr;
+    uint32_t *d_gram1 = nullptr, *d_prefix4 = nullptr;   /* the compacted-output kernel's level 1 and depth-4 test (struct Filter) */
     /* grow-only scratch of the compacted-output path (the arrays the pairs are ordered through), owned by the handle so that a
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;

@@ -13,6 +13,7 @@ PFAC_status_t compilePatternFile(const char *filename, Automaton &fa, unsigned i
 PFAC_status_t compilePatternBytes(std::vector<unsigned char> bytes, Automaton &fa, unsigned int flags = 0);   /* flags: PFACX_READ_* */
 void buildInitialRow(const Automaton &fa, std::vector<int> &row);
 void buildFilter(const Automaton &fa, Filter &f);
+void buildReduceFilter(const Automaton &fa, Filter &f);     /* gram1 + prefix4 alone (buildFilter calls it; a compiled set is loaded without them) */
 
 /* tables.cpp */
 PFAC_status_t buildDenseTable(const Automaton &fa, std::vector<int> &dense);

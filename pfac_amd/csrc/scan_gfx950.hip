@@ -119,6 +119,8 @@ constexpr int kBlockThreads = PFAC_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kTileBytes = 1024;              /* input bytes one wave-wide 16 B/lane load covers */
 constexpr uint32_t kLadderLdsOffset = (uint32_t)pfac::kGram3LdsBytes;  /* LDS: [0, 32 KiB) the level-1 bitmap (at most 2^18 bits), then the prefix ladder */
+/* ... of the compacted-output kernel: [0, 16 KiB) the 4-byte prefixes, [16, 80 KiB) its one-bit level-1 bitmap (pfac_context.h: gram1, prefix4) */
+constexpr uint32_t kPrefix4LdsBytes = (1u << pfac::kPrefix4Log2) / 8, kGram1LdsOffset = kPrefix4LdsBytes, kGram1LdsBytes = (1u << pfac::kGram1Log2) / 8;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -142,6 +144,7 @@ struct ScanArgs {
                                                           breadth first) are copied to LDS by every block */
     const int *initialRow;
     const uint32_t *gram3;
+    const uint32_t *gram1, *prefix4;                   /* compacted-output kernel: its level 1 and depth-4 test */
     const uint32_t *ladder;
     const uint32_t *final3;
     const uint32_t *shortBits;
@@ -521,12 +524,9 @@ constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more
 #ifndef PFAC_REDUCE_PARTS
 #define PFAC_REDUCE_PARTS 32                    /* claim counters of the compacted-output kernel (its waves claim granules of chunks themselves) */
 #endif
-#ifndef PFAC_REDUCE_LADDER_LEVELS
-#define PFAC_REDUCE_LADDER_LEVELS 0            /* ladder levels behind depth 4 that the compacted-output kernel tests (8 = all of them): that kernel is bound by
-                                                * instruction issue, not by the memory system, and there a walk is cheaper than the levels that would spare it
-                                                * (C3 0.97 / 0.96 / 0.93 / 0.90 ms per call with 8 / 4 / 2 / 0 levels, C5 1.37 / 1.28 / 1.22 / 1.16) */
-#endif
-constexpr int kReduceLadderLevels = PFAC_REDUCE_LADDER_LEVELS;
+/* The compacted-output kernel tests no ladder level behind depth 4: it is bound by instruction issue, not by the memory system,
+ * and there a walk is cheaper than the levels that would spare it (round 3: C3 0.97 / 0.96 / 0.93 / 0.90 ms per call with 8 / 4 /
+ * 2 / 0 levels, C5 1.37 / 1.28 / 1.22 / 1.16).  Its LDS holds gram1 and prefix4 (pfac_context.h) instead of gram3 and the ladder. */
 #ifndef PFAC_APPEND_MIN
 #define PFAC_APPEND_MIN 48                     /* a ladder / append batch that the walk queue's room cuts short takes at least this many candidates (or waits
                                                 * for room): on walk-bound input the queue is always nearly full and batches of 16 cost as many instructions as
@@ -616,7 +616,7 @@ void pfac_scan_filter(ScanArgs a)
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *sLadder = sGram3 + kLadderLdsOffset / 4;          /* at a compile-time address whatever the size of the level-1 bitmap: a ladder probe's
                                                                   ds_read takes it as its immediate offset */
-    uint32_t *sFinal3 = sLadder + wordsLad;
+    uint32_t *sFinal3 = REDUCE ? sGram3 + (kGram1LdsOffset + kGram1LdsBytes) / 4 : sLadder + wordsLad;
     uint32_t *sShort = sFinal3 + wordsF3;
     constexpr int kWriters = REDUCE ? 0 : PFAC_WRITERS;             /* the compacted-output variant has no zeros to write */
     constexpr int kScanners = REDUCE ? kReduceScanners : kWavesPerBlock - kWriters;
@@ -638,8 +638,13 @@ void pfac_scan_filter(ScanArgs a)
             u32x4 *s = reinterpret_cast<u32x4 *>(dst);
             for (int i = tid; i < words / 4; i += kBlockThreads) s[i] = g[i];
         };
-        copy16(sGram3, a.gram3, words3);
-        copy16(sLadder, a.ladder, wordsLad);
+        if (REDUCE) {
+            copy16(sGram3, a.prefix4, (int)(kPrefix4LdsBytes / 4));
+            copy16(sGram3 + kGram1LdsOffset / 4, a.gram1, (int)(kGram1LdsBytes / 4));
+        } else {
+            copy16(sGram3, a.gram3, words3);
+            copy16(sLadder, a.ladder, wordsLad);
+        }
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
@@ -1013,7 +1018,7 @@ void pfac_scan_filter(ScanArgs a)
      * issues at ~0.6 of the rate of the same instruction on vector registers (tools/valu_probe2.hip: v_lshrrev
      * 1.10 vs 1.78 ns, v_mul_u32_u24 1.76 vs 2.03 ns per wave and SIMD), and these two run 2048 times per chunk */
     uint32_t vShift3, vGram3Mul;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(lds.shift3));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(REDUCE ? 0xFFFCu : lds.shift3));      /* compacted-output kernel: the address mask of gram1 */
     asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     bool freshChunk = false;                    /* level 1 of the staged chunk has just run: `hits` holds all of its hits */
@@ -1133,15 +1138,25 @@ void pfac_scan_filter(ScanArgs a)
                              * the 48-bit product -- one v_mul_hi_u32_u24 and an AND -- would save an instruction, but the first byte of
                              * the gram hardly reaches it: level-1 hits went from 5 % to 18 % of the text stream.) */
                             const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
-                            word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
+                            if (REDUCE) {
+                                /* gram1: byte address of the dword = bits 18..31 of the product, times four = the product's high half
+                                 * AND 0xFFFC -- one SDWA instruction (a shift and an AND otherwise) */
+                                uint32_t addr;
+                                asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(product), "v"(vShift3));
+                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(addr + kGram1LdsOffset);
+                            } else {
+                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
+                            }
                             xs[q] = x;
                         }
                         /* the second bit of a 3-gram is numbered by the low five bits of its SECOND byte: the first byte of the
                          * next position -- whose gram (or whose raw dword) is at hand, no shift needed */
                         xs[kBatch] = b0 + kBatch < 16 ? dw[(b0 + kBatch) >> 2] : nxtLane;
 #pragma unroll
-                        for (int q = 0; q < kBatch; q++)
-                            hits = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> (xs[q + 1] & 31u)), hits, 1);   /* both bits set: bit 0 enters at the top */
+                        for (int q = 0; q < kBatch; q++) {
+                            if (REDUCE) hits = __builtin_amdgcn_alignbit(word[q] >> (xs[q] & 31u), hits, 1);    /* one bit per 3-gram */
+                            else hits = __builtin_amdgcn_alignbit((word[q] >> (xs[q] & 31u)) & (word[q] >> (xs[q + 1] & 31u)), hits, 1);   /* both bits set: bit 0 enters at the top */
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1204,8 +1219,18 @@ void pfac_scan_filter(ScanArgs a)
                 const uint32_t at = o >> 2, sh = o & 3u;
                 const uint32_t x = __builtin_amdgcn_alignbyte(stage[at + 1], stage[at], sh);
                 const uint32_t h = x * pfac::kLadMul0;
-                const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS) & 1u;
-                const uint32_t gHit = ladProbe(h * pfac::kLadMulG) & ladProbe(h * pfac::kLadMulG2) & 1u;
+                uint32_t sHit, gHit;
+                if (REDUCE) {                                      /* every 4-byte pattern prefix walks: prefix4, two probes (LDS address 0) */
+                    auto probe4 = [&](uint32_t v) -> uint32_t {
+                        const uint32_t idx = v >> (32 - pfac::kPrefix4Log2);
+                        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((idx >> 3) & ~3u) >> (idx & 31u);
+                    };
+                    sHit = probe4(h) & probe4(h * pfac::kLadMulS) & 1u;
+                    gHit = 0;
+                } else {
+                    sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS) & 1u;
+                    gHit = ladProbe(h * pfac::kLadMulG) & ladProbe(h * pfac::kLadMulG2) & 1u;
+                }
                 uint32_t decided = sHit | (testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3) &
                                            testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul2) >> lds.shiftF3));
                 if (HAS_SHORT) decided |= testBit(sShort, x & 0xFFFFu);
@@ -1247,7 +1272,7 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t und0 = (uint32_t)__popcll(__ballot(und != 0));
             const bool skipLadder = !REDUCE && ladderSkip != 0;
             if (skipLadder) { ladderSkip--; walk |= und; und = 0; }
-            if (!(REDUCE && kReduceLadderLevels == 0) && __ballot(und != 0) != 0) {
+            if (!REDUCE && __ballot(und != 0) != 0) {
                 uint32_t hl[pfac::kLadderLevels];
                 hl[0] = x0 * pfac::kLadMul0;
 #pragma unroll
@@ -1257,7 +1282,6 @@ void pfac_scan_filter(ScanArgs a)
                 }
 #pragma unroll
                 for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
-                    if (REDUCE && lv > kReduceLadderLevels) break;  /* the compacted-output kernel stops early: see kReduceLadderLevels */
                     /* one early exit, in the middle: a check per level makes every level wait for the LDS reads of the one before
                      * it, and on text a batch almost always has a candidate that follows some long keyword to the last levels */
                     if (lv == 5 && __ballot(und != 0) == 0) break;
@@ -1759,12 +1783,14 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 constexpr size_t kLdsPerCu = 160 * 1024;
 constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
 constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
-static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + (kScannerLdsFull > kScannerLdsReduce ? kScannerLdsFull : kScannerLdsReduce) <= kLdsPerCu,
-              "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
+static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + kScannerLdsFull <= kLdsPerCu, "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
+static_assert(kGram1LdsOffset + kGram1LdsBytes + 1024 /* final3 */ + 8192 /* 2-byte bitmap */ + kControlWords * 4 + kScannerLdsReduce <= kLdsPerCu,
+              "compacted-output kernel: gram1 + prefix4 + final3 + short bitmap + scanning waves' buffers must fit the CU's LDS");
 
 size_t filterLdsBytes(const PFAC_context *c, bool reduce)
 {
-    size_t bytes = kLadderLdsOffset + ((size_t(1) << c->filter.log2BitsLad) + (size_t(1) << c->filter.log2BitsF3)) / 8;   /* the level-1 bitmap has its 32 KiB whatever its size */
+    size_t bytes = reduce ? (size_t)kGram1LdsOffset + kGram1LdsBytes + (size_t(1) << c->filter.log2BitsF3) / 8
+                          : kLadderLdsOffset + ((size_t(1) << c->filter.log2BitsLad) + (size_t(1) << c->filter.log2BitsF3)) / 8;   /* the level-1 bitmap has its 32 KiB whatever its size */
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
@@ -1936,7 +1962,7 @@ uint32_t clampExtent(size_t bytes) { return bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu 
 PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_string, size_t input_size,
                        int *d_matched_result, ScanArgs &a)
 {
-    if (!c->d_initialRow || !c->d_gram3 || !c->d_ladder || !c->d_final3 || !c->d_shortBits || !c->d_workCounters) return PFAC_STATUS_INTERNAL_ERROR;
+    if (!c->d_initialRow || !c->d_gram3 || !c->d_ladder || !c->d_final3 || !c->d_shortBits || !c->d_workCounters || !c->d_gram1 || !c->d_prefix4) return PFAC_STATUS_INTERNAL_ERROR;
     if (!c->d_chainSlots || c->chainJumpLog2 <= 0) return PFAC_STATUS_INTERNAL_ERROR;
     /* the reference-layout tables are on the device only while PFACX_KERNEL_REFTABLE is selected (pfac_api.cpp uploads them) */
     if (c->kernelVariant == PFACX_KERNEL_REFTABLE && (hashed ? (!c->d_hashRow || !c->d_hashVal) : !c->d_dense)) return PFAC_STATUS_INTERNAL_ERROR;
@@ -1957,6 +1983,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.chainBytes = clampExtent(c->numChainSlots * sizeof(pfac::ChainSlot));
     a.initialRow = c->d_initialRow;
     a.gram3 = c->d_gram3;
+    a.gram1 = c->d_gram1;
+    a.prefix4 = c->d_prefix4;
     a.shortBits = c->d_shortBits;
     a.ladder = c->d_ladder;
     a.final3 = c->d_final3;

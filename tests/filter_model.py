@@ -53,3 +53,31 @@ def prefilter_model(h, data):
         walk |= und & s
         und = und & go_on(hh) & ~s if depth < LADDER_LAST else und & False
     return level1, cand, walk
+
+
+def reduce_filter_model(h, data):
+    """The compacted-output kernel's filter (pfac_context.h: gram1, prefix4): (level-1 hits, positions that are walked)."""
+    info = h.info()
+    g1, p4 = h.table(api.PFACX_TABLE_FILTER_GRAM1), h.table(api.PFACX_TABLE_FILTER_PREFIX4)
+    f3, sb = h.table(api.PFACX_TABLE_FILTER_FINAL3), h.table(api.PFACX_TABLE_FILTER_SHORT)
+    assert g1.size == (1 << 19) // 32 and p4.size == (1 << 17) // 32
+    u = np.uint64
+    m32 = u(0xFFFFFFFF)
+    n = data.size
+    d = np.concatenate([data, np.zeros(8, dtype=np.uint8)]).astype(np.uint64)
+    x = d[:n] | (d[1:n + 1] << u(8)) | (d[2:n + 2] << u(16)) | (d[3:n + 3] << u(24))
+
+    def bit(bitmap, hv):
+        return ((bitmap[(hv >> u(5)).astype(np.int64)] >> (hv & u(31)).astype(np.uint32)) & 1).astype(bool)
+
+    prod = ((x & u(0xFFFFFF)) * u(GRAM3_MUL)) & m32
+    word = g1[((prod >> u(18)) & u(0x3FFF)).astype(np.int64)]          # the kernel: (product's high half) & 0xFFFC as the byte address
+    level1 = ((word >> (x & u(31)).astype(np.uint32)) & 1).astype(bool)
+    k3 = x & u(0xFFFFFF)
+    sf = u(32 - info.filterLog2BitsFinal3)
+    walk = bit(f3, ((k3 * u(FINAL3_MUL)) & m32) >> sf) & bit(f3, ((k3 * u(FINAL3_MUL2)) & m32) >> sf)
+    if info.filterHasShort:
+        walk |= bit(sb, x & u(0xFFFF))
+    hh = (x * u(LAD_MUL0)) & m32
+    walk |= bit(p4, hh >> u(32 - 17)) & bit(p4, ((hh * u(LAD_MULS)) & m32) >> u(32 - 17))
+    return level1, level1 & walk

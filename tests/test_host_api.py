@@ -183,7 +183,7 @@ def test_pattern_file_quirks(tmp_path):
     h.destroy()
 
 
-from tests.filter_model import prefilter_model       # noqa: E402
+from tests.filter_model import prefilter_model, reduce_filter_model       # noqa: E402
 
 
 def test_strict_and_crlf_readers(tmp_path):
@@ -235,6 +235,23 @@ def test_prefilter_has_no_false_negatives(workloads, oracle_results, name):
     assert info.filterLog2Bits <= 18
     lds = 32768 + ((1 << info.filterLog2BitsLadder) + (1 << info.filterLog2BitsFinal3)) // 8 + 8192 * info.filterHasShort    # level 1 has its 32 KiB whatever its size
     assert lds <= 97 * 1024, "the bitmaps share the LDS budget of the kernel (pfac_context.h: kFilterLdsBudget)"
+
+
+@pytest.mark.parametrize("name", ["c1", "ex2", "c2", "c3", "c5", "dense_hits", "binary"])
+def test_compacted_output_filter_has_no_false_negatives(workloads, oracle_results, name):
+    """The compacted-output kernel has its own level 1 (gram1: one bit per 3-gram, 64 KiB) and depth-4 test (prefix4): every
+    position with a non-zero result passes both as the kernel evaluates them, and on the Snort-style sample gram1 lets no
+    more positions through than the two-bit gram3 of half its size (within a few per cent on this 1 MiB sample; 51.9 M against 53.2 M on the 1 GiB stream)."""
+    w = workloads[name]
+    h = api.PFAC.createHostOnly()
+    h.readPatternFromFile(w.pattern_file)
+    level1, walk = reduce_filter_model(h, w.data)
+    full_level1 = prefilter_model(h, w.data)[0]
+    h.destroy()
+    hit = oracle_results[name] != 0
+    assert np.all(level1[hit]) and np.all(walk[hit])
+    if name == "c3":
+        assert level1.sum() <= 1.05 * full_level1.sum() and walk.sum() < 0.6 * level1.sum()
 
 
 def test_prefix_ladder_of_a_very_large_pattern_set(tmp_path):

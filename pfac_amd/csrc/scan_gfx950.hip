@@ -599,7 +599,10 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
 /* vector registers the compiler may use in the filter kernel, HALVED (on gfx90a and later the attribute counts a
  * unified VGPR + AGPR budget of twice its value; the kernel uses no AGPRs): v0..v117.  v119..v127 hold the chunk
  * in flight (prefetchChunk). */
-constexpr int kCompilerVgprs = 59;
+#ifndef PFAC_COMPILER_VGPRS
+#define PFAC_COMPILER_VGPRS 59                  /* (-DPFAC_COMPILER_VGPRS=48 is what tests/test_kernel_isa.py breaks the contract with: `make` then fails) */
+#endif
+constexpr int kCompilerVgprs = PFAC_COMPILER_VGPRS;
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 64 readable input bytes follow it */
 template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets>

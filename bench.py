@@ -95,6 +95,12 @@ def parse_args(argv=None):
     ap.add_argument("--worker", default=None, choices=[None, "cpu", "pmc", "rank"],
                     help="rank: be the single rank right here, no orchestrator and no child process (the form to put behind `rocprofv3 ... --`); "
                          "pmc: the same, a few launches only; cpu: the CPU-baseline process")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver's --gpus N runs): one slice of --size-mib per GPU.  strong: BASELINE config 4 as ONE workload -- "
+                         "--total-gib GiB of the stream in slices of --size-mib, dealt round-robin over the ranks (rank r scans slices r, r + N, ...: "
+                         "PFAC/test/omp_PFAC.cpp:351-355), the same total work at N = 1, 2, 4, 8")
+    ap.add_argument("--total-gib", type=int, default=8, help="--scaling strong: size of the whole stream")
+    ap.add_argument("--total-mib", type=int, default=None, help="... in MiB (small dry runs: tests/test_sharding_gloo.py)")
     ap.add_argument("--sparse-file", default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -333,33 +339,50 @@ def cpu_worker(args):
 class Run:
     """One workload on one device: handle, input slice, device buffers."""
 
-    def __init__(self, args, name, perf_mode, texture, rank, world, device, buffers=None):
+    def __init__(self, args, name, perf_mode, texture, rank, world, device, buffers=None, share=None, host_in=None):
+        """rank / world: slice `rank` of a stream of `world` slices.  share = another Run: its handle (same pattern set) and
+        its result buffer are used, only the input is this Run's own (the slices of --scaling strong)."""
         import torch
         from pfac_amd import api, sharding
         from pfac_amd import workloads as wl
         self.api, self.torch = api, torch
-        self.cfg = wl.make_config(name)
-        self.perf_mode = self.cfg.perf_mode if perf_mode is None else perf_mode
-        os.makedirs(SCRATCH, exist_ok=True)
-        self.pattern_file = wl.write_pattern_file(os.path.join(SCRATCH, f"{self.cfg.name}_rank{rank}.pat"), self.cfg.patterns)
         self.gpu = args.platform == "gpu"
-        if self.gpu:
-            self.handle = api.PFAC.create()
+        self.owner = share is None
+        if share is None:
+            self.cfg = wl.make_config(name)
+            self.perf_mode = self.cfg.perf_mode if perf_mode is None else perf_mode
+            os.makedirs(SCRATCH, exist_ok=True)
+            self.pattern_file = wl.write_pattern_file(os.path.join(SCRATCH, f"{self.cfg.name}_rank{rank}.pat"), self.cfg.patterns)
+            if self.gpu:
+                self.handle = api.PFAC.create()
+            else:
+                self.handle = api.PFAC.createHostOnly()
+                self.handle.setPlatform(api.PFAC_PLATFORM_CPU_OMP)
+            self.handle.setPerfMode(self.perf_mode)
+            self.handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[texture])
+            self.variant = {"auto": api.PFACX_KERNEL_AUTO, "filter": api.PFACX_KERNEL_FILTER, "naive": api.PFACX_KERNEL_NAIVE,
+                            "reftable": api.PFACX_KERNEL_REFTABLE}[args.variant]
+            if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
+                self.handle.setKernelVariant(self.variant)
+            self.handle.readPatternFromFile(self.pattern_file)
+            self.info = self.handle.info()
         else:
-            self.handle = api.PFAC.createHostOnly()
-            self.handle.setPlatform(api.PFAC_PLATFORM_CPU_OMP)
-        self.handle.setPerfMode(self.perf_mode)
-        self.handle.setTextureMode({"auto": api.PFAC_AUTOMATIC, "on": api.PFAC_TEXTURE_ON, "off": api.PFAC_TEXTURE_OFF}[texture])
-        self.variant = {"auto": api.PFACX_KERNEL_AUTO, "filter": api.PFACX_KERNEL_FILTER, "naive": api.PFACX_KERNEL_NAIVE,
-                        "reftable": api.PFACX_KERNEL_REFTABLE}[args.variant]
-        if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
-            self.handle.setKernelVariant(self.variant)
-        self.handle.readPatternFromFile(self.pattern_file)
-        self.info = self.handle.info()
+            self.cfg, self.perf_mode, self.pattern_file, self.handle, self.info = share.cfg, share.perf_mode, share.pattern_file, share.handle, share.info
         # slice `rank` of the N x size stream plus the head of the next slice (generators are prefix-stable)
-        self.host_in, self.n = sharding.rank_input(self.cfg, args.size_mib << 20, rank, world, self.info.maxPatternLen)
+        if host_in is None:
+            self.host_in, self.n = sharding.rank_input(self.cfg, args.size_mib << 20, rank, world, self.info.maxPatternLen)
+        else:
+            self.host_in, self.n = host_in, args.size_mib << 20
         self.n_read = self.host_in.size
-        if self.gpu:
+        if share is not None:
+            if self.gpu:
+                self.d_in = torch.from_numpy(self.host_in).to(device)
+                self.d_out = share.d_out
+                assert self.d_out.numel() >= self.n_read
+                torch.cuda.synchronize()
+            else:
+                self.h_out = share.h_out
+        elif self.gpu:
             if buffers is not None and buffers[0].numel() >= self.n_read:
                 self.d_in, self.d_out = buffers
                 self.d_in[: self.n_read].copy_(torch.from_numpy(self.host_in))
@@ -443,7 +466,91 @@ class Run:
         return st if st["walkerRounds"] else None
 
     def close(self):
-        self.handle.destroy()
+        if self.owner:
+            self.handle.destroy()
+
+
+class SliceSet:
+    """BASELINE config 4 as ONE workload (--scaling strong): the stream is `total` slices of --size-mib (slice i from seed + i,
+    scanned with the maxPatternLen + 1 bytes of its successor: omp_PFAC.cpp:324), of which this rank scans slices rank,
+    rank + world, ... (omp_PFAC.cpp:351-355: tid + k * num_threads; pfac_amd/sharding.py: rank_slices).  One handle per rank,
+    every slice's input resident in HBM, one result buffer (a slice's results are checked before the next launch overwrites
+    them: the correctness gate runs slice by slice)."""
+
+    def __init__(self, args, name, perf_mode, texture, total, rank, world, device):
+        import concurrent.futures
+        from pfac_amd import sharding
+        self.total, self.rank, self.world = total, rank, world
+        self.mine = sharding.rank_slices(total, rank, world)
+        assert self.mine, "more ranks than slices"
+        n = args.size_mib << 20
+        # the rank's handle and result buffer come with its first slice
+        owner = Run(args, name, perf_mode, texture, self.mine[0], total, device)
+        room = n + sharding.overlap_bytes(owner.info.maxPatternLen)
+        if owner.gpu and owner.d_out.numel() < room:
+            owner.d_out = owner.torch.full((room,), -1, dtype=owner.torch.int32, device=device)
+        elif not owner.gpu and owner.h_out.size < room:
+            owner.h_out = np.full(room, -1, dtype=np.int32)
+        self.owner = owner
+        self.runs, self.index = [owner], [self.mine[0]]
+        rest = self.mine[1:]
+        with concurrent.futures.ThreadPoolExecutor(4) as pool:       # the generator is C code: slices are generated side by side
+            hosts = list(pool.map(lambda i: sharding.rank_input(owner.cfg, n, i, total, owner.info.maxPatternLen)[0], rest))
+        for i, h in zip(rest, hosts):
+            self.runs.append(Run(args, name, perf_mode, texture, i, total, device, share=owner, host_in=h))
+            self.index.append(i)
+
+    def gate(self, args):
+        """every slice once, each checked against its reference digest: -> (all exact, method, matches, folded checksum)"""
+        from pfac_amd import sharding
+        ok_all, method, count, acc = True, None, 0, 0
+        for r, i in zip(self.runs, self.index):
+            r.step()
+            ok, method, pos, ids = r.verify(args, i, self.total)
+            ok_all = ok_all and ok
+            count += int(pos.size)
+            acc = (acc + sharding.position_checksum(pos, ids, base=i * r.n)) & 0xFFFFFFFFFFFFFFFF
+        return ok_all, method, count, acc
+
+    def step(self):
+        for r in self.runs:
+            r.step()
+
+    def timed(self, steps, warmup, settle, barrier=None):
+        """-> (ms per step = one pass over this rank's slices, wall seconds of the K steps)"""
+        gpu = bool(self.runs) and self.runs[0].gpu
+        for _ in range(settle + warmup):
+            self.step()
+        if gpu:
+            from pfac_amd import hiprt
+            torch = self.runs[0].torch
+            events = [(hiprt.Event(), hiprt.Event()) for _ in range(steps)]
+            torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        ms = []
+        for k in range(steps):
+            if gpu:
+                events[k][0].record(0)
+                self.step()
+                events[k][1].record(0)
+            else:
+                t1 = time.perf_counter()
+                self.step()
+                ms.append((time.perf_counter() - t1) * 1e3)
+        if gpu:
+            torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        elapsed = time.perf_counter() - t0
+        if gpu:
+            ms = [a.elapsed_ms(b) for a, b in events]
+        return ms, elapsed
+
+    def close(self):
+        for r in self.runs:
+            r.close()
 
 
 def kernel_name(args, run):
@@ -523,13 +630,14 @@ def other_configs(args, device, buffers):
     return out
 
 
-def rank_main(args):
+def setup_rank(args):
+    """Rank, device and process group of this process: -> None (refused) or (rank, world, device, use_dist, barrier, dist)"""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a number for a different rank count")
-        return 2
+        return None
     gpu = args.platform == "gpu"
 
     import torch
@@ -538,18 +646,18 @@ def rank_main(args):
     if gpu:
         if not torch.cuda.is_available():
             log("[bench] no GPU: the match path has no CPU fallback (use --platform cpu_omp --dist-backend gloo for a dry run)")
-            return 2
+            return None
         ndev = torch.cuda.device_count()
         if args.dist_backend == "gloo":
             local_rank = local_rank % ndev                       # dry run: ranks may share a device
         elif local_rank >= ndev:
             log(f"[bench] rank {rank} needs GPU {local_rank} but only {ndev} visible: --gpus {args.gpus} needs {args.gpus} GPUs")
-            return 2
+            return None
         torch.cuda.set_device(local_rank)
         device = f"cuda:{local_rank}"
     elif args.dist_backend != "gloo":
         log("[bench] --platform cpu_omp needs --dist-backend gloo")
-        return 2
+        return None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         if args.force_dist and world == 1:
@@ -562,11 +670,109 @@ def rank_main(args):
         else:
             dist.init_process_group("gloo")
 
-    from pfac_amd import sharding
-
     def barrier():
         if use_dist:
             dist.barrier()
+
+    return rank, world, device, use_dist, barrier, dist
+
+
+def strong_numbers(args, sset, ms, elapsed_max, total_matches, folded, all_ok, method, world):
+    """The facts of one --scaling strong measurement (also other_configs.c4_8gib_one_gpu of the default line)."""
+    from pfac_amd import sharding
+    n = args.size_mib << 20
+    expected = None
+    dgs = [load_digest(sset.owner.cfg.name, i, args.size_mib, last=(i == sset.total - 1)) for i in range(sset.total)]
+    if all(d is not None for d in dgs):
+        ec, es = sharding.combine_checksums([(d["match_count"], d["checksum"]) for d in dgs])
+        expected = {"match_count": ec, "checksum": es & 0x7FFFFFFFFFFFFFFF,
+                    "equal": bool(ec == total_matches and (es & 0x7FFFFFFFFFFFFFFF) == (folded & 0x7FFFFFFFFFFFFFFF))}
+        all_ok = all_ok and expected["equal"]
+    steps = len(ms)
+    per_launch = [x / len(sset.runs) for x in ms]
+    return {"total_bytes": sset.total * n, "slices": sset.total, "slice_bytes": n, "slices_of_rank0": sset.index, "steps": steps,
+            "aggregate_GBps": round(sset.total * n / (elapsed_max / steps) / 1e9, 2), "ms_per_step": round(elapsed_max / steps * 1e3, 4),
+            "kernel_ms_per_slice_avg": round(float(np.mean(per_launch)), 4),
+            "frac": round(ALGO_BYTES_PER_INPUT_BYTE * sset.runs[0].n_read / (float(np.mean(per_launch)) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+            "matches": int(total_matches), "bit_exact": bool(all_ok), "bit_exact_method": method,
+            "folded_result": {"match_count": int(total_matches), "checksum": folded & 0x7FFFFFFFFFFFFFFF}, "folded_reference": expected,
+            "note": f"BASELINE config 4 as one workload: {sset.total} slices, each scanned with the head of its successor, dealt round-robin over "
+                    f"{world} rank(s) (omp_PFAC.cpp:351-355); inputs resident in HBM, one result buffer per rank"}, all_ok
+
+
+def strong_rank_main(args):
+    """--scaling strong: the same --total-gib stream at every N (see SliceSet)."""
+    got = setup_rank(args)
+    if got is None:
+        return 2
+    rank, world, device, use_dist, barrier, dist = got
+    gpu = args.platform == "gpu"
+    from pfac_amd import sharding
+    total_mib = args.total_mib if args.total_mib else args.total_gib << 10
+    total = total_mib // args.size_mib
+    if total < world or total < 1:
+        log(f"[bench] --scaling strong: {total} slice(s) of {args.size_mib} MiB for {world} rank(s)")
+        return 2
+    t_setup = time.perf_counter()
+    perf_mode = None if args.perf_mode is None else (0 if args.perf_mode == "dense" else 1)
+    sset = SliceSet(args, args.workload, perf_mode, args.texture, total, rank, world, device)
+    log(f"[bench r{rank}] strong: slices {sset.index} of {total}, setup {time.perf_counter() - t_setup:.1f}s")
+    ok, method, count, checksum = sset.gate(args)
+    ms, elapsed = sset.timed(args.steps, args.warmup, SETTLE_STEPS if gpu else 0, barrier)
+    if not args.no_verify:                                     # the result of the last launch again (the rank's last slice)
+        last, i = sset.runs[-1], sset.index[-1]
+        ok2, _, _, _ = last.verify(args, i, total)
+        ok = ok and ok2
+    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
+                                     device=device if (gpu and args.dist_backend == "nccl") else None, force=args.force_dist)
+    elapsed_max = float(allf[:, 3].max()) / 1e9
+    total_matches, folded = sharding.combine_checksums([(int(c), int(s)) for c, s in allf[:, :2]])
+    all_ok = bool(allf[:, 2].all()) and sorted(int(r) for r in allf[:, 4]) == list(range(world))
+    rc = 0
+    if rank == 0:
+        facts, all_ok = strong_numbers(args, sset, ms, elapsed_max, total_matches, folded, all_ok, method, world)
+        info, run0 = sset.owner.info, sset.owner
+        kname = kernel_name(args, run0)
+        per_launch = [x / len(sset.runs) for x in ms]
+        out = {
+            "metric": "input GB/s scanned (PFAC_matchFromDevice, bit-exact)" if gpu else
+                      "input GB/s scanned (DRY RUN on the CPU_OMP platform, not the metric)",
+            "value": facts["aggregate_GBps"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_steps": SETTLE_STEPS if gpu else 0, "ms_per_step": facts["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": f"c4 = {run0.cfg.name}: {run0.cfg.description}; {total_mib} MiB in {total} slices of {args.size_mib} MiB "
+                            f"(overlap {sharding.overlap_bytes(info.maxPatternLen)} B) dealt round-robin over {world} GPU(s): a step is one pass over the whole stream",
+                "patterns": info.numOfPatterns, "states": info.numOfStates, "table": "hashed" if run0.perf_mode else "dense",
+                "table_bytes": int(info.sizeOfTableInBytes), "walker_table": walker_table(args, run0),
+                "texture_mode": int(run0.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname, "build": build_info(),
+                "platform": args.platform, "bytes_total": facts["total_bytes"], "slices_per_rank": len(sset.runs), "matches": facts["matches"],
+                "bit_exact": facts["bit_exact"], "bit_exact_method": method, "dist_backend": args.dist_backend if use_dist else None,
+                "folded_result": facts["folded_result"], "folded_reference": facts["folded_reference"],
+            },
+            "roofline": roofline_block(per_launch, run0.n_read, kname),
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+        if not all_ok:
+            log("[bench] RESULT NOT BIT-EXACT")
+            rc = 1
+    sset.close()
+    if use_dist:
+        dist.destroy_process_group()
+    return rc
+
+
+def rank_main(args):
+    if args.scaling == "strong":
+        return strong_rank_main(args)
+    got = setup_rank(args)
+    if got is None:
+        return 2
+    rank, world, device, use_dist, barrier, dist = got
+    gpu = args.platform == "gpu"
+    import torch
+    from pfac_amd import sharding
 
     t_setup = time.perf_counter()
     perf_mode = None if args.perf_mode is None else (0 if args.perf_mode == "dense" else 1)
@@ -785,6 +991,16 @@ def rank_main(args):
             if not args.no_other_configs:
                 buffers = (run.d_in, run.d_out)
                 out["other_configs"] = other_configs(args, device, buffers)
+                if args.workload == "c3" and args.size_mib == 1024 and args.perf_mode is None:
+                    # BASELINE config 4 (8 GiB) as ONE workload on this one GPU: what `--scaling strong --gpus 1` reports, the
+                    # N = 1 point of the 1/2/4/8 strong-scaling curve
+                    t0 = time.perf_counter()
+                    sset = SliceSet(args, "c3", None, args.texture, 8, 0, 1, device)
+                    ok4, method4, count4, sum4 = sset.gate(args)
+                    ms4, el4 = sset.timed(3, 1, 4)
+                    out["other_configs"]["c4_8gib_one_gpu"], _ = strong_numbers(args, sset, ms4, el4, count4, sum4, ok4, method4, 1)
+                    sset.close()
+                    log(f"[bench] c4_8gib_one_gpu: {out['other_configs']['c4_8gib_one_gpu']['aggregate_GBps']} GB/s ({time.perf_counter() - t0:.1f}s)")
                 if not all(e["bit_exact"] for e in out["other_configs"].values()):
                     all_ok = False
         out["cpu_baseline"] = None
@@ -816,7 +1032,7 @@ def orchestrate(args, argv):
         return 2
     os.makedirs(SCRATCH, exist_ok=True)
     n = args.gpus
-    single = n == 1 and args.platform == "gpu"
+    single = n == 1 and args.platform == "gpu" and args.scaling == "weak"      # the CPU baseline and the PMC passes belong to the headline (weak) line
     sparse_file = os.path.join(SCRATCH, f"{args.workload}_rank0_sparse.npz")
     if os.path.exists(sparse_file):
         os.remove(sparse_file)

@@ -151,3 +151,32 @@ def test_bench_spawns_the_ranks_itself_and_checks_the_reference_digests():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--platform", "cpu_omp", "--dist-backend", "gloo",
                         "--size-mib", "8", "--steps", "1", "--warmup", "0"], cwd=root, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 2 and b"refusing" in p.stderr
+
+
+def test_strong_scaling_mode_deals_the_slices_round_robin():
+    """`bench.py --scaling strong`: BASELINE config 4 as ONE workload -- the stream's 8 slices dealt round-robin over the
+    ranks (rank r scans slices r, r + N, ...: PFAC/test/omp_PFAC.cpp:351-355, pfac_amd/sharding.py rank_slices), the same total
+    work at every N.  Two ranks x four slices of the 8 x 8 MiB c3 stream on the CPU_OMP platform over gloo: every slice
+    equals its reference digest, the folded result equals the folded digests of all eight; and the same stream on one rank
+    gives the same folded result."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    folded = {}
+    for gpus in (2, 1):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--scaling", "strong", "--total-mib", "64", "--size-mib", "8",
+                            "--platform", "cpu_omp", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0", "--workload", "c3"],
+                           cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+        assert out["scaling"] == "strong" and out["n_gpus"] == gpus and out["config"]["slices_per_rank"] == 8 // gpus
+        assert out["config"]["bytes_total"] == 64 << 20
+        assert out["config"]["bit_exact"] is True and out["config"]["folded_reference"]["equal"] is True
+        assert out["config"]["folded_result"]["match_count"] == 4579 + 4590 + 4579 + 4571 + 4454 + 4655 + 4583 + 4493   # tests/golden/full_digests.json
+        folded[gpus] = out["config"]["folded_result"]
+    assert folded[1] == folded[2]
+    assert sharding.rank_slices(8, 1, 2) == [1, 3, 5, 7]

@@ -966,8 +966,10 @@ def rank_main(args):
                 t0h = time.perf_counter()
                 fill.fill(0)
                 host_path["host_zero_fill_GBps_one_thread"] = round(4 * hn / (time.perf_counter() - t0h) / 1e9, 1)
-                host_path["bound"] = "per position: 1 B over the host link + 4 B of zero fill in host memory (2-8 helper threads) + the pairs of the matches; " \
-                                     "the scan of a 32 Mi-position piece runs beside the upload of the next"
+                host_path["bound"] = "per position: 1 B over the host link + 4 B of zero fill in host memory (2-8 helper threads, streaming stores, piece by piece) " \
+                                     "+ the pairs of the matches, scattered piece by piece; the uploads are queued by a thread of their own, the scan of a " \
+                                     "32 Mi-position piece runs beside the upload of the next.  Fill and link share the host's memory channels."
+                host_path["of_the_link"] = {k: round(host_path[k]["input_GBps"] / host_path["link_h2d_GBps_pinned"], 3) for k in ("pageable", "pinned")}
                 del probe_in, fill
                 out["host_path_pcie_inclusive"] = host_path
             # What this part sustains for the traffic shape of the path with nothing else in it ("also

@@ -13,9 +13,14 @@
 #include <sched.h>
 #include <hip/hip_runtime_api.h>
 
+#include <emmintrin.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -525,6 +530,24 @@ static PFAC_status_t matchHostFullVector(PFAC_context *c, char *h_inputString, s
  * and the pairs are scattered on top at the end.  A piece in which more than one position in eight matches takes the
  * full-vector route above instead (after the zero fill, so the two never write the same words at the same time).
  */
+/* zeros without reading the lines first: streaming stores, 64 bytes per trip (the result vector of a 1 GiB call is 4 GiB
+ * that nothing reads before the caller does) */
+static void fillZeroStreaming(int *p, size_t n)
+{
+    static const bool plain = std::getenv("PFAC_HOST_FILL_MEMSET") != nullptr;
+    if (plain) { std::memset(p, 0, n * sizeof(int)); return; }
+    while (n && (reinterpret_cast<uintptr_t>(p) & 63u)) { *p++ = 0; n--; }
+    const __m128i z = _mm_setzero_si128();
+    for (; n >= 16; n -= 16, p += 16) {
+        _mm_stream_si128(reinterpret_cast<__m128i *>(p), z);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(p + 4), z);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(p + 8), z);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(p + 12), z);
+    }
+    while (n) { *p++ = 0; n--; }
+    _mm_sfence();
+}
+
 PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
 {
     if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
@@ -535,29 +558,6 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
     correctTextureMode(c);
     PFAC_reduce_kernel_protoType reduce = c->perfMode == PFAC_TIME_DRIVEN ? c->reduce_kernel_ptr : c->reduce_inplace_kernel_ptr;
     hipStream_t up = static_cast<hipStream_t>(c->stageUp);
-
-    /* zero fill of the caller's vector, in parallel with everything below */
-    unsigned helpers = 0;
-    if (owned >= (size_t(4) << 20)) {
-        unsigned hw = std::thread::hardware_concurrency();
-        cpu_set_t allowed;                                 /* the cores this thread may run on (a caller bound to a cpuset: fewer than the machine has) */
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) hw = (unsigned)CPU_COUNT(&allowed);
-        helpers = hw >= 64 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
-    }
-    std::vector<std::thread> fillers;
-    try {
-        fillers.reserve(helpers);
-        for (unsigned t = 0; t < helpers; t++) {
-            const size_t lo = owned * t / helpers, hi = owned * (t + 1) / helpers;
-            fillers.emplace_back([=]() { std::memset(h_matched_result + lo, 0, (hi - lo) * sizeof(int)); });
-        }
-    } catch (...) { /* no memory for the vector, or fewer threads than planned: what the helpers started do not cover is filled below */ }
-    const size_t filledByHelpers = fillers.empty() ? 0 : owned * fillers.size() / helpers;
-    auto joinAll = [&]() { for (std::thread &t : fillers) if (t.joinable()) t.join(); };
-
-    struct Found { size_t off; std::vector<int> pos, id; };
-    std::vector<Found> found;
-    std::vector<size_t> densePieces;
     const size_t numPieces = (owned + piece - 1) / piece;
     auto uploadPiece = [&](size_t i) -> bool {               /* into buffer i & 1, on the upload stream */
         const size_t off = i * piece;
@@ -566,47 +566,138 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
         return hipMemcpyAsync(c->d_stageIn[i & 1], h_inputString + off, scanned, hipMemcpyHostToDevice, up) == hipSuccess &&
                hipEventRecord(static_cast<hipEvent_t>(c->evUp[i & 1]), up) == hipSuccess;
     };
+    /* the link first: nothing below is worth a microsecond of an idle copy engine */
+    const bool trace = std::getenv("PFAC_HOST_TRACE") != nullptr;
+    const auto tStart = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count(); };
+    /* The uploads are queued by a thread of their own: hipMemcpyAsync from PAGEABLE memory does not return until the runtime
+     * has staged the piece (0.6 ms for 32 MiB), and this thread has the scans to launch and their pairs to fetch meanwhile.
+     * Piece i goes into buffer i & 1 once the scan of piece i - 2 is over. */
+    std::atomic<size_t> scansDone{0}, uploadsQueued{0};
+    std::atomic<bool> uploadFailed{false}, stopUploads{false};
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::thread uploader;
+    bool ok = true;
     try {
-        found.reserve(numPieces);
-        bool ok = uploadPiece(0);
+        uploader = std::thread([&]() {
+            if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
+            for (size_t i = 0; i < numPieces; i++) {
+                while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
+                if (stopUploads.load(std::memory_order_relaxed)) return;
+                if (!uploadPiece(i)) { uploadFailed.store(true); return; }
+                uploadsQueued.store(i + 1, std::memory_order_release);
+            }
+        });
+    } catch (...) { ok = false; }
+    const double tUp0 = since();
+
+    /* Zero fill of the caller's vector, in parallel with everything below: 4 bytes of host memory per position against 1 byte
+     * over the link, so it takes a few threads -- sized from the cores this thread may run on (a caller bound to a cpuset has
+     * fewer than the machine) up to 8: the fill and the link's reads share the host's memory channels, and beyond eight
+     * threads the upload loses more than the fill gains (256 MiB from pinned buffers on a 2 x 64-core box, link 54 GB/s:
+     * 47.0 / 48.8 / 43.8 / 43.3 / 46.4 GB/s with 4 / 8 / 12 / 16 / 24 threads; memset instead of streaming stores: 24.7) --
+     * streaming stores, and the pieces IN ORDER, every thread its share of each: the pairs of piece k are scattered as soon
+     * as they are back, while piece k + 1 uploads, not in one pass at the end.  (PFAC_HOST_FILL_THREADS overrides the count:
+     * a measurement aid.) */
+    unsigned helpers = 0;
+    if (owned >= (size_t(4) << 20)) {
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t allowed;
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) hw = (unsigned)CPU_COUNT(&allowed);
+        helpers = hw >= 64 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
+        if (const char *e = std::getenv("PFAC_HOST_FILL_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) helpers = (unsigned)v; }
+    }
+    auto share = [&](size_t k, unsigned t, unsigned of, size_t &lo, size_t &hi) {          /* thread t's part of piece k */
+        const size_t off = k * piece, mine = owned - off < piece ? owned - off : piece;
+        lo = off + mine * t / of / 16 * 16;
+        hi = t + 1 == of ? off + mine : off + mine * (t + 1) / of / 16 * 16;
+    };
+    std::unique_ptr<std::atomic<unsigned>[]> filled;
+    std::vector<std::thread> fillers;
+    try {
+        filled.reset(new std::atomic<unsigned>[numPieces]);
+        for (size_t k = 0; k < numPieces; k++) filled[k].store(0, std::memory_order_relaxed);
+        fillers.reserve(helpers);
+        for (unsigned t = 0; t < helpers; t++)
+            fillers.emplace_back([&, t]() {
+                for (size_t k = 0; k < numPieces; k++) {
+                    size_t lo, hi;
+                    share(k, t, helpers, lo, hi);
+                    fillZeroStreaming(h_matched_result + lo, hi - lo);
+                    filled[k].fetch_add(1, std::memory_order_release);
+                }
+            });
+    } catch (...) { /* no memory, or fewer threads than planned: the shares nobody started are filled by this thread, below */ }
+    if (!filled) {                                             /* not even the counters: no helper was started */
+        std::memset(h_matched_result, 0, owned * sizeof(int));
+        helpers = 0;
+    }
+    const unsigned started = (unsigned)fillers.size();
+    const double tThreads = since();
+    auto joinAll = [&]() { for (std::thread &t : fillers) if (t.joinable()) t.join(); };
+    /* piece k of the caller's vector is all zeros when this returns */
+    auto waitFilled = [&](size_t k) {
+        if (!filled) return;
+        if (helpers == 0) {                                    /* a small call: this thread fills, piece by piece */
+            size_t lo, hi;
+            share(k, 0, 1, lo, hi);
+            if (filled[k].load(std::memory_order_relaxed) == 0) { std::memset(h_matched_result + lo, 0, (hi - lo) * sizeof(int)); filled[k].store(1, std::memory_order_relaxed); }
+            return;
+        }
+        if (filled[k].load(std::memory_order_relaxed) < helpers) {
+            for (unsigned t = started; t < helpers; t++) {          /* the shares of threads that could not be started */
+                size_t lo, hi;
+                share(k, t, helpers, lo, hi);
+                fillZeroStreaming(h_matched_result + lo, hi - lo);
+            }
+            while (filled[k].load(std::memory_order_acquire) < started) std::this_thread::yield();
+            filled[k].store(helpers, std::memory_order_relaxed);
+        }
+    };
+
+    std::vector<int> pos, id;                                  /* the pairs of one piece */
+    std::vector<size_t> densePieces;
+    try {
         for (size_t i = 0; i < numPieces && ok && st == PFAC_STATUS_SUCCESS; i++) {
             const int b = (int)(i & 1);
             const size_t off = i * piece;
             const size_t mine = owned - off < piece ? owned - off : piece;
             const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
-            /* the scan of piece i - 1 (synchronous, below) is over: its input buffer may take piece i + 1 */
-            if (i + 1 < numPieces) ok = uploadPiece(i + 1);
-            ok = ok && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
+            while (uploadsQueued.load(std::memory_order_acquire) <= i && !uploadFailed.load(std::memory_order_relaxed)) std::this_thread::yield();
+            ok = !uploadFailed.load(std::memory_order_relaxed) && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
             if (!ok) break;
             int count = 0;
             c->reduceUnordered = true;
             st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)scanned, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
             c->reduceUnordered = false;
             if (st != PFAC_STATUS_SUCCESS) break;
+            scansDone.store(i + 1, std::memory_order_release);     /* the scan is synchronous: its input buffer may take piece i + 2 */
             if ((size_t)count > mine / 8) { densePieces.push_back(i); continue; }
-            Found f;
-            f.off = off;
-            f.pos.resize((size_t)count);
-            f.id.resize((size_t)count);
-            if (count && (hipMemcpy(f.pos.data(), c->d_stagePos[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
-                          hipMemcpy(f.id.data(), c->d_stageOut[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)) {
+            pos.resize((size_t)count);
+            id.resize((size_t)count);
+            if (count && (hipMemcpy(pos.data(), c->d_stagePos[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                          hipMemcpy(id.data(), c->d_stageOut[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)) {
                 ok = false;
                 break;
             }
-            found.push_back(std::move(f));
+            waitFilled(i);                                     /* long done, as a rule: the fill runs ahead of the link */
+            for (size_t k = 0; k < pos.size(); k++)
+                if ((size_t)pos[k] < mine) h_matched_result[off + (size_t)pos[k]] = id[k];   /* beyond: the next piece's (or nobody's) */
         }
         if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
+    stopUploads.store(true);
+    if (uploader.joinable()) uploader.join();
+    const double tLoop = since();
     const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
     if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
-    if (filledByHelpers < owned) std::memset(h_matched_result + filledByHelpers, 0, (owned - filledByHelpers) * sizeof(int));
+    const double tDrained = since();
+    for (size_t k = 0; k < numPieces; k++) waitFilled(k);      /* every element of the caller's vector is written, whatever happened */
     joinAll();
+    if (trace) std::fprintf(stderr, "PFAC_HOST_TRACE %zu B %zu pieces %u helpers: first upload queued %.3f ms, threads started %.3f, piece loop done %.3f, drained %.3f, filled+joined %.3f\n",
+                            owned, numPieces, started, tUp0, tThreads, tLoop, tDrained, since());
     if (st != PFAC_STATUS_SUCCESS) return st;
-    for (const Found &f : found) {
-        const size_t mine = owned - f.off < piece ? owned - f.off : piece;
-        for (size_t k = 0; k < f.pos.size(); k++)
-            if ((size_t)f.pos[k] < mine) h_matched_result[f.off + (size_t)f.pos[k]] = f.id[k];   /* beyond: the next piece's (or nobody's) */
-    }
     for (size_t i : densePieces) {
         const size_t off = i * piece;
         const size_t mine = owned - off < piece ? owned - off : piece;

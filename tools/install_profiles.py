@@ -9,8 +9,18 @@ for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json
              ("bench_c5_dense.json", "bench_c5_dense.json"), ("bench_c5_hashed.json", "bench_c5_hashed.json"),
              ("bench_c3_naive.json", "bench_c3_naive_kernel.json"), ("bench_c2_naive.json", "bench_c2_naive_kernel.json"),
              ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json"),
-             ("bench_c3_2ranks_one_gpu_gloo.json", "bench_c3_2ranks_one_gpu_gloo.json")):
-    cp(a, b)
+             ("bench_c3_2ranks_one_gpu_gloo.json", "bench_c3_2ranks_one_gpu_gloo.json"),
+             ("bench_c5_naive.json", "bench_c5_naive_kernel.json"), ("bench_c4_strong_one_gpu.json", "bench_c4_strong_one_gpu.json"),
+             (os.path.join("traffic_c5", "summary.json"), "hbm_traffic_c5.json")):
+    if os.path.exists(os.path.join(src, a)):
+        cp(a, b)
+with open(os.path.join("profiles", f"{tag}_pmc_instruction_counts.txt"), "w") as out:
+    out.write("# rocprofv3 --pmc (tools/pmc_run.py over tools/reduce_driver.py: 4 calls of PFAC_matchFromDeviceReduce on the 1 GiB stream), per-launch means of the\n"
+              "# compacted-output scan kernel pfac_scan_filter<..., REDUCE = true, 2>; counters are summed over the 8 XCDs (GRBM_GUI_ACTIVE / 8 = cycles)\n")
+    for w in ("c3", "c5"):
+        f = os.path.join(src, f"pmc_reduce_{w}.txt")
+        if os.path.exists(f):
+            out.write(f"== {w}\n" + open(f).read() + "\n")
 for w in ("c3", "c2"):
     rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
     keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "pfac_order" in r[0] or "fillBuffer" in r[0]]

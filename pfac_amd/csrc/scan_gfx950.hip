@@ -36,8 +36,8 @@
  *      for it.
  *   2. LIST.  The lanes' hits become one list of 16-bit codes (prefix sum of the hit
  *      counts, one divergent loop).  A chunk in which more than 90 % of the positions
- *      hit is not listed: it goes on the launch's dense list, and the simple kernel
- *      behind this launch walks its positions one per thread.
+ *      hit is not listed: it goes on the launch's dense list, and the tiled kernel
+ *      behind this launch walks its positions in place (its dense mode).
  *   3. LEVEL-4 TEST, one hit per lane: the first four bytes against level 4 of the
  *      prefix ladder (+ length-3 bitmap, + exact 2-byte bitmap); survivors stay in the
  *      list, compacted in place.
@@ -78,10 +78,14 @@
  *   along in the same launch (ScanArgs::endsIn): scanning waves of the first blocks walk
  *   them with bounds (boundedWalk) before they start scanning.  A call is ONE launch of
  *   this kernel -- no memset in front (the last block out leaves the launch counters
- *   zero and publishes the statistics) -- plus a launch of pfac_scan_naive that looks at
- *   the dense list (empty: it leaves at once).  pfac_scan_naive (one thread per byte,
- *   reference-layout tables) also serves calls of less than 1 MiB and is the independent
- *   second implementation the tests cross-check against.
+ *   zero and publishes the statistics) -- plus a launch of pfac_scan_tiled that looks at
+ *   the dense list (empty: it leaves at once).
+ *
+ *   pfac_scan_tiled (further down) is the kernel of calls below 32 MiB, of PFACX_KERNEL_NAIVE and of
+ *   those dense chunks: one position per thread slot, a group of tiles + halo and the hottest
+ *   transition rows in LDS, coalesced result lines.  pfac_scan_naive (one thread per byte through the
+ *   reference-layout tables, PFACX_KERNEL_REFTABLE) is the reference-shaped baseline and the
+ *   independent second implementation the tests cross-check against; it is on no default path.
  *   No MFMA: nothing here is a contraction.
  */
 #if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
@@ -131,7 +135,7 @@ struct ScanArgs {
     const unsigned char *in;
     int *out;
     size_t n;                                          /* filter kernel: owned = readable bytes handled here (whole chunks); naive: readable bytes */
-    size_t owned;                                      /* naive kernel: positions [0, owned) get a result */
+    size_t owned;                                      /* tiled / naive kernel: positions [0, owned) get a result */
     const int *dense;
     const Int2 *hashRow;
     const Int2 *hashVal;
@@ -157,7 +161,7 @@ struct ScanArgs {
     unsigned int *reduceCount;
     unsigned int reduceBase;                           /* position of a.in[0] inside the caller's stream */
     /* pattern-dense chunks (full-result path): the filter kernel lists the chunks in which most positions pass level 1
-     * instead of filtering them; the simple kernel that follows it (the launch that also scans the end of the input)
+     * instead of filtering them; the tiled kernel that follows it
      * walks their positions one per thread.  denseIn / denseOut / denseReadable describe the filter launch the chunk
      * numbers refer to.  The list's length is a.work[kDenseCountWord]; a wave appends 8 chunks at a time (one device
      * counter answers ~90 atomics per microsecond: an append per chunk cost 1.5 ms for 256 MiB of pattern-dense input). */
@@ -289,7 +293,7 @@ __device__ __forceinline__ u32x4 loadWindow16(const uint32_t *in32, uint32_t pos
  * What is scarce on pattern-dense input is gathered loads, then instruction issue:
  * a step is written as straight-line selects (every early `return` costs exec-mask bookkeeping for
  * the whole wave), positions are 32-bit, and nothing checks a bound -- the launcher hands the last
- * maxPatternLen + 64 bytes of the input to the simple kernel, so a walk that starts in this kernel's
+ * maxPatternLen + 64 bytes of the input to bounds-checked walks (ScanArgs::endsIn), so a walk that starts in this kernel's
  * range can neither run past the input nor load past it.
  *
  * Both table modes walk the CHAINED table (tables.cpp: buildChainedHashTable): a device-only copy of the
@@ -1191,7 +1195,7 @@ void pfac_scan_filter(ScanArgs a)
             if (dense) {
                 /* a pattern-dense chunk (most positions pass level 1: patterns of one or two bytes over text, a run of
                  * one byte that is a pattern): listing, testing and queueing every position costs more than walking them
-                 * all.  The chunk goes on the launch's dense list and the simple kernel behind this one does it. */
+                 * all.  The chunk goes on the launch's dense list and the tiled kernel behind this one does it. */
                 if (lane == 0) sDense[nDense] = stagedBase / (uint32_t)kChunkBytes;
                 nDense++;
                 if (nDense == kDenseStage) flushDense();
@@ -1376,7 +1380,7 @@ void pfac_scan_filter(ScanArgs a)
 #endif
 }
 
-/* ---------------------------------------------------------- naive kernel */
+/* ------------------------------------------- reference-shaped kernel (PFACX_KERNEL_REFTABLE) */
 
 /* One thread per input byte, no prefilter: the reference's algorithm with only the initial-state row
  * staged in LDS.  Alignment-agnostic, 64-bit positions.  Produces results for positions [0, owned);
@@ -2019,7 +2023,7 @@ constexpr size_t kSmallInput = size_t(32) << 20;
  *   [first, first + mainLen)   filter kernel: whole chunks whose walks stay >= 64 bytes inside the input
  *                              (a walk is at most maxPatternLen deep, a window load reads <= 35 bytes on, the
  *                              prefetch of a chunk the 64 bytes behind it)
- *   [first + mainLen, ownEnd)  simple kernel (bounds-checked byte loads): the end of the input
+ *   [first + mainLen, ownEnd)  bounds-checked walks inside the same launch (ScanArgs::endsIn): the end of the input
  * (`first` is the first 16-byte aligned input byte: scan() and reduceScan() peel the positions in front of it) */
 size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
 {
@@ -2037,7 +2041,7 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
 constexpr size_t kMaxLaunchBytes = (size_t(1) << 32) - (size_t(1) << 24);
 
 /* The filter kernel reads the input 16 bytes per lane: it starts at the first 16-byte aligned input byte.  The (at most
- * 15) positions in front of it go to the simple kernel, like the end of the input.  The result vector needs no alignment
+ * 15) positions in front of it are walked with bounds, like the end of the input.  The result vector needs no alignment
  * beyond that of an int (its 16-byte stores then straddle lines; a 1 KiB-per-instruction stream does not care). */
 size_t headPositions(const unsigned char *in, size_t input_size)
 {
@@ -2067,7 +2071,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
     const PFAC_status_t st = fillArgs(c, hashed, d_input_string, input_size, d_matched_result, a);
     if (st != PFAC_STATUS_SUCCESS) return st;
     const bool tex = (c->textureMode == PFAC_TEXTURE_ON);
-    const bool vectorOk = (reinterpret_cast<uintptr_t>(a.out) & 3u) == 0;       /* an int vector that is not int-aligned: simple kernel only */
+    const bool vectorOk = (reinterpret_cast<uintptr_t>(a.out) & 3u) == 0;       /* an int vector that is not int-aligned: tiled kernel only */
     hipError_t e = hipSuccess;
     const size_t head = vectorOk ? headPositions(a.in, input_size) : 0;
     bool headDone = head == 0;
@@ -2078,7 +2082,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
         part.in = a.in + first;
         part.out = a.out + first;
         if (mainLen) {
-            /* room for the list of pattern-dense chunks this launch may leave to the simple kernel: a grow-only buffer of
+            /* room for the list of pattern-dense chunks this launch may leave to the tiled kernel: a grow-only buffer of
              * the handle (the caller holds its lock) */
             const size_t chunks = mainLen / kChunkBytesHost;
             if (handle->denseListEntries < chunks) {
@@ -2123,7 +2127,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             }
 #endif
         } else {
-            /* no filter launch (a small call, PFACX_KERNEL_NAIVE, an odd result pointer): the simple kernel does it all */
+            /* no filter launch (a small call, PFACX_KERNEL_NAIVE / REFTABLE, an odd result pointer): the tiled (or reference-shaped) kernel does it all */
             const size_t back = headDone ? 0 : head;
             ScanArgs rest = part;
             rest.in = part.in - back;
@@ -2429,7 +2433,7 @@ struct PairOrder {
  * Same kernel as the full-result path with REDUCE = true: no zero stores (the 4 B/byte output wall
  * is gone, traffic is ~1 B per input byte), finished walkers append (id, position) through one
  * device counter.  The ends of the input (ScanArgs::endsIn) are walked with bounds by the first blocks of the same
- * launch and join the list through the same counter (a small input: the simple kernel appends).  The list is then put in position
+ * launch and join the list through the same counter (a small input: the tiled kernel appends).  The list is then put in position
  * order (PairOrder) by launches queued behind the scan; the host reads the count once, at the end (synchronous, like
  * the reference's call).
  * The reference needs a block-local compaction, a Thrust scan and a second gather kernel
@@ -2472,7 +2476,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         part.endsB1 = (uint32_t)n;
         if (launchChained<true>(c, part, tex) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     } else {
-        /* a small input (or PFACX_KERNEL_NAIVE): positions [0, n) through the simple kernel, which appends its matches to the list */
+        /* a small input (or PFACX_KERNEL_NAIVE / REFTABLE): positions [0, n) through the tiled (reference-shaped) kernel, which appends its matches to the list */
         ScanArgs part = a;
         part.owned = n;
         part.reduceBase = 0;

@@ -375,6 +375,125 @@ def test_compiled_set_round_trip_on_the_host(workloads, oracle_results, tmp_path
     b.destroy()
 
 
+def _fnv1a64(b):
+    h = 0xcbf29ce484222325
+    for x in b:
+        h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _sections(payload):
+    """[(tag, offset of the data, bytes)] of a compiled set's payload (tag u32, size u64, data)"""
+    out, at = [], 0
+    while at + 12 <= len(payload):
+        tag = int.from_bytes(payload[at:at + 4], "little")
+        size = int.from_bytes(payload[at + 4:at + 12], "little")
+        out.append((tag, at + 12, size))
+        at += 12 + size
+    return out
+
+
+def test_crafted_compiled_sets_with_a_valid_checksum_are_refused(workloads, oracle_results, tmp_path):
+    """The checksum of a compiled set is FNV-1a: anyone can recompute it.  So nothing a kernel indexes memory with is taken from
+    the file -- every transition table is rebuilt from the trie at load -- and the trie itself is checked to BE one: a file
+    whose edges form a cycle (a walk that never ends would run past the margin the kernels keep behind the input), point at
+    the initial state, carry the same byte twice, or put a final state at the wrong depth is PFAC_STATUS_INVALID_PARAMETER,
+    checksum recomputed or not.  Files of format 6 (tables inside) are refused by their version."""
+    w = workloads["c3"]
+    a = api.PFAC.createHostOnly()
+    a.setPerfMode(api.PFAC_SPACE_DRIVEN)
+    a.readPatternFromFile(w.pattern_file)
+    path = str(tmp_path / "set.pfacx")
+    a.saveCompiled(path)
+    raw = bytearray(open(path, "rb").read())
+    head, payload = raw[:40], raw[40:]                             # magic 8, version / fingerprint / perfMode / jumpLog2 4 x 4, payload bytes 8, FNV 8
+    assert int.from_bytes(head[8:12], "little") == 7 and int.from_bytes(head[24:32], "little") == len(payload)
+    secs = {tag: (off, size) for tag, off, size in _sections(payload)}
+    assert 14 not in secs and 15 not in secs and 16 not in secs    # kSecHashRow, kSecHashVal, kSecChain: no transition table in the file
+    off_next, size_next = secs[8]                                  # kSecEdgeNext
+    off_ch, _ = secs[7]                                            # kSecEdgeCh
+    off_begin, _ = secs[6]                                         # kSecEdgeBegin
+    info = a.info()
+    begin = np.frombuffer(bytes(payload[off_begin:off_begin + 4 * (info.numOfStates + 1)]), dtype=np.int32)
+    nxt = np.frombuffer(bytes(payload[off_next:off_next + size_next]), dtype=np.int32)
+    init = info.initialState
+    e0 = int(begin[init])                                          # first edge of the initial state
+    child = int(nxt[e0])
+    grand_edge = int(begin[child])                                 # first edge of that child
+
+    def crafted(mutate):
+        p2 = bytearray(payload)
+        mutate(p2)
+        h2 = bytearray(head)
+        h2[32:40] = _fnv1a64(bytes(p2)).to_bytes(8, "little")
+        out = str(tmp_path / "crafted.pfacx")
+        open(out, "wb").write(bytes(h2) + bytes(p2))
+        return out
+
+    def set_next(p2, edge, state):
+        p2[off_next + 4 * edge:off_next + 4 * edge + 4] = int(state).to_bytes(4, "little", signed=True)
+
+    b = api.PFAC.createHostOnly()
+    b.readPatternFromFile(workloads["c1"].pattern_file)            # what must survive every refused load
+    before = b.match_host_array(workloads["c1"].data)
+    cases = {
+        "a cycle: the child's first edge leads back to the child": lambda p2: set_next(p2, grand_edge, child),
+        "an edge into the initial state": lambda p2: set_next(p2, grand_edge, init),
+        "two edges into one state": lambda p2: set_next(p2, e0 + 1, child),
+        "the same byte twice in one state": lambda p2: p2.__setitem__(off_ch + e0 + 1, p2[off_ch + e0]),
+        "a state number beyond the trie": lambda p2: set_next(p2, grand_edge, info.numOfStates + 5),
+    }
+    for what, mutate in cases.items():
+        assert b.loadCompiled(crafted(mutate), check=False) == api.STATUS.INVALID_PARAMETER, what
+        assert np.array_equal(b.match_host_array(workloads["c1"].data), before), what
+    # the untouched payload with its checksum recomputed loads, and matches like the set it was saved from
+    assert b.loadCompiled(crafted(lambda p2: None), check=False) == api.STATUS.SUCCESS
+    assert np.array_equal(b.match_host_array(w.data), oracle_results["c3"])
+    assert b.info().trailingBytesIgnored == a.info().trailingBytesIgnored
+    # an older format is refused by its version number
+    old = bytearray(raw)
+    old[8:12] = (6).to_bytes(4, "little")
+    open(path, "wb").write(bytes(old))
+    assert b.loadCompiled(path, check=False) == api.STATUS.INVALID_PARAMETER
+    a.destroy()
+    b.destroy()
+
+
+def test_trailing_bytes_survive_a_compiled_set(tmp_path):
+    """A pattern file whose last line has no newline: the bytes are ignored like in the reference, PFACX_getInfo says how many,
+    and a set compiled from it says the same after PFACX_saveCompiled / PFACX_loadCompiled (format 7 stores the count)."""
+    p = tmp_path / "trail.pat"
+    p.write_bytes(b"alpha\nbeta\ngamm")
+    a = api.PFAC.createHostOnly()
+    a.readPatternFromFile(str(p))
+    assert a.info().numOfPatterns == 2 and a.info().trailingBytesIgnored == 4
+    f = str(tmp_path / "trail.pfacx")
+    a.saveCompiled(f)
+    b = api.PFAC.createHostOnly()
+    b.loadCompiled(f)
+    assert b.info().trailingBytesIgnored == 4 and b.info().numOfPatterns == 2
+    a.destroy()
+    b.destroy()
+
+
+def test_info_struct_is_versioned_by_its_size():
+    """PFACX_info_t / PFACX_scan_stats_t carry their size: a caller built against an older, shorter header is never written past,
+    a caller that forgot to set the size is refused."""
+    import ctypes as C
+    h = api.PFAC.createHostOnly()
+    lib = api.load_library()
+    info = api.PFACX_info()
+    assert lib.PFACX_getInfo(h._h, C.byref(info)) == api.STATUS.INVALID_PARAMETER          # structSize == 0
+    buf = (C.c_ubyte * C.sizeof(api.PFACX_info))(*([0xAB] * C.sizeof(api.PFACX_info)))
+    short = C.cast(buf, C.POINTER(api.PFACX_info))
+    short.contents.structSize = 48                                  # "an older header": the first 48 bytes only
+    assert lib.PFACX_getInfo(h._h, short) == api.STATUS.SUCCESS
+    assert short.contents.structSize == 48 and all(x == 0xAB for x in bytes(buf)[48:])
+    full = h.info()
+    assert full.structSize == C.sizeof(api.PFACX_info) and full.deviceTableBytes == 0 and full.hasDevice == 0
+    h.destroy()
+
+
 def test_sparse_fnv_equals_the_full_vector_fnv():
     """workloads.fnv1a_sparse_i32 (used to pin 4 GiB result vectors from their sparse form) == FNV-1a-64 of the vector."""
     from oracle import binding as ob

@@ -1,6 +1,6 @@
 """tools/stress_calls.py [calls] [seed] -- one handle, many calls of changing shape: random slices (any alignment, 1 byte ..
 48 MiB) of one 64 MiB Snort-style buffer through PFAC_matchFromDevice and PFAC_matchFromDeviceReduce in random order, every
-result against the simple kernel's (a second handle with PFACX_KERNEL_NAIVE: the independent implementation) on the same
+result against the reference-shaped kernel's (a second handle with PFACX_KERNEL_REFTABLE: the independent implementation) on the same
 slice.  What it is after: state that one launch leaves for the next (launch counters left zero by the last block out,
 the two dense-chunk counters, the ordering scratch)."""
 import os, sys
@@ -27,7 +27,7 @@ def handle(variant):
     return h
 
 
-a, b = handle(api.PFACX_KERNEL_AUTO), handle(api.PFACX_KERNEL_NAIVE)
+a, b = handle(api.PFACX_KERNEL_AUTO), handle(api.PFACX_KERNEL_REFTABLE)
 d_out = torch.empty(N + 16, dtype=torch.int32, device="cuda:0")
 d_ref = torch.empty(N + 16, dtype=torch.int32, device="cuda:0")
 d_res = torch.empty(N, dtype=torch.int32, device="cuda:0")

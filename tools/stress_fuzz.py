@@ -26,7 +26,7 @@ for seed in range(first, first + count):
         pats.add(b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), ln)))
     pats = sorted(pats, key=lambda p: (rng.random(), p))
     pf = wl.write_pattern_file(os.path.join(work, f"s{seed}.pat"), pats)
-    n = int(rng.integers(1 << 20, 6 << 20))                 # above 1 MiB: the filter kernel, not the simple one
+    n = int(rng.integers(1 << 20, 6 << 20))
     skew = rng.random(len(alphabet)) ** 3 + 0.01
     idx = rng.choice(len(alphabet), size=n, p=skew / skew.sum())
     data = np.frombuffer(b"".join(alphabet), dtype=np.uint8)[idx].copy()
@@ -41,16 +41,24 @@ for seed in range(first, first + count):
     for perf, tex in MODES:
         h = api.PFAC.create()
         h.setPerfMode(perf); h.setTextureMode(tex); h.readPatternFromFile(pf)
-        h.setKernelVariant(api.PFACX_KERNEL_FILTER)
         try:
-            for rep in range(3):
-                d_out = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
-                h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
-                got = d_out.cpu().numpy()
-                if not np.array_equal(got, want):
-                    w = np.nonzero(got != want)[0]
-                    print(f"MISMATCH seed {seed} mode {perf}/{tex} rep {rep}: {w.size} positions, first {w[0]} got {got[w[0]]} want {want[w[0]]}", flush=True)
-                    bad += 1
+            for variant, reps in ((api.PFACX_KERNEL_NAIVE, 2), (api.PFACX_KERNEL_FILTER, 3)):       # the tiled kernel alone, then the filter kernel (+ its dense chunks through the tiled one)
+                h.setKernelVariant(variant)
+                for rep in range(reps):
+                    d_out = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                    h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+                    got = d_out.cpu().numpy()
+                    if not np.array_equal(got, want):
+                        w = np.nonzero(got != want)[0]
+                        print(f"MISMATCH seed {seed} mode {perf}/{tex} variant {variant} rep {rep}: {w.size} positions, first {w[0]} got {got[w[0]]} want {want[w[0]]}", flush=True)
+                        bad += 1
+                if variant == api.PFACX_KERNEL_NAIVE:                                                 # compacted output through the tiled kernel too
+                    d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                    d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+                    st, cnt = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+                    if not (cnt == nz.size and np.array_equal(d_pos[:cnt].cpu().numpy(), nz) and np.array_equal(d_res[:cnt].cpu().numpy(), want[nz])):
+                        print(f"REDUCE MISMATCH (tiled) seed {seed} mode {perf}/{tex}", flush=True)
+                        bad += 1
             d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
             d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
             st, cnt = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())

@@ -128,8 +128,11 @@ def test_misaligned_pointers_stay_on_the_vector_kernel(workdir, capsys):
     """The reference casts the input to int* (PFAC_kernel.cu:203) and asks for a padded buffer (PFAC.cpp:838-842); this
     library takes any pointer.  Round 2 sent a call whose pointers were not 16-byte aligned to the simple kernel as a
     whole (18 times slower); now only the <= 15 positions in front of the first aligned input byte go there.  64 MiB of
-    the Snort-style stream at several input / result offsets: results equal the aligned call's (itself checked against
-    the oracle on its first MiB) and the rate stays within a fifth of it."""
+    the Snort-style stream at several input / result offsets: results equal the aligned call's and the rate stays within a
+    fifth of it.
+    ANCHOR: this is a HIP-vs-HIP comparison at 64 MiB (the aligned call of the same handle is the expected value); what ties
+    it to the reference is that aligned call's first MiB against the oracle, plus test_full_size_result_equals_reference_digest
+    (the same stream, aligned, whole 1 GiB vector == SHA-256 of the reference's output)."""
     from oracle import binding as ob
     from pfac_amd import hiprt
     cfg = wl.make_config("c3")
@@ -186,9 +189,11 @@ def test_compacted_output_is_in_position_order_at_every_bin_shape(workdir, n, ev
     the input size (64 positions ... 32 Ki positions), a bin with more than 64 pairs is ranked through a bitmap in LDS.
     Inputs with crowded stretches (one position in eight matches) between sparse ones, at sizes that take every bin
     width class -- and crowded everywhere: more pairs than the handle's scratch holds on a first call, the launches leave
-    and are queued again behind a larger one; expected = the non-zero entries of the full result of the same handle (itself checked against the
-    oracle in test_gpu_parity.py), which is the reference's definition of the compacted output
-    (PFAC_reduce_kernel.cu:417-457: a stable compaction of the full result)."""
+    and are queued again behind a larger one.
+    ANCHOR: HIP-vs-HIP at these sizes -- expected = the non-zero entries of the FULL result of the same handle, which is the
+    reference's definition of the compacted output (PFAC_reduce_kernel.cu:417-457: a stable compaction of the full result);
+    the full-result path is what test_gpu_parity.py / test_gpu_round2.py pin on the oracle and the reference digests, and the
+    patterns here are planted ones whose matches can be counted by hand (one per 'h', ...)."""
     pats = [b"h", b"ab", b"abc", b"gfe", b"mnop", b"xyzzy", b"qq", b"nopqrstu"]
     pf = wl.write_pattern_file(os.path.join(workdir, f"order{n}.pat"), pats)
     g = torch.Generator(device="cuda:0")

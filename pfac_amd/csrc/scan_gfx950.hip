@@ -1465,7 +1465,10 @@ constexpr uint32_t kTiledList = 256;                   /* 16-bit codes of surviv
 constexpr int kTiledWalks = PFAC_TILED_WALKS;          /* independent walks per lane */
 constexpr int kTiledTilesBig = PFAC_TILED_TILES;       /* tiles per group: launches with megabytes in front of them */
 constexpr uint32_t kTiledFar = 0x40000000u;            /* "the input ends nowhere near this group" */
-constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2; }   /* stage, list */
+/* per wave: stage, list and -- the one-tile shape of small calls -- the tile's results: there a call is as long as its slowest wave, and
+ * a patch that has to wait until the zeros are in L2 is on that path (4 KiB call 8.3 -> 7.2 us); the big shape hides the wait behind
+ * fifteen other waves and spends the LDS on hot rows */
+constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + (tiles == 1 ? kTiledTile * 4 : 0); }
 
 template <bool TEX, int WALKS, int TILES, bool HOTALL>
 __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
@@ -1488,6 +1491,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     unsigned char *waveBase = reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + wave * tiledWaveLds(TILES);
     uint32_t *stage = reinterpret_cast<uint32_t *>(waveBase);
     uint16_t *list = reinterpret_cast<uint16_t *>(waveBase + kStage);
+    constexpr bool kLdsResults = TILES == 1;               /* a sparse group's results are assembled in LDS and stored once, as whole lines */
+    int *res = reinterpret_cast<int *>(waveBase + kStage + kTiledList * 2);
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
     {
         const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.gram3);
@@ -1689,7 +1694,10 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
          * lines, nothing read; they are 80 % of the call's traffic -- and the few walks that end in a match overwrite theirs */
         if (!reduce) {
             const i32x4 zero = {0, 0, 0, 0};
-            if (whole) {
+            if (kLdsResults) {
+#pragma unroll
+                for (int k = 0; k < 4 * TILES; k++) reinterpret_cast<i32x4 *>(res)[k * 64 + lane] = zero;
+            } else if (whole) {
 #pragma unroll
                 for (int k = 0; k < 4 * TILES; k++)
                     if ((uint32_t)k * 256u < hi) __builtin_nontemporal_store(zero, reinterpret_cast<i32x4 *>(outGroup) + k * 64 + lane);
@@ -1739,14 +1747,31 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #pragma unroll
                     for (int k = 0; k < WALKS; k++) found |= match[k] != 0;
                     if (__ballot(found) != 0) {                /* one position in two thousand matches on the Snort-style stream: most sets store nothing */
-                        /* every load of these walks has been consumed; the wait is for the zero stores of a group none of whose
-                         * walks left LDS (vmcnt counts vector memory in issue order on gfx9): the zero is in L2 before its patch */
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (kLdsResults) {
 #pragma unroll
-                        for (int k = 0; k < WALKS; k++)
-                            if (match[k] != 0) outGroup[o[k]] = match[k];
+                            for (int k = 0; k < WALKS; k++)
+                                if (match[k] != 0) res[o[k]] = match[k];
+                        } else {
+                            /* every load of these walks has been consumed; the wait is for the zero stores of a group none of whose
+                             * walks left LDS (vmcnt counts vector memory in issue order on gfx9): the zero is in L2 before its patch */
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int k = 0; k < WALKS; k++)
+                                if (match[k] != 0) outGroup[o[k]] = match[k];
+                        }
                     }
                 }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        if (kLdsResults && !reduce) {                          /* the tile's results, whole lines */
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 4 * TILES; k++)
+                    if ((uint32_t)k * 256u < hi) __builtin_nontemporal_store(reinterpret_cast<const i32x4 *>(res)[k * 64 + lane], reinterpret_cast<i32x4 *>(outGroup) + k * 64 + lane);
+            } else {
+                for (uint32_t p = lo + (uint32_t)lane; p < hi; p += 64u) outGroup[p] = res[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
@@ -1899,7 +1924,10 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
 {
     auto kernelBig = pfac_scan_tiled<TEX, kTiledWalks, kTiledTilesBig, false>;
     auto kernelBigHot = pfac_scan_tiled<TEX, kTiledWalks, kTiledTilesBig, true>;     /* every bucket of the table fits the CU's LDS: no global path in the step */
-    auto kernelSmall = pfac_scan_tiled<TEX, kTiledWalks, 1, false>;
+#ifndef PFAC_TILED_WALKS_SMALL
+#define PFAC_TILED_WALKS_SMALL 2
+#endif
+    auto kernelSmall = pfac_scan_tiled<TEX, PFAC_TILED_WALKS_SMALL, 1, false>;
     static ShapeCache cache;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);

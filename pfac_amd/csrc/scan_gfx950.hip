@@ -1475,6 +1475,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 {
     constexpr uint32_t kGroup = (uint32_t)TILES * kTiledTile, kStage = kGroup + kTiledHalo;
     static_assert(kGroup <= 4096, "a position's code is 12 bits of offset in 16");
+    static_assert(kTiledList >= 64u * (uint32_t)TILES, "dense mode parks the lanes' hit masks in the list's place");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool listMode = a.denseList != nullptr;
     unsigned int listed = 0;

@@ -1508,6 +1508,10 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     const uint32_t shift3 = 35u - (uint32_t)a.log2Bits;
     const uint32_t hot = a.hotSlots;
     const bool reduce = a.reducePos != nullptr;
+#ifndef PFAC_TILED_STATS
+#define PFAC_TILED_STATS 0                     /* measurement build: wave-wide step iterations, live lane-steps, walks, passes, dense groups */
+#endif
+    uint32_t tsIter = 0, tsLane = 0, tsWalks = 0, tsPasses = 0, tsDense = 0, tsGroups = 0;
 
     /* One group: g16 = its 16-byte aligned first byte; `span` bytes from there may be loaded (a multiple of 16: up to the
      * end of the 16-byte block that holds the last input byte); positions [lo, hi) of the group get a result, written to
@@ -1611,6 +1615,11 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             {   /* first transition: the initial state's row, in LDS, indexed by the byte itself */
                 u32x4 s[WALKS];
                 uint32_t w0[WALKS], w1[WALKS];
+#if PFAC_TILED_STATS
+                tsIter++;
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) { const uint32_t c = (uint32_t)__popcll(__ballot(alive[k])); tsLane += c; tsWalks += c; }
+#endif
 #pragma unroll
                 for (int k = 0; k < WALKS; k++) {
                     q[k] = o[k]; match[k] = 0; row[k] = 0; ks[k] = 0;
@@ -1625,6 +1634,11 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #pragma unroll
                 for (int k = 0; k < WALKS; k++) any |= alive[k];
                 if (__ballot(any) == 0) break;                 /* every walk of the wave is in the dead state (or matched at a leaf) */
+#if PFAC_TILED_STATS
+                tsIter++;
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) tsLane += (uint32_t)__popcll(__ballot(alive[k]));
+#endif
                 u32x4 s[WALKS];
                 uint32_t w0[WALKS], w1[WALKS];
 #pragma unroll
@@ -1661,6 +1675,10 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #pragma unroll
         for (int t = 0; t < TILES; t++) cnt += (uint32_t)__builtin_popcount(hits[t]);
         const uint32_t survivors = (uint32_t)__builtin_amdgcn_readlane((int)waveInclusiveScan(cnt), 63);
+#if PFAC_TILED_STATS
+        tsGroups++;
+        if (survivors * 2u >= hi - lo) tsDense++;
+#endif
         if (survivors * 2u >= hi - lo) {
             /* ---- DENSE group (half of its positions or more survive: short patterns over text, runs of a pattern byte):
              * compaction would cost more than idle lanes.  Position p = 256 r + 64 k + lane walks in round r, walk k: the
@@ -1729,6 +1747,9 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                 }
             }
             const uint32_t listedNow = total < kTiledList ? total : kTiledList;
+#if PFAC_TILED_STATS
+            tsPasses++;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (uint32_t base = 0; base < listedNow; base += 64u * (uint32_t)WALKS) {
@@ -1807,6 +1828,15 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             scanGroup(a.denseIn + T, spanAll - T, 0u, kTake, limit, a.denseOut + T, 0u);
         }
     }
+#if PFAC_TILED_STATS
+    if (lane == 0) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 26;   /* behind the PFAC_TIMING words */
+        atomicAdd(acc + 0, (unsigned long long)tsIter); atomicAdd(acc + 1, (unsigned long long)tsLane); atomicAdd(acc + 2, (unsigned long long)tsWalks);
+        atomicAdd(acc + 3, (unsigned long long)tsPasses); atomicAdd(acc + 4, (unsigned long long)tsDense); atomicAdd(acc + 5, (unsigned long long)tsGroups);
+    }
+#else
+    (void)tsIter; (void)tsLane; (void)tsWalks; (void)tsPasses; (void)tsDense; (void)tsGroups;
+#endif
 }
 
 /* ------------------------------------------------------------- launching */
@@ -1963,9 +1993,21 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
     if (a.denseList != nullptr || blocks > (big ? cus : cus * 16)) blocks = big ? cus : cus * 16;
     if (blocks < 1) blocks = 1;
     const size_t lds = fixed + hot * sizeof(pfac::ChainSlot);
+#if PFAC_TILED_STATS
+    (void)hipMemsetAsync(c->d_workCounters + pfac::kStatsWord + 52, 0, 6 * sizeof(unsigned long long), 0);
+#endif
     if (big && hot == a.rootRow) hipLaunchKernelGGL(kernelBigHot, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
     else if (big) hipLaunchKernelGGL(kernelBig, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
     else hipLaunchKernelGGL(kernelSmall, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+#if PFAC_TILED_STATS
+    {
+        unsigned long long t[6];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(t, c->d_workCounters + pfac::kStatsWord + 52, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "PFAC_TILED_STATS owned %zu: groups %llu (dense %llu) passes %llu walks %llu wave-steps %llu live lane-steps %llu: %.2f steps per walk, %.1f live lanes per wave-step of %d\n",
+                a.owned, t[5], t[4], t[3], t[2], t[0], t[1], t[2] ? (double)t[1] / t[2] : 0.0, t[0] ? (double)t[1] / t[0] : 0.0, 64 * kTiledWalks);
+    }
+#endif
     return hipGetLastError();
 }
 

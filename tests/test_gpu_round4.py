@@ -133,3 +133,36 @@ def test_reference_layout_tables_exist_on_the_device_only_on_request(workdir):
         assert h.table(api.PFACX_TABLE_DENSE).size == 256 * info.numOfStates     # the host copy: built on first use
     finally:
         h.destroy()
+
+
+@pytest.mark.parametrize("perf,tex,mode_name", [MODES[1], MODES[2]])
+def test_tiled_kernel_with_every_bucket_in_lds(workdir, perf, tex, mode_name):
+    """A pattern set whose whole chained table fits the CU's LDS takes the HOTALL instance of the tiled kernel's big shape (no
+    global path in a walk step): the README's four patterns plus a few longer ones over 24 MiB of text in which they occur
+    sparsely, and over a stretch in which they occur at every position (dense groups), full and compacted output."""
+    from oracle import binding as ob
+    rng = np.random.Generator(np.random.PCG64(77))
+    pats = [b"AB", b"ABG", b"BEDE", b"ED", b"GATTACA", b"EDEDEDEDEDEDEDEDED", b"ABGABGAB"]
+    pf = wl.write_pattern_file(os.path.join(workdir, "tiny.pat"), pats)
+    n = (24 << 20) + 333
+    alpha = np.frombuffer(b"ABCDEGT", dtype=np.uint8)
+    data = np.frombuffer(b"xyzw", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    for at in rng.integers(0, n - 64, 20000):                      # sparse occurrences
+        k = int(rng.integers(4, 40))
+        data[at:at + k] = alpha[rng.integers(0, alpha.size, k)]
+    data[5 << 20:(5 << 20) + 300000] = np.frombuffer(b"ED", dtype=np.uint8)[np.arange(300000) % 2]   # dense: a match at every position
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    h = make_handle(pf, perf, tex, api.PFACX_KERNEL_NAIVE)
+    try:
+        assert_same(device_match(h, data), want, f"hotall / {mode_name}")
+        assert_same(device_match(h, data, in_offset=9, out_offset=1), want, f"hotall / {mode_name} / misaligned")
+        d_in = torch.from_numpy(data).to("cuda:0")
+        d_res = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+        d_pos = torch.full((n,), -5, dtype=torch.int32, device="cuda:0")
+        _, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+        pos = np.flatnonzero(want)
+        assert count == pos.size and np.array_equal(d_pos[:count].cpu().numpy(), pos) and np.array_equal(d_res[:count].cpu().numpy(), want[pos])
+    finally:
+        h.destroy()

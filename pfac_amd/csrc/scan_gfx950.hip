@@ -1627,7 +1627,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                     if (alive[k]) { fetch(q[k], w0[k], w1[k]); s[k] = sRoot[w0[k] & 0xFFu]; }
                 }
 #pragma unroll
-                for (int k = 0; k < WALKS; k++) step(k, s[k], w0[k], w1[k]);
+                for (int k = 0; k < WALKS; k++)
+                    if (__ballot(alive[k]) != 0) step(k, s[k], w0[k], w1[k]);      /* a walk set nobody is in costs a branch */
             }
             for (;;) {
                 bool any = false;
@@ -1653,7 +1654,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < WALKS; k++) step(k, s[k], w0[k], w1[k]);
+                for (int k = 0; k < WALKS; k++)
+                    if (__ballot(alive[k]) != 0) step(k, s[k], w0[k], w1[k]);
             }
         };
         /* compacted output: the matches of a walk set join the pair list, one atomic per set */

@@ -606,10 +606,17 @@ def other_configs(args, device, buffers):
     c2 with texture mode on and off, c5 with the dense and the hashed table."""
     from pfac_amd import api
     out = {}
-    todo = [("c2_texture_on", "c2", None, "on"), ("c2_texture_off", "c2", None, "off"),
-            ("c5_dense", "c5", api.PFAC_TIME_DRIVEN, "auto"), ("c5_hashed", "c5", api.PFAC_SPACE_DRIVEN, "auto")]
-    for key, name, perf, tex in todo:
+    todo = [("c2_texture_on", "c2", None, "on", None), ("c2_texture_off", "c2", None, "off", None),
+            ("c5_dense", "c5", api.PFAC_TIME_DRIVEN, "auto", None), ("c5_hashed", "c5", api.PFAC_SPACE_DRIVEN, "auto", None),
+            # BASELINE config 2 names the dense 2-D table: the filter kernel walks the chained table in both perf modes, so this is the
+            # entry in which a kernel really walks int[S][256] -- the reference-shaped one (PFACX_KERNEL_REFTABLE), and the tiled kernel alone
+            ("c2_dense_table_reference_shaped_kernel", "c2", api.PFAC_TIME_DRIVEN, "on", "reftable"), ("c2_tiled_kernel", "c2", None, "auto", "naive")]
+    for key, name, perf, tex, variant in todo:
         t0 = time.perf_counter()
+        if variant is not None:
+            import copy
+            args = copy.copy(args)
+            args.variant = variant
         run = Run(args, name, perf, tex, 0, 1, device, buffers)
         run.step()
         ok, method, pos, _ = run.verify(args, 0, 1)
@@ -617,7 +624,7 @@ def other_configs(args, device, buffers):
         r = roofline_block(ms, run.n_read, kernel_name(args, run))
         entry = {"workload": run.cfg.description.replace("dense table", "hashed table") if run.perf_mode else run.cfg.description,
                  "table": "hashed" if run.perf_mode else "dense", "walker_table": walker_table(args, run),
-                 "texture_mode": int(run.handle.info().textureMode), "steps": OTHER_STEPS,
+                 "texture_mode": int(run.handle.info().textureMode), "steps": OTHER_STEPS, "kernel": args.variant, "kernel_launched": kernel_name(args, run),
                  "kernel_ms_avg": r["kernel_ms_avg"], "kernel_ms_min": r["kernel_ms_min"], "frac": r["frac"],
                  "input_GBps": round(run.n_read / (r["kernel_ms_avg"] / 1e3) / 1e9, 1),
                  "matches": int(pos.size), "bit_exact": bool(ok), "bit_exact_method": method}

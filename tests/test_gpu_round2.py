@@ -201,10 +201,11 @@ def test_snort_length_distribution_with_1_and_2_byte_patterns(workdir, capsys):
         print("\n[snort-length set, 64 MiB, 1-byte patterns present] input GB/s:", rates)
     # the floor under pattern-dense text, in every table mode (round 3: 60-118 GB/s through the reference-shaped kernel): the
     # tiled kernel is bound by instruction issue here (profiles/r04_hostile_pmc.txt: 1.9e8 VALU instructions per launch = 85 %
-    # of its time), measured 160-170; the filter kernel keeps such text itself (40 % of the positions pass level 1), 127-135
+    # of its time), measured 160-174; through the filter kernel every chunk of this text goes on the dense list (fifteen 1-byte patterns
+    # saturate the 3-gram bitmap: 98 % of the positions pass it) and comes back to the tiled kernel: 127-137.  The floors leave 20-25 % for a slow box
     for mode_name in ("dense-global", "dense-buffer", "hash-global", "hash-buffer"):
-        assert rates[f"{mode_name}/naive"] >= 135.0, rates
-        assert rates[f"{mode_name}/auto"] >= 105.0 and rates[f"{mode_name}/filter"] >= 105.0, rates
+        assert rates[f"{mode_name}/naive"] >= 125.0, rates
+        assert rates[f"{mode_name}/auto"] >= 95.0 and rates[f"{mode_name}/filter"] >= 95.0, rates
 
 
 @pytest.mark.parametrize("perf,tex,mode_name", MODES)
@@ -285,7 +286,7 @@ def test_every_position_matches_256_mib(workdir, capsys):
     # no chain folds them) are 4.2e8 VALU instructions per 64 MiB, which is all of the launch's time
     # (profiles/r04_hostile_pmc.txt); measured 84-94 GB/s
     assert rates["hash-buffer/filter"] >= 0.8 * rates["hash-buffer/naive"] and rates["dense-buffer/filter"] >= 0.8 * rates["dense-buffer/naive"], rates
-    assert min(rates["hash-buffer/naive"], rates["dense-buffer/naive"], rates["auto"]) >= 70.0, rates
+    assert min(rates["hash-buffer/naive"], rates["dense-buffer/naive"], rates["auto"]) >= 65.0, rates
 
 
 # ------------------------------------------------------------------------------------- pattern ingest

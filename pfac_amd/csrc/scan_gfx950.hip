@@ -1468,7 +1468,8 @@ constexpr uint32_t kTiledFar = 0x40000000u;            /* "the input ends nowher
 /* per wave: stage, list and -- the one-tile shape of small calls -- the tile's results: there a call is as long as its slowest wave, and
  * a patch that has to wait until the zeros are in L2 is on that path (4 KiB call 8.3 -> 7.2 us); the big shape hides the wait behind
  * fifteen other waves and spends the LDS on hot rows */
-constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + (tiles == 1 ? kTiledTile * 4 : 0); }
+constexpr uint32_t kTiledPairs = 32;                   /* compacted output: (position, id) pairs a wave stages in LDS before it appends them with one atomic */
+constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + kTiledPairs * 8 + (tiles == 1 ? kTiledTile * 4 : 0); }
 
 template <bool TEX, int WALKS, int TILES, bool HOTALL>
 __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
@@ -1493,7 +1494,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     uint32_t *stage = reinterpret_cast<uint32_t *>(waveBase);
     uint16_t *list = reinterpret_cast<uint16_t *>(waveBase + kStage);
     constexpr bool kLdsResults = TILES == 1;               /* a sparse group's results are assembled in LDS and stored once, as whole lines */
-    int *res = reinterpret_cast<int *>(waveBase + kStage + kTiledList * 2);
+    uint32_t *pairPos = reinterpret_cast<uint32_t *>(waveBase + kStage + kTiledList * 2), *pairId = pairPos + kTiledPairs;
+    int *res = reinterpret_cast<int *>(waveBase + kStage + kTiledList * 2 + kTiledPairs * 8);
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
     {
         const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.gram3);
@@ -1508,6 +1510,21 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     const uint32_t shift3 = 35u - (uint32_t)a.log2Bits;
     const uint32_t hot = a.hotSlots;
     const bool reduce = a.reducePos != nullptr;
+    /* compacted output: matches are staged per wave and appended kTiledPairs at a time -- one device counter answers ~90 atomics per
+     * microsecond, and the Snort-style stream has 583 K matches per GiB in 500 K different (walk set, round)s: an atomic each was
+     * 5 ms per GiB on top of a 1.4 ms scan */
+    uint32_t staged = 0;                                   /* wave-uniform */
+    auto flushPairs = [&]() {
+        if (staged == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned int at = 0;
+        if (lane == 0) at = atomicAdd(a.reduceCount, staged);
+        at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at);
+        if ((uint32_t)lane < staged) { a.out[at + lane] = (int)pairId[lane]; a.reducePos[at + lane] = (int)pairPos[lane]; }
+        staged = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
 #ifndef PFAC_TILED_STATS
 #define PFAC_TILED_STATS 0                     /* measurement build: wave-wide step iterations, live lane-steps, walks, passes, dense groups */
 #endif
@@ -1658,17 +1675,25 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                     if (__ballot(alive[k]) != 0) step(k, s[k], w0[k], w1[k]);
             }
         };
-        /* compacted output: the matches of a walk set join the pair list, one atomic per set */
+        /* compacted output: the matches of a walk set join the wave's staged pairs */
         auto appendPairs = [&](const uint32_t (&o)[WALKS], const int (&match)[WALKS]) {
 #pragma unroll
             for (int k = 0; k < WALKS; k++) {
                 const bool has = match[k] != 0;
                 const uint64_t m = __ballot(has);
                 if (m) {
-                    unsigned int at = 0;
-                    if (lane == 0) at = atomicAdd(a.reduceCount, (unsigned int)__popcll(m));
-                    at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + laneRankIn(m);
-                    if (has) { a.out[at] = match[k]; a.reducePos[at] = (int)(posBase + o[k]); }
+                    const uint32_t n = (uint32_t)__popcll(m);
+                    if (staged + n > kTiledPairs) flushPairs();
+                    if (n > kTiledPairs) {                         /* match-dense input: this set alone is worth an atomic */
+                        unsigned int at = 0;
+                        if (lane == 0) at = atomicAdd(a.reduceCount, n);
+                        at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + laneRankIn(m);
+                        if (has) { a.out[at] = match[k]; a.reducePos[at] = (int)(posBase + o[k]); }
+                    } else {
+                        const uint32_t at = staged + laneRankIn(m);
+                        if (has) { pairPos[at] = posBase + o[k]; pairId[at] = (uint32_t)match[k]; }
+                        staged += n;
+                    }
                 }
             }
         };
@@ -1830,6 +1855,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             scanGroup(a.denseIn + T, spanAll - T, 0u, kTake, limit, a.denseOut + T, 0u);
         }
     }
+    if (reduce) flushPairs();
 #if PFAC_TILED_STATS
     if (lane == 0) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 26;   /* behind the PFAC_TIMING words */

@@ -69,7 +69,7 @@ typedef struct {
     int filterLog2BitsFinal3; /* length-3-pattern bitmap                         */
     size_t filterBitsSetLadder;
     int chainJumpLog2;        /* PFACX_TABLE_CHAIN: log2 of its jump-table slots (0 until the table exists) */
-    size_t chainSlots;        /* PFACX_TABLE_CHAIN: slots in total                                          */
+    size_t chainSlots;        /* PFACX_TABLE_CHAIN: 16-byte units in total: slot headers, then as many extension units */
     size_t ladderStops;       /* prefix ladder: trie nodes inserted as "stop: walk from here" ...            */
     size_t ladderGoOns;       /* ... and as "go on: test the next prefix length"                             */
     int ladderThin;           /* nodes with at most this many patterns below them are stops ...             */
@@ -94,10 +94,11 @@ typedef enum {
     PFACX_TABLE_FILTER_FINAL3 = 7, /* uint32[2^filterLog2BitsFinal3 / 32]           */
     PFACX_TABLE_FILTER_GRAM1 = 9,  /* uint32[2^19 / 32]: one-bit 3-gram bitmap of the compacted-output kernel       */
     PFACX_TABLE_FILTER_PREFIX4 = 10, /* uint32[2^17 / 32]: the 4-byte pattern prefixes, two probes (same kernel)    */
-    PFACX_TABLE_CHAIN        = 8   /* uint32[4] per slot: the device-only chained form of the hashed table that the
-                                      filter kernel walks in both perf modes (slot i = reference hashValPtr[i]; then
-                                      the 256 slots of the initial state; the last 2^chainJumpLog2 slots are the
-                                      jump table of 4-byte prefixes).  Built on first use on a host-only handle.  */
+    PFACX_TABLE_CHAIN        = 8   /* uint32[4] per 16-byte unit: the device-only chained form of the hashed table that the
+                                      GPU kernels walk in both perf modes.  chainSlots / 2 slot headers -- compact buckets,
+                                      breadth first; then the 256 slots of the initial state; then the 2^chainJumpLog2
+                                      slots of the jump table of 4-byte prefixes -- followed by as many extension units,
+                                      unit i = chain bytes 8..22 of slot i (long slots of wide buckets only).  Built on first use on a host-only handle.  */
 } PFACX_table_t;
 
 PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const void **ptr,

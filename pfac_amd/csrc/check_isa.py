@@ -10,7 +10,8 @@ tests/test_kernel_isa.py runs the same functions):
   * the reserved registers appear only as destinations of the six prefetch loads and as sources of the ten copies that
     take a tile;
   * inside the scan loop the only wait for vector memory is the explicit one at the top of a trip (and, in the
-    compacted-output instances, the ones behind the returning atomics that hand out chunks and output slots).
+    compacted-output instances, the ones behind the returning atomics that hand out chunks and output slots, and the
+    one behind the on-demand fetch of a long slot's extension unit).
 Exit status 0 = the contract holds; otherwise the first violation is printed."""
 import re
 import sys
@@ -88,11 +89,25 @@ def check_waits(text):
         member = [i for i, l in enumerate(lines) if f"Header={label} " in l]             # blocks annotated as part of the loop
         end = next(i for i, l in enumerate(lines) if i > max(member) and re.match(r"\.LBB\d+_\d+:", l))
         # the compiler may place blocks of the loop (its rotated top, with the explicit wait) in front of the header label
-        start = min(header, max(i for i, l in enumerate(lines[:min(member)]) if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", l)))
+        start = min(header, max(i for i, l in enumerate(lines[:min(member) + 1]) if re.match(r"(\.LBB\d+_\d+:|; %bb\.\d+:)", l)))     # + 1: the annotation may sit on the label's own line
         loop = lines[start:end]
         waits = [i for i, l in enumerate(loop) if "s_waitcnt" in l and "vmcnt" in l]
         # the compacted-output instances flush their staged pairs with a returning atomic now and then and wait for it
         after_atomic = [i for i in waits if any("global_atomic_add" in l for l in loop[max(0, i - 4):i])]
+        # the compacted-output instances fetch the extension unit of a LONG slot (wide buckets, pfac_context.h) and the input
+        # behind it when a header's first eight chain bytes have matched, and wait for them on the spot: the source marks the
+        # place (`; pfac_ext_sync`), the wait is the first one behind the marker
+        def behind_marker(i):
+            for j in range(i - 1, max(0, i - 80), -1):
+                if "pfac_ext_sync" in loop[j]:
+                    return True
+                if "s_waitcnt" in loop[j] and "vmcnt" in loop[j]:
+                    return False
+            return False
+        ext_sync = [i for i in waits if i not in after_atomic and behind_marker(i)]
+        if re.search(r"ELb0ELi\dE", name) and ext_sync:                            # (a -DPFAC_WIDE_SPEC=0 measurement build does: it is not built by `make`)
+            raise ContractError(f"{name}: the full-result scan loop waits for an extension unit on the spot")
+        waits = [i for i in waits if i not in ext_sync]
         # ... of which the compiler may lay out one copy per path into the loop top (tail duplication): every copy is
         # followed by the same instruction, the first of the walkers' consume stage
         top = {loop[i + 1].strip() for i in waits if i not in after_atomic}

@@ -51,28 +51,40 @@ constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, wa
 #define PFAC_WALK_SETS_FULL 1                  /* ... full-result kernel: behind the prefix ladder one walk per lane keeps up, and is 1 % (C3) to 5 % (C5) faster */
 #endif
 constexpr int kChunkTiles = 2;                 /* KiB of input a wave stages at a time */
-constexpr int kChainMax = 7;                  /* bytes of single-successor chain folded into one slot */
+constexpr int kChainMax = 7;                  /* bytes of single-successor chain a slot header folds in ...                                */
+constexpr int kChainMaxWide = 23;             /* ... a slot of a WIDE bucket: 8 in the header + 15 in its extension unit                    */
 /* 16-byte device slot of the chained hashed table: one gathered 16-byte load per transition.
- * meta = edge byte | chain length << 8 | flags | k << 16 | (S-1) << 24, where {k, S} are the hash
+ * meta = edge byte | chain length << 8 (5 bits) | flags | k << 16 | (S-1) << 24, where {k, S} are the hash
  * parameters of the END state's bucket: the successor on byte ch sits in slot ((k * ch) >> 7) & (S-1) of it
  * (1 <= k <= 255, S a power of two <= 256, k the smallest multiplier without a collision; k = 128, S = 256 is the
- * identity and always works).  The reference's hashed layout uses ((k * ch) mod 257) & (S-1) (PFAC.cpp:506-542); this
- * table is device-only and its own: the multiply-shift costs a walk step four instructions instead of nine. */
+ * identity and always works; k = 0: the end state is a LEAF, it has no bucket).  The reference's hashed layout uses
+ * ((k * ch) mod 257) & (S-1) (PFAC.cpp:506-542); this table is device-only and its own: the multiply-shift costs a
+ * walk step four instructions instead of nine.
+ * WIDE buckets (round 5: long single-successor runs -- near misses of long patterns, BASELINE config 5 -- were eight
+ * dependent steps of 8 bytes): a slot of a wide bucket folds up to kChainMaxWide chain bytes, bytes 0..7 in the header and
+ * bytes 8..22 in the slot's EXTENSION UNIT.  The table is N headers followed by N units, the unit of slot i at N + i, so
+ * a walker that expects long slots (kSlotWide of the slot that led into the bucket) can fetch header and unit as two
+ * INDEPENDENT loads and take 24 bytes with one dependent round trip.  Only slots of wide buckets have chains longer
+ * than kChainMax; the initial state's bucket and the jump table are never wide. */
 struct ChainSlot {
     uint32_t meta;
     int endRow;                               /* hashRowPtr[end].x (first slot of the end state's bucket);
                                                  if the end state is a final LEAF: its pattern ID        */
-    unsigned char chain[8];                   /* chain bytes, zero padded; if the end state is final and
+    unsigned char chain[8];                   /* chain bytes 0..7, zero padded; if the end state is final and
                                                  has successors: <= 3 chain bytes, pattern ID in [4..7]  */
 };
 constexpr size_t kGram3LdsBytes = 32 * 1024;     /* LDS set aside for the level-1 bitmap (2^18 bits at most): the ladder behind it sits at a compile-time address */
 constexpr size_t kFilterLdsBudget = 97 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp); the rest of the
                                                     CU's 160 KiB is the scanning waves' queues and stages (scan_gfx950.hip checks the sum) */
-constexpr uint32_t kSlotFinal = 1u << 12;     /* the end state is a final state                         */
-constexpr uint32_t kSlotLeaf = 1u << 13;      /* the end state has no outgoing transition               */
+constexpr uint32_t kSlotLenShift = 8, kSlotLenMask = 0x1Fu;   /* chain length: bits 8..12 */
+constexpr uint32_t kSlotFinal = 1u << 13;     /* the end state is a final state                         */
 constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */
+constexpr uint32_t kSlotWide = 1u << 15;      /* the end state's bucket is wide: its slots may be long (chain bytes 8.. in their extension units) */
+constexpr uint32_t kSlotKMask = 0xFFu << 16;  /* k == 0: the end state has no outgoing transition (a leaf) */
 static_assert(sizeof(ChainSlot) == 16, "ChainSlot is read as one 16-byte load");
+static_assert(kChainMaxWide <= (int)kSlotLenMask && kChainMaxWide == 8 + 15, "the chain length has five bits; a unit holds chain bytes 8..22 and the byte behind the chain must still be one of 24");
 constexpr uint32_t kChainRootMeta = (128u << 16) | (255u << 24);   /* hash parameters of the initial state's bucket: slot of byte b = b */
+inline bool chainSlotLeaf(uint32_t meta) { return (meta & kSlotKMask) == 0; }
 inline uint32_t chainSlotOf(uint32_t meta, uint32_t ch) { return ((((meta >> 16) & 0xFFu) * ch) >> 7) & (meta >> 24); }
 
 /* One compiled pattern set: patterns + trie.  Independent of perfMode. */
@@ -193,8 +205,9 @@ struct PFAC_context {
     std::vector<pfac::ChainSlot> h_chainSlots;               /* host copy of the chained table (PFACX_saveCompiled)       */
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
     size_t numChainSlots = 0;
-    int chainJumpLog2 = 0;                    /* the last 2^J slots of the chained table are the jump table, the 256 before them the
-                                                 initial state's bucket (tables.cpp: buildChainedHashTable)                        */
+    int chainJumpLog2 = 0;                    /* the chained table is numChainSlots / 2 slot headers, then as many extension units; the last 2^J
+                                                 headers are the jump table, the 256 before them the initial state's bucket (tables.cpp:
+                                                 buildChainedHashTable) */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_ladder = nullptr;

@@ -140,6 +140,7 @@ struct ScanArgs {
     const Int2 *hashRow;
     const Int2 *hashVal;
     const u32x4 *chainSlots;                           /* pfac::ChainSlot[], 16 bytes each               */
+    uint32_t extDelta;                                 /* the extension unit of slot i is chainSlots[i + extDelta] (long slots of wide buckets: pfac_context.h) */
     uint32_t rootRow, jumpBase, jumpShift;             /* inside chainSlots: the initial state's bucket (256 slots, indexed by the byte)
                                                           and the jump table (2^(32 - jumpShift) slots): tables.cpp */
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
@@ -310,11 +311,11 @@ template <bool TEX> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
     const uint32_t *in32;
-    uint32_t rootRow, jumpBase, jumpShift;
+    uint32_t rootRow, jumpBase, jumpShift, extDelta;
     __device__ ChainCtx(const ScanArgs &a)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift) {}
+          in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift), extDelta(a.extDelta) {}
 };
 constexpr uint32_t kRootKs = pfac::kChainRootMeta;      /* the initial state's bucket: k = 128, S = 256 -- the slot of byte b is b */
 
@@ -330,10 +331,32 @@ __device__ __forceinline__ uint32_t chainHashSlot(uint32_t ks, uint32_t ch)
 constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brings along: compacted-output kernel (what the prefix ladder looks at) */
 constexpr uint32_t kEntryBytesFull = 36;       /* ... full-result kernel: 16 more, so that a walk 21..36 bytes deep (near misses of long patterns) needs no
                                                 * gathered input load: those were 40 % of the gathered loads of BASELINE config 5 */
+#ifndef PFAC_WIDE_SPEC
+#define PFAC_WIDE_SPEC 1                       /* full-result kernel: 1 = the extension unit of a wide bucket's slot is fetched WITH the header (four more registers
+                                                * per lane); 0 = fetched when a header's first 8 chain bytes have matched, and waited for on the spot */
+#endif
+
+__device__ __forceinline__ uint32_t slotLen(uint32_t meta) { return __builtin_amdgcn_ubfe(meta, pfac::kSlotLenShift, 5u); }
+/* the low n (0..8) bytes of d are zero */
+__device__ __forceinline__ bool lowBytesZero(uint64_t d, uint32_t n) { return n >= 8u ? d == 0 : ((d << 8) << (56u - 8u * n)) == 0; }
+/* byte i (0..15) of the 16 bytes y0..y3 */
+__device__ __forceinline__ uint32_t byteOf16(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t i)
+{
+    const uint32_t lo = (i & 4u) ? y1 : y0, hi = (i & 4u) ? y3 : y2;
+    return (((i & 8u) ? hi : lo) >> (8u * (i & 3u))) & 0xFFu;
+}
+/* chain bytes 8 .. len-1 of a long slot (extension unit e) against the input bytes 8 .. 23 behind the edge byte (y0..y3), 8 <= len <= 23 */
+__device__ __forceinline__ bool extensionEqual(const u32x4 &e, uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t len)
+{
+    const uint32_t n = len - 8u;                                   /* 0..15 bytes */
+    const uint64_t lo = ((uint64_t)(y1 ^ e.y) << 32) | (y0 ^ e.x), hi = ((uint64_t)(y3 ^ e.w) << 32) | (y2 ^ e.z);
+    return lowBytesZero(lo, n < 8u ? n : 8u) & lowBytesZero(hi, n > 8u ? n - 8u : 0u);
+}
 
 template <bool TEX, uint32_t ENTRY> struct ChainLane {
     using Ctx = ChainCtx<TEX>;
     static constexpr bool kDeep = ENTRY > kEntryBytes;          /* 36-byte entries: the window is nine dwords, re-fetched 32 bytes at a time */
+    static constexpr bool kSpec = kDeep && PFAC_WIDE_SPEC != 0; /* wide buckets: header and extension unit are fetched together, the unit compared out of the window */
     uint32_t pos = 0;
     uint32_t row = 0;                          /* first slot of the current state's bucket */
     int match = 0;
@@ -342,11 +365,14 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
      * It starts as the queue entry's 20 bytes and is only re-fetched (16 bytes into W1..W4) when a MATCHING
      * slot needs bytes beyond it: the step that ends a walk -- a slot for some other byte -- needs none. */
     u32x4 t = {0, 0, 0, 0};
+    u32x4 E;                                   /* kSpec: the extension unit of the slot in flight (loaded whenever the bucket is wide, read only then: no initial value,
+                                                * which would be four register writes that wait for the loads of the bounded walks in front of the scan loop) */
     uint32_t W0 = 0;
     u32x4 W = {0, 0, 0, 0};                    /* W1..W4 as one register quad: the destination of the window load itself */
     u32x4 V = {0, 0, 0, 0};                    /* kDeep: W5..W8 */
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
+    bool haveE = false, needExt = false, usedE = false;   /* kSpec: the unit in E belongs to the slot in t; a long slot's header matched without it; ... and it was looked at */
     bool first = false;                        /* the slot in flight comes from the jump table */
     bool longWalk = false;                     /* a walk that outran its window once fetches a new one with every step from then on */
 
@@ -374,27 +400,22 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
             x1 = __builtin_amdgcn_alignbyte(G2, G1, o & 3u);
         }
     }
-
-    /* Take the transition described by slot `s` (pfac::ChainSlot) on edge byte b0, given the input
-     * bytes x0:x1 behind the edge byte: compares the chain, lands in the slot's end state and picks
-     * the next edge byte.  Straight-line: the walker's fields are garbage afterwards unless the result
-     * is true; `match` is always valid.  False = the walk is over (trap, or no successor). */
-    __device__ __forceinline__ bool advance(const u32x4 &s, uint32_t x0, uint32_t x1, bool &ok)
+    /* kDeep: input bytes q+8 .. q+23 out of the nine-dword window (a long slot's extension: the caller has checked that the
+     * window holds all 24 bytes from q, so q - (wend - 36) <= 12: the dword number is 0..3 and only the shifts by 2 and 1 are needed) */
+    __device__ __forceinline__ void windowBytesExt(uint32_t q, uint32_t &y0, uint32_t &y1, uint32_t &y2, uint32_t &y3) const
     {
-        const uint32_t meta = s.x;
-        const uint32_t len = (meta >> 8) & 0xFu;               /* <= kChainMax = 7 */
-        const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
-        /* the slot is this byte's (not empty, not another byte's), and the first len chain bytes equal the
-         * input: two shifts by less than 64 each, so that len == 0 shifts everything out */
-        ok = ((meta & (pfac::kSlotEmpty | 0xFFu)) == b0) & (((diff << 8) << (56u - 8u * len)) == 0);
-        const bool leaf = (meta & pfac::kSlotLeaf) != 0;
-        const int id = (int)(leaf ? s.y : s.w);                /* kSlotFinal: see pfac::ChainSlot */
-        match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
-        row = s.y;
-        ks = meta;
-        depth += 1 + len;
-        b0 = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * len)) & 0xFFu;   /* byte len (<= 7) behind the edge byte */
-        return ok & !leaf;
+        const uint32_t o = q - (wend - ENTRY);
+        const bool b1 = (o & 4u) != 0, b2 = (o & 8u) != 0;
+        const uint32_t W1 = W.x, W2 = W.y, W3 = W.z, W4 = W.w, W5 = V.x, W6 = V.y, W7 = V.z, W8 = V.w;
+        (void)W1;
+        /* dwords 2 .. 6 behind dword number d = o >> 2 (0..3): d + 2 .. d + 6 <= 9; W9 does not exist and is never needed (o <= 12 means
+         * d = 3 only with o = 12: the 24 bytes end with W8) */
+        const uint32_t F2 = b2 ? W4 : W2, F3 = b2 ? W5 : W3, F4 = b2 ? W6 : W4, F5 = b2 ? W7 : W5, F6 = b2 ? W8 : W6, F7 = b2 ? W8 : W7;
+        const uint32_t G2 = b1 ? F3 : F2, G3 = b1 ? F4 : F3, G4 = b1 ? F5 : F4, G5 = b1 ? F6 : F5, G6 = b1 ? F7 : F6;
+        y0 = __builtin_amdgcn_alignbyte(G3, G2, o & 3u);
+        y1 = __builtin_amdgcn_alignbyte(G4, G3, o & 3u);
+        y2 = __builtin_amdgcn_alignbyte(G5, G4, o & 3u);
+        y3 = __builtin_amdgcn_alignbyte(G6, G5, o & 3u);
     }
 
     /* A walk starts in the JUMP table (tables.cpp): the queue entry {position, 20 input bytes} is its first window,
@@ -407,7 +428,7 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         W0 = ea.y; W.x = ea.z; W.y = ea.w; W.z = eb0; W.w = eb1;
         if (kDeep) V = ec;
         wend = pos + ENTRY;
-        needWin = false; needSlot = true; longWalk = false;
+        needWin = false; needSlot = true; longWalk = false; haveE = false; needExt = false;
         /* a pattern of one or two bytes matches here (shortBits: the exact 2-byte bitmap, only given when the set has
          * such patterns): the prefix passes a final state, so it has no jump slot -- straight to the initial state's
          * bucket instead of finding that out a round later */
@@ -416,7 +437,16 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         row = viaRoot ? c.rootRow : c.jumpBase + ((ea.y * pfac::kJumpMul) >> c.jumpShift);
         ks = viaRoot ? kRootKs : 0u;
     }
-    __device__ __forceinline__ void issue(const Ctx &c)
+    __device__ __forceinline__ u32x4 loadSlot(const Ctx &c, uint32_t idx) const
+    {
+        if (TEX) return __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, PFAC_SLOT_AUX);
+        return c.slots[idx];
+    }
+    /* spec (wave-uniform, kSpec only): the wave expects long slots -- its stream has been full of near misses -- and fetches
+     * the extension unit of a wide bucket's slot WITH the header.  Otherwise a unit is fetched when a long slot's header bytes
+     * have matched (one more trip of the scan loop for that walk, like a window that has to be re-fetched): on benign input
+     * that is rare, and a unit fetched for nothing is a gathered load of a cold line. */
+    __device__ __forceinline__ void issue(const Ctx &c, bool spec)
     {
         if (needSlot) {
 #if defined(PFAC_EXP_CONFINE)           /* timing experiment: every slot load inside one window of the table; results are wrong */
@@ -424,8 +454,14 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
 #else
             const uint32_t idx = row + chainHashSlot(ks, b0);
 #endif
-            if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, PFAC_SLOT_AUX);
-            else t = c.slots[idx];
+            t = loadSlot(c, idx);
+            if (kSpec) {
+                haveE = spec & ((ks & pfac::kSlotWide) != 0);
+                if (haveE) E = loadSlot(c, idx + c.extDelta);
+            }
+        } else if (kSpec && needExt) {                         /* the header in t is a long slot whose unit did not come with it */
+            E = loadSlot(c, row + chainHashSlot(ks, b0) + c.extDelta);
+            haveE = true;
         }
         if (needWin) {                                         /* rare: the walk is deeper than its entry */
             W = loadWindow16(c.in32, pos + depth + 1);                 /* pos + depth = position of the edge byte b0 */
@@ -433,19 +469,81 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
             wend = ((pos + depth + 1) & ~3u) + (kDeep ? 32u : 16u);
         }
     }
-    __device__ __forceinline__ bool consume(const Ctx &c)
+    /* Finish the transition whose slot is in t (pfac::ChainSlot) on edge byte b0: compares the chain with the input behind
+     * the edge byte, lands in the slot's end state and picks the next edge byte.  Straight-line but for the extension of a
+     * long slot, which only runs when some lane of the wave has one; `match` is always valid.  False = the walk is over
+     * (trap, or no successor). */
+    __device__ __forceinline__ bool consume(const Ctx &c, bool spec)
     {
         const uint32_t q = pos + depth + 1;                    /* first byte behind the edge byte */
-        const uint32_t len = (t.x >> 8) & 0xFu;
-        const bool mine = (t.x & (pfac::kSlotEmpty | 0xFFu)) == b0;
-        const bool covered = q + len + 1u <= wend;
-        needWin = mine & !covered;                             /* matching slot, bytes missing: fetch them and come back */
-        needSlot = !needWin;
-        longWalk |= needWin;
+        const uint32_t meta = t.x;
+        const uint32_t len = slotLen(meta);                    /* <= kChainMax, or <= kChainMaxWide in a wide bucket */
+        const bool mine = (meta & (pfac::kSlotEmpty | 0xFFu)) == b0;
+        const bool isLong = len > (uint32_t)pfac::kChainMax;
+        const uint32_t lenIn = isLong ? (uint32_t)pfac::kChainMax : len;
+        /* bytes of the window the header needs behind the edge byte: a short slot's chain and the next edge byte, a long
+         * slot's eight header bytes */
+        const bool coveredIn = q + lenIn + 1u <= wend;
         uint32_t x0, x1;
         windowBytes(q, x0, x1);
-        bool cont = true, ok = true;
-        if (!needWin) cont = advance(t, x0, x1, ok);
+        const uint64_t diff = ((uint64_t)(x1 ^ t.w) << 32) | (x0 ^ t.z);
+        /* the slot is this byte's (not empty, not another byte's), and the first lenIn chain bytes equal the
+         * input: two shifts by less than 64 each, so that len == 0 shifts everything out */
+        bool ok = mine & (((diff << 8) << (56u - 8u * lenIn)) == 0);
+        /* a matching slot whose bytes are not all in the window: fetch them and come back.  A long slot whose header bytes
+         * match (kSpec) needs all 24 bytes in the window (windowBytesExt shifts by at most three dwords) and its unit */
+        const bool longGo = kSpec && (isLong & ok & coveredIn);
+        needWin = mine & (!coveredIn | (longGo & (q + 24u > wend)));
+        needExt = longGo & !haveE;
+        usedE = kSpec && (haveE & mine & isLong);
+        const bool retry = needWin | needExt;
+        needSlot = !retry;
+        longWalk |= needWin;
+        bool cont = true;
+        if (retry) ok = true;
+        if (!retry) {
+            uint32_t next = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * lenIn)) & 0xFFu;   /* byte len (<= 7) behind the edge byte */
+            if (__ballot(ok & isLong) != 0) {
+                /* long slots (wide buckets): header byte 7, then chain bytes 8 .. len-1 in the extension unit against the
+                 * input bytes 8 .. 23 behind the edge byte; the next edge byte is one of those */
+                uint32_t y0, y1, y2, y3;
+                u32x4 e;
+                if (kSpec) {
+                    windowBytesExt(q, y0, y1, y2, y3);
+                    e = E;
+                } else {
+                    /* fetched now and waited for on the spot: rare where this path is compiled in (the compacted-output kernel,
+                     * whose 20-byte window could not hold the bytes anyway) */
+                    asm volatile("; pfac_ext_sync" ::: "memory");
+                    const uint32_t at = row + chainHashSlot(ks, b0) + c.extDelta;
+                    e = u32x4{0, 0, 0, 0};
+                    u32x4 in4 = {0, 0, 0, 0};
+                    uint32_t in1 = 0;
+                    if (ok & isLong) {
+                        e = loadSlot(c, at);
+                        in4 = loadWindow16(c.in32, q + 8u);
+                        in1 = c.in32[((q + 8u) >> 2) + 4u];
+                    }
+                    const uint32_t sh = (q + 8u) & 3u;
+                    y0 = __builtin_amdgcn_alignbyte(in4.y, in4.x, sh);
+                    y1 = __builtin_amdgcn_alignbyte(in4.z, in4.y, sh);
+                    y2 = __builtin_amdgcn_alignbyte(in4.w, in4.z, sh);
+                    y3 = __builtin_amdgcn_alignbyte(in1, in4.w, sh);
+                    longWalk |= ok & isLong;                   /* the window is behind the walk now */
+                }
+                const bool okLong = (((x1 ^ t.w) >> 24) == 0) & extensionEqual(e, y0, y1, y2, y3, len);
+                ok &= !isLong | okLong;
+                next = isLong ? byteOf16(y0, y1, y2, y3, len - 8u) : next;
+            }
+            const bool leaf = (meta & pfac::kSlotKMask) == 0;
+            const int id = (int)(leaf ? t.y : t.w);                /* kSlotFinal: see pfac::ChainSlot (a final state with successors never ends a long slot) */
+            match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;   /* skipped chain states are never final */
+            row = t.y;
+            ks = meta;
+            depth += 1 + len;
+            b0 = next;
+            cont = ok & !leaf;
+        }
         /* the jump table does not know these four bytes (a collision, a final state on the way, a false positive
          * of the prefilter): the walk starts over in the initial state's bucket, one byte at a time */
         const bool restart = first & !ok;
@@ -456,8 +554,14 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         cont |= restart;
         first = false;
         /* long walks (adversarial input): no more retry rounds -- a new window with every step, or, with the wide window,
-         * whenever fewer than nine bytes (the most a step consumes) are left of it */
-        needWin |= kDeep ? (longWalk & (wend < pos + depth + 10u)) : longWalk;
+         * whenever fewer bytes than the next step can consume are left of it (nine; 25 if the wave expects long slots and the
+         * next bucket is wide: the slot, its unit and the window then come back together) */
+        if (kDeep) {
+            const bool wideNext = kSpec && (spec & ((ks & pfac::kSlotWide) != 0));
+            if (!retry) needWin |= (longWalk | wideNext) & (wend < pos + depth + (wideNext ? 25u : 10u));
+        } else {
+            needWin |= longWalk;
+        }
         return cont;
     }
 };
@@ -479,13 +583,21 @@ __device__ int boundedWalk(const ChainCtx<TEX> &c, const unsigned char *in, size
         if (TEX) t = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, 0);
         else t = c.slots[idx];
         if ((t.x & (pfac::kSlotEmpty | 0xFFu)) != b0) break;
-        const uint32_t len = (t.x >> 8) & 0xFu;
+        const uint32_t len = slotLen(t.x);
         if (at + len >= readable) break;             /* the chain's bytes at+1 .. at+len must exist */
         const uint64_t chain = ((uint64_t)t.w << 32) | t.z;
         bool ok = true;
-        for (uint32_t k = 0; k < len; k++) ok &= in[at + 1 + k] == (uint32_t)((chain >> (8u * k)) & 0xFFu);
+        for (uint32_t k = 0; k < len && k < 8u; k++) ok &= in[at + 1 + k] == (uint32_t)((chain >> (8u * k)) & 0xFFu);
+        if (ok && len > 8u) {                        /* a long slot of a wide bucket: chain bytes 8 .. len-1 in its extension unit */
+            const uint32_t eidx = idx + c.extDelta;
+            u32x4 e;
+            if (TEX) e = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(eidx * 16u), 0, 0);
+            else e = c.slots[eidx];
+            const uint64_t lo = ((uint64_t)e.y << 32) | e.x, hi = ((uint64_t)e.w << 32) | e.z;
+            for (uint32_t k = 8; k < len; k++) ok &= in[at + 1 + k] == (uint32_t)(((k < 16u ? lo : hi) >> (8u * (k & 7u))) & 0xFFu);
+        }
         if (!ok) break;
-        const bool leaf = (t.x & pfac::kSlotLeaf) != 0;
+        const bool leaf = (t.x & pfac::kSlotKMask) == 0;
         if (t.x & pfac::kSlotFinal) match = (int)(leaf ? t.y : t.w);
         if (leaf) break;
         row = t.y;
@@ -769,10 +881,23 @@ void pfac_scan_filter(ScanArgs a)
             }
         }
     };
+    /* Does this wave expect LONG slots (pfac_context.h: wide buckets)?  Wave-uniform, decided from what its own walks meet:
+     * off, a long slot whose header bytes match costs its walk one more trip (the unit is fetched then); once kSpecOnScore
+     * walks have paid that, the units of wide buckets' slots are fetched with the headers and the window is kept 24 bytes
+     * ahead -- until, eight rounds in a row, fewer than a quarter of the units fetched were looked at.  Near-miss streams
+     * (BASELINE config 5) run with it on from their first rounds; on text it stays off: a unit fetched for a walk that
+     * dies on its edge byte is a gathered load of a cold line (Snort-style stream, always on: +2.8 % launch time). */
+    constexpr bool kSpecKernel = WLane::kSpec;
+    constexpr uint32_t kSpecOnScore = 16, kSpecOffRounds = 8;
+#ifndef PFAC_SPEC_FORCE
+#define PFAC_SPEC_FORCE -1                     /* measurement builds: 0 = never, 1 = always */
+#endif
+    bool specOn = PFAC_SPEC_FORCE == 1;
+    uint32_t specScore = 0, specIdle = 0;
     auto walkIssue = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
-            if (alive[s]) walk[s].issue(wctx);
+            if (alive[s]) walk[s].issue(wctx, specOn);
             stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
         }
         stRounds++;
@@ -788,7 +913,17 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             bool cont = false;
-            if (alive[s]) cont = walk[s].consume(wctx);
+            if (alive[s]) cont = walk[s].consume(wctx, specOn);
+            if (kSpecKernel && PFAC_SPEC_FORCE < 0) {
+                if (!specOn) {
+                    specScore += (uint32_t)__popcll(__ballot(alive[s] & walk[s].needExt));
+                    if (specScore >= kSpecOnScore) { specOn = true; specScore = 0; specIdle = 0; }
+                } else {
+                    const uint32_t loaded = (uint32_t)__popcll(__ballot(alive[s] & walk[s].haveE)), used = (uint32_t)__popcll(__ballot(alive[s] & walk[s].usedE));
+                    if (loaded >= 8u) specIdle = used * 4u < loaded ? specIdle + 1u : 0u;
+                    if (specIdle >= kSpecOffRounds) { specOn = false; specIdle = 0; }
+                }
+            }
             report(alive[s] & !cont, walk[s], s);
             alive[s] = cont;
         }
@@ -1607,21 +1742,61 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             w1 = __builtin_amdgcn_alignbyte(e2, e1, q & 3u);
         };
 
+        /* bytes q .. q+15 of the group (the input behind a long slot's header) */
+        auto fetch16 = [&](uint32_t q, uint32_t &y0, uint32_t &y1, uint32_t &y2, uint32_t &y3) {
+            uint32_t e0, e1, e2, e3, e4;
+            if (q + 20u <= kStage) {
+                const uint32_t *p = stage + (q >> 2);
+                e0 = p[0]; e1 = p[1]; e2 = p[2]; e3 = p[3]; e4 = p[4];
+            } else {
+                const uint32_t at = q & ~3u;
+                e0 = at < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at) : 0u;
+                e1 = at + 4u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 4u) : 0u;
+                e2 = at + 8u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 8u) : 0u;
+                e3 = at + 12u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 12u) : 0u;
+                e4 = at + 16u < span32 ? *reinterpret_cast<const uint32_t *>(g16 + at + 16u) : 0u;
+            }
+            y0 = __builtin_amdgcn_alignbyte(e1, e0, q & 3u);
+            y1 = __builtin_amdgcn_alignbyte(e2, e1, q & 3u);
+            y2 = __builtin_amdgcn_alignbyte(e3, e2, q & 3u);
+            y3 = __builtin_amdgcn_alignbyte(e4, e3, q & 3u);
+        };
+
         /* WALKS walks per lane from the group offsets o[] (alive[]: the lane has one), to the end: match[] = result */
         auto runWalks = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
             uint32_t q[WALKS], row[WALKS], ks[WALKS];
             /* one transition through slot s on the edge byte at q, w0:w1 = bytes q .. q+7 (ChainLane::advance, with the
              * end of the input checked: edge byte and chain must lie in front of `limit`) */
             auto step = [&](int k, const u32x4 &s, uint32_t w0, uint32_t w1) {
-                const uint32_t meta = s.x, len = __builtin_amdgcn_ubfe(meta, 8u, 4u);
+                const uint32_t meta = s.x, len = slotLen(meta);
                 bool ok = alive[k] & ((meta & (pfac::kSlotEmpty | 0xFFu)) == (w0 & 0xFFu));
                 if (bounded) ok &= q[k] + len < limit;
                 if (__ballot(ok & (len != 0)) != 0) {              /* the top of a trie branches at every byte: no chain, nothing to compare */
                     const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, 1), x1 = w1 >> 8;
                     const uint64_t diff = ((uint64_t)(x1 ^ s.w) << 32) | (x0 ^ s.z);
-                    ok &= ((diff << 8) << (56u - 8u * len)) == 0;
+                    const uint32_t lenIn = len < (uint32_t)pfac::kChainMax ? len : (uint32_t)pfac::kChainMax;
+                    ok &= ((diff << 8) << (56u - 8u * lenIn)) == 0;
+                    const bool isLong = len > (uint32_t)pfac::kChainMax;
+                    if (__ballot(ok & isLong) != 0) {
+                        /* a long slot of a wide bucket (pfac_context.h): header byte 7 and the chain bytes 8 .. len-1 of its
+                         * extension unit against the 16 bytes from q + 8.  (row, ks and the edge byte still describe the bucket
+                         * the slot came from.) */
+                        const uint32_t ea = row[k] + chainHashSlot(ks[k], w0 & 0xFFu) + a.extDelta;
+                        u32x4 e = {0, 0, 0, 0};
+                        uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+                        if (ok & isLong) {
+                            if (TEX) e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ea * 16u), 0, 0);      /* the units are not among the hot rows */
+                            else e = a.chainSlots[ea];
+                            fetch16(q[k] + 8u, y0, y1, y2, y3);
+                        }
+                        const uint32_t c0 = __builtin_amdgcn_alignbyte(e.x, s.w, 3), c1 = __builtin_amdgcn_alignbyte(e.y, e.x, 3),
+                                       c2 = __builtin_amdgcn_alignbyte(e.z, e.y, 3), c3 = __builtin_amdgcn_alignbyte(e.w, e.z, 3);
+                        const uint32_t n = len - 7u;                   /* 1..16 bytes from header byte 7 on */
+                        const uint64_t lo = ((uint64_t)(y1 ^ c1) << 32) | (y0 ^ c0), hi = ((uint64_t)(y3 ^ c3) << 32) | (y2 ^ c2);
+                        ok &= !isLong || (lowBytesZero(lo, n < 8u ? n : 8u) && lowBytesZero(hi, n > 8u ? n - 8u : 0u));
+                    }
                 }
-                const bool leaf = (meta & pfac::kSlotLeaf) != 0;
+                const bool leaf = (meta & pfac::kSlotKMask) == 0;
                 const int id = (int)(leaf ? s.y : s.w);
                 match[k] = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match[k];
                 row[k] = s.y;
@@ -2084,7 +2259,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.hashValBytes = clampExtent(c->h_hashVal.size() * sizeof(Int2));
     a.chainSlots = reinterpret_cast<const u32x4 *>(c->d_chainSlots);
     a.jumpShift = 32u - (uint32_t)c->chainJumpLog2;
-    a.jumpBase = (uint32_t)(c->numChainSlots - (size_t(1) << c->chainJumpLog2));
+    a.extDelta = (uint32_t)(c->numChainSlots / 2);                         /* headers, then as many extension units (tables.cpp) */
+    a.jumpBase = (uint32_t)(c->numChainSlots / 2 - (size_t(1) << c->chainJumpLog2));
     a.rootRow = a.jumpBase - (uint32_t)pfac::kCharSet;
     a.chainBytes = clampExtent(c->numChainSlots * sizeof(pfac::ChainSlot));
     a.initialRow = c->d_initialRow;

@@ -115,7 +115,8 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  *   - a slot carries the bucket {offset, k, S} of the state the walker will be in next, so a transition needs ONE
  *     dependent 16-byte load;
  *   - a slot carries the single-successor chain that follows `next`: while the current state is not final and has
- *     exactly one outgoing transition, the byte of that transition is appended (up to kChainMax bytes) and the state
+ *     exactly one outgoing transition, the byte of that transition is appended (up to kChainMax bytes; up to kChainMaxWide
+ *     in a WIDE bucket, whose slots keep the bytes behind the eighth in their extension units: pfac_context.h) and the state
  *     advances.  The walker compares the chain against the input and lands directly in the end state.  Skipping is
  *     exact: the skipped states are not final, so they could not have changed the reported match, and a mismatch
  *     anywhere in the chain is the trap state (PFAC_CPU.cpp:76-96);
@@ -129,7 +130,11 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * and such a slot's chain is cut to <= 3 bytes (the cut lands on a non-final chain state; the next slot carries on
  * from there).
  *
- * Behind the buckets the array carries two more regions:
+ * The array is N slot headers followed by N EXTENSION UNITS, unit i (at N + i) belonging to slot i: a slot of a wide bucket
+ * keeps its chain bytes 8..22 there (pfac_context.h).  The headers lie exactly where the table of rounds 2-4 had them --
+ * what a walk touches while it follows no long single-successor run is unchanged --, and a unit is only ever fetched for
+ * a long slot (or, by a walker that has found its stream to be full of near misses, together with the header).
+ * Behind the buckets the headers carry two more regions:
  *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 128, S = 256);
  *   [jumpBase, jumpBase + 2^J) the JUMP table: one slot per 4-byte pattern prefix whose first three states are not
  *                              final, at hash(prefix), encoded as a transition on the first byte with the other
@@ -142,14 +147,26 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  */
 namespace {
 
+#ifndef PFAC_WIDE_BUCKETS
+#define PFAC_WIDE_BUCKETS 1                    /* 0: no wide buckets (every chain <= kChainMax: the table of rounds 2-4) */
+#endif
+
+/* a slot as the builder makes it: the 16-byte header and the chain bytes 8..22 that go to the slot's extension unit */
+struct BuiltSlot {
+    ChainSlot hdr;
+    unsigned char ext[16];
+};
+
 struct ChainBuilder {
     const Automaton &fa;
     std::vector<ChainSlot> &slots;                 /* the buckets; root row and jump table are appended at the end */
+    std::vector<ChainSlot> units;                  /* the extension unit of every slot of `slots` (zeros but for the long slots) */
     std::vector<int> bucketOff;                    /* per state: first slot of its bucket, -1 = none yet */
-    std::vector<uint32_t> bucketKS;                /* per state: k << 8 | (S - 1) */
+    std::vector<uint32_t> bucketKS;                /* per state: wide << 16 | k << 8 | (S - 1) */
     static int chainSlotIn(int k, int ch, int S) { return ((k * ch) >> 7) & (S - 1); }     /* pfac::chainSlotOf */
     std::vector<int> pending;                      /* states whose bucket is allocated but not filled, in allocation order */
     bool failed = false;
+    size_t wideBuckets = 0, longSlots = 0;
 
     ChainBuilder(const Automaton &a, std::vector<ChainSlot> &out)
         : fa(a), slots(out), bucketOff((size_t)a.numStates, -1), bucketKS((size_t)a.numStates, 0u) {}
@@ -162,9 +179,28 @@ struct ChainBuilder {
         s.endRow = -1;
         return s;
     }
+    static ChainSlot zeroUnit()
+    {
+        ChainSlot s;
+        std::memset(&s, 0, sizeof(s));
+        return s;
+    }
     int fanout(int s) const { return fa.edgeBegin[s + 1] - fa.edgeBegin[s]; }
 
-    /* the bucket of a state with successors: allocated on first use */
+    /* single-successor, non-final states in a row from `state` on (what a slot into `state` can fold), up to `limit` */
+    int naturalChain(int state, int limit) const
+    {
+        int k = 0;
+        while (k < limit && state > fa.numPatterns && fanout(state) == 1) {
+            state = fa.edgeNext[fa.edgeBegin[state]];
+            k++;
+        }
+        return k;
+    }
+
+    /* the bucket of a state with successors: allocated on first use.  WIDE (its slots may fold up to kChainMaxWide chain
+     * bytes, those behind the eighth in the slot's extension unit) if one of its transitions is followed by more
+     * single-successor bytes than a header holds: a walk through such a run then takes 24 bytes per step instead of 8. */
     void needBucket(int state)
     {
         if (bucketOff[state] >= 0) return;
@@ -187,43 +223,56 @@ struct ChainBuilder {
             if (k >= 0) break;
         }
         if (k < 0) { failed = true; return; }      /* cannot happen: k = 128, S = 256 is the identity */
+        bool wide = false;
+        if (PFAC_WIDE_BUCKETS)
+            for (int i = b; i < e && !wide; i++) wide = naturalChain(fa.edgeNext[i], kChainMax + 1) > kChainMax;
         bucketOff[state] = (int)slots.size();
-        bucketKS[state] = ((uint32_t)k << 8) | (uint32_t)(S - 1);
+        bucketKS[state] = ((uint32_t)wide << 16) | ((uint32_t)k << 8) | (uint32_t)(S - 1);
         slots.resize(slots.size() + (size_t)S, emptySlot());
+        units.resize(slots.size(), zeroUnit());
+        if (wide) wideBuckets++;
         pending.push_back(state);
     }
 
-    /* the slot of the transition on byte ch into state `next`; forced: the first chain bytes are given (a path through
-     * non-final states that may branch: the jump slots) and `next` is the state behind them */
-    ChainSlot makeSlot(int ch, int next, const unsigned char *forced = nullptr, int numForced = 0)
+    /* the slot of the transition on byte ch into state `next`, folding at most `cap` chain bytes (kChainMax, or kChainMaxWide
+     * for a slot of a wide bucket); forced: the first chain bytes are given (a path through non-final states that may
+     * branch: the jump slots) and `next` is the state behind them */
+    BuiltSlot makeSlot(int ch, int next, int cap, const unsigned char *forced = nullptr, int numForced = 0)
     {
-        ChainSlot s = emptySlot();
-        if (next < 0) return s;
+        BuiltSlot out;
+        out.hdr = emptySlot();
+        std::memset(out.ext, 0, sizeof(out.ext));
+        ChainSlot &s = out.hdr;
+        if (next < 0) return out;
+        unsigned char chain[kChainMaxWide + 1];
         auto follow = [&](int limit, int &end) {
             int k = 0;
-            for (; k < numForced; k++) s.chain[k] = forced[k];
+            std::memset(chain, 0, sizeof(chain));
+            for (; k < numForced; k++) chain[k] = forced[k];
             end = next;
             while (k < limit && end > fa.numPatterns && fanout(end) == 1) {
-                s.chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
+                chain[k++] = fa.edgeCh[fa.edgeBegin[end]];
                 end = fa.edgeNext[fa.edgeBegin[end]];
             }
             return k;
         };
         int cur;
-        int k = follow(kChainMax, cur);
-        if (cur <= fa.numPatterns && fanout(cur) > 0 && k > 3) {         /* final with successors: the ID needs chain[4..7] */
-            std::memset(s.chain, 0, sizeof(s.chain));
-            k = follow(3, cur);
-        }
+        int k = follow(cap, cur);
+        if (cur <= fa.numPatterns && fanout(cur) > 0 && k > 3)          /* final with successors: the ID needs chain[4..7]: the chain is cut so that the */
+            k = follow(k >= 8 ? k - 4 : 3, cur);                         /* NEXT slot reaches that state with <= 3 chain bytes (the cut lands on a non-final chain state) */
         const bool leaf = fanout(cur) == 0;
         const bool fin = cur <= fa.numPatterns;
         if (!leaf) needBucket(cur);
-        const uint32_t hashK = leaf ? 0u : bucketKS[cur] >> 8;           /* 1..256 */
-        const uint32_t sizeMask = leaf ? 0u : bucketKS[cur] & 0xFFu;     /* S-1 <= 255 */
-        s.meta = (uint32_t)ch | ((uint32_t)k << 8) | (fin ? kSlotFinal : 0u) | (leaf ? kSlotLeaf : 0u) | (hashK << 16) | (sizeMask << 24);
+        const uint32_t hashK = leaf ? 0u : (bucketKS[cur] >> 8) & 0xFFu;        /* 1..255; 0 = leaf */
+        const uint32_t sizeMask = leaf ? 0u : bucketKS[cur] & 0xFFu;             /* S-1 <= 255 */
+        const bool wideEnd = !leaf && (bucketKS[cur] >> 16) != 0;
+        s.meta = (uint32_t)ch | ((uint32_t)k << kSlotLenShift) | (fin ? kSlotFinal : 0u) | (wideEnd ? kSlotWide : 0u) | (hashK << 16) | (sizeMask << 24);
         s.endRow = leaf ? (fin ? cur : -1) : bucketOff[cur];
-        if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));
-        return s;
+        std::memcpy(s.chain, chain, 8);
+        if (k > 8) std::memcpy(out.ext, chain + 8, (size_t)(k - 8));
+        if (fin && !leaf) std::memcpy(s.chain + 4, &cur, sizeof(int));           /* k <= 3 here */
+        if (k > kChainMax) longSlots++;
+        return out;
     }
 
     /* fill the buckets allocated so far, and those their slots allocate, breadth first */
@@ -231,10 +280,13 @@ struct ChainBuilder {
     {
         for (size_t at = 0; at < pending.size() && !failed; at++) {
             const int state = pending[at];
-            const int k = (int)(bucketKS[state] >> 8), S = (int)(bucketKS[state] & 0xFFu) + 1;
+            const int k = (int)((bucketKS[state] >> 8) & 0xFFu), S = (int)(bucketKS[state] & 0xFFu) + 1;
+            const bool wide = (bucketKS[state] >> 16) != 0;
             for (int e = fa.edgeBegin[state]; e < fa.edgeBegin[state + 1]; e++) {
-                const ChainSlot slot = makeSlot(fa.edgeCh[e], fa.edgeNext[e]);           /* may grow `slots` */
-                slots[(size_t)bucketOff[state] + (size_t)chainSlotIn(k, fa.edgeCh[e], S)] = slot;
+                const BuiltSlot slot = makeSlot(fa.edgeCh[e], fa.edgeNext[e], wide ? kChainMaxWide : kChainMax);   /* may grow `slots` */
+                const size_t at0 = (size_t)bucketOff[state] + (size_t)chainSlotIn(k, fa.edgeCh[e], S);
+                slots[at0] = slot.hdr;
+                std::memcpy(&units[at0], slot.ext, sizeof(slot.ext));
             }
         }
         pending.clear();
@@ -254,6 +306,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         if (fa.numStates <= init) {                                /* no patterns: root row + smallest jump table, all empty */
             jumpLog2 = kJumpLog2Min;
             slots.assign((size_t)kCharSet + (size_t(1) << jumpLog2), ChainBuilder::emptySlot());
+            slots.resize(2 * slots.size(), ChainBuilder::zeroUnit());
             return PFAC_STATUS_SUCCESS;
         }
         for (int e1 = fa.edgeBegin[init]; e1 < fa.edgeBegin[init + 1]; e1++) {
@@ -281,17 +334,20 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
         /* the top of the trie first: what the initial state's transitions land in, then what the jump slots land in,
          * then everything below, level by level */
-        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++) root[fa.edgeCh[e]] = b.makeSlot(fa.edgeCh[e], fa.edgeNext[e]);
+        for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++) root[fa.edgeCh[e]] = b.makeSlot(fa.edgeCh[e], fa.edgeNext[e], kChainMax).hdr;
         for (const Prefix &p : prefixes) {
             ChainSlot &dst = jump[jumpHash(p.key, jumpLog2)];
             if (!(dst.meta & kSlotEmpty)) continue;            /* taken: this prefix walks from the initial state */
             const unsigned char rest[3] = {(unsigned char)(p.key >> 8), (unsigned char)(p.key >> 16), (unsigned char)(p.key >> 24)};
-            dst = b.makeSlot((int)(p.key & 0xFFu), p.state, rest, 3);
+            dst = b.makeSlot((int)(p.key & 0xFFu), p.state, kChainMax, rest, 3).hdr;
         }
         b.drain();
         if (b.failed) return PFAC_STATUS_INTERNAL_ERROR;
         slots.insert(slots.end(), root.begin(), root.end());
         slots.insert(slots.end(), jump.begin(), jump.end());
+        /* the extension units, slot for slot: unit i belongs to slot i (root row and jump table never have one) */
+        b.units.resize(slots.size(), ChainBuilder::zeroUnit());
+        slots.insert(slots.end(), b.units.begin(), b.units.end());
     } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     return PFAC_STATUS_SUCCESS;
 }

@@ -546,10 +546,12 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
     info = h.info()
     h.destroy()
     J = info.chainJumpLog2
-    assert 10 <= J <= 20 and info.chainSlots == len(slots)
-    jump_base = len(slots) - (1 << J)
+    assert 10 <= J <= 20 and info.chainSlots == len(slots) and len(slots) % 2 == 0
+    ext_delta = len(slots) // 2                    # N slot headers, then N extension units: the unit of slot i at N + i
+    jump_base = ext_delta - (1 << J)
     root_row = jump_base - 256
-    EMPTY, LEAF, FINAL = 1 << 14, 1 << 13, 1 << 12
+    EMPTY, FINAL, WIDE = 1 << 14, 1 << 13, 1 << 15         # pfac_context.h: kSlotEmpty, kSlotFinal, kSlotWide; a leaf has k == 0
+    long_steps = 0
 
     def walk_all(stream, expect):
         nonlocal data
@@ -560,12 +562,12 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
         for i in range(limit):
             x = int.from_bytes(data[i:i + 4], "little")
             match = 0
-            ok, leaf, ident, row, ks, used = step(slots[jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J))], data[i], i + 1)
+            ok, leaf, ident, row, ks, used = step(jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J)), False, data[i], i + 1)
             if ok:
                 used_jump += 1
             else:                                  # restart in the initial state's bucket (k = 128, S = 256: the byte itself)
                 fell_back += 1
-                ok, leaf, ident, row, ks, used = step(slots[root_row + data[i]], data[i], i + 1)
+                ok, leaf, ident, row, ks, used = step(root_row + data[i], False, data[i], i + 1)
             depth = 0
             while ok:
                 if ident:
@@ -575,19 +577,28 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
                     break
                 b0 = data[i + depth]
                 r = ((((ks >> 16) & 0xFF) * b0) >> 7) & (ks >> 24)        # pfac_context.h: chainSlotOf
-                ok, leaf, ident, row, ks, used = step(slots[row + r], b0, i + depth + 1)
+                ok, leaf, ident, row, ks, used = step(row + r, bool(ks & WIDE), b0, i + depth + 1)   # only the slots of WIDE buckets may be long
             assert match == int(expect[i]), (name, perf, i, match, int(expect[i]))
         return used_jump, fell_back
 
     data = b""
 
-    def step(slot, b0, p):
-        """transition on edge byte b0 with the input behind it at p: (ok, leaf, match id or 0, end row, ks, bytes consumed)"""
+    def step(at, wide, b0, p):
+        """transition through the slot at index `at` (wide: the slot that led here says its bucket may hold long slots) on edge
+        byte b0 with the input behind it at p: (ok, leaf, match id or 0, end row, ks, bytes consumed)"""
+        nonlocal long_steps
+        slot = slots[at]
         meta = int(slot[0])
-        ln = (meta >> 8) & 0xF
+        ln = (meta >> 8) & 0x1F
         chain = int(slot[2]).to_bytes(4, "little") + int(slot[3]).to_bytes(4, "little")
+        if ln > 7:                                 # only slots of wide buckets fold more than 7 bytes: 8 in the header, the rest in the unit
+            assert wide and ln <= 23
+            chain += b"".join(int(v).to_bytes(4, "little") for v in slots[at + ext_delta])
+        else:
+            assert not slots[at + ext_delta].any()     # the unit of a short slot is never written
+            long_steps += 1
         ok = (meta & (EMPTY | 0xFF)) == b0 and chain[:ln] == data[p:p + ln]
-        leaf = bool(meta & LEAF)
+        leaf = (meta >> 16) & 0xFF == 0
         ident = 0
         if ok and meta & FINAL:
             ident = int(slot[1]) if leaf else int(slot[3])
@@ -596,6 +607,8 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
     used_jump, fell_back = walk_all(w.data[:30000], oracle_results[name])
     if name in ("c2", "c3"):
         assert used_jump > 0                       # the stream does contain 4-byte pattern prefixes
+    if name == "c5":
+        assert long_steps > 0                      # the near-miss stream walks the long single-successor runs: wide buckets
     if name == "c2":
         # 1000 random prefixes in 8192 slots: some collide.  A pattern whose prefix lost its slot must be found
         # through the restart: a stream of exactly those patterns, against the oracle

@@ -155,11 +155,14 @@ typedef struct {
                                              output kernel differ)                                              */
     unsigned long long ladderCandidates;  /* level-1 hits whose first four bytes are a pattern prefix (or a short
                                              pattern): what the prefix ladder was asked about                  */
-    unsigned long long denseChunks;       /* 2 KiB chunks in which more than 90 % of the positions passed level 1:
+    unsigned long long denseChunks;       /* 2 KiB chunks in which more than half of the positions (PFAC_DENSE_HITS of 2048) passed level 1:
                                              left to the tiled kernel that follows the filter kernel (0 for a
                                              compacted-output launch, which lists none)                         */
     double filterKernelMs;                /* GPU time of that launch of the filter kernel alone (HIP events around it);
                                              -1 unless PFACX_setKernelTiming(handle, 1) was in force           */
+    unsigned long long stageModeWaves;    /* full-result launch: scanning waves that ended it in STAGE mode (their stream was full
+                                             of deep walks -- near misses of long patterns --, so they kept two chunks staged and
+                                             walked out of LDS); the next launch on the handle starts in the majority's mode  */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);

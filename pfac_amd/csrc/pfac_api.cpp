@@ -1244,7 +1244,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
     std::lock_guard<std::mutex> guard(handle->lock);
     if (!handle->hasDevice || !handle->d_workCounters) return PFAC_STATUS_LIB_NOT_EXIST;
-    unsigned long long v[pfac::kStatsCount + 2];             /* published by the last block of the launch: scan_gfx950.hip, the kernel's end */
+    unsigned long long v[pfac::kStatsCount + 3];             /* published by the last block of the launch: scan_gfx950.hip, the kernel's end */
     if (hipStreamSynchronize(nullptr) != hipSuccess ||
         hipMemcpy(v, handle->d_workCounters + pfac::kStatsPublishedWord, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
         return PFAC_STATUS_INTERNAL_ERROR;
@@ -1260,6 +1260,7 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     }
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = (int)v[pfac::kStatsCount + 1];     /* of the launch the counters describe: the full-result and the compacted-output kernel differ */
+    stats->stageModeWaves = v[pfac::kStatsCount + 2];
     return PFAC_STATUS_SUCCESS;
 }
 

@@ -40,6 +40,9 @@ constexpr int kDenseCountWord = 32 * 32;         /* line 32 / 34: dense chunks l
 constexpr int kDenseCountWordB = 34 * 32;
 constexpr int kDoneWord = 33 * 32;               /* blocks of the running filter launch that have finished: the last one publishes the statistics and leaves
                                                     every counter zero for the next launch (no memset in front of a launch) */
+constexpr int kModeHintWord = 35 * 32;           /* full-result filter kernel: 1 = most scanning waves of the last launch ended it in stage mode (near-miss stream): the next
+                                                    launch on this handle starts there (scan_gfx950.hip: StageLane); kModeVotesWord counts them during a launch */
+constexpr int kModeVotesWord = 36 * 32;
 constexpr int kStatsPublishedWord = 48 * 32;     /* 64-bit: the kStatsCount statistics of the last finished filter launch, then its dense chunks */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */

@@ -98,6 +98,7 @@
 #include <mutex>
 
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 #include "pfac_context.h"
@@ -141,11 +142,13 @@ struct ScanArgs {
     const Int2 *hashVal;
     const u32x4 *chainSlots;                           /* pfac::ChainSlot[], 16 bytes each               */
     uint32_t extDelta;                                 /* the extension unit of slot i is chainSlots[i + extDelta] (long slots of wide buckets: pfac_context.h) */
+    uint32_t jumpLongBase;                             /* the long jump table (same hash, slots with chains of up to kChainMaxWide bytes) */
     uint32_t rootRow, jumpBase, jumpShift;             /* inside chainSlots: the initial state's bucket (256 slots, indexed by the byte)
                                                           and the jump table (2^(32 - jumpShift) slots): tables.cpp */
     uint32_t denseBytes, hashRowBytes, hashValBytes, chainBytes;     /* buffer-resource extents */
     uint32_t maxWalk;                                  /* longest pattern: no walk reads further from its start position */
-    uint32_t hotSlots;                                 /* tiled kernel: the first hotSlots slots of chainSlots (the buckets the initial state's transitions land in,
+    uint32_t hotSlots;                                 /* tiled kernel, and the full-result filter kernel with what LDS its bitmaps and buffers leave (small pattern sets):
+                                                          the first hotSlots slots of chainSlots (the buckets the initial state's transitions land in,
                                                           breadth first) are copied to LDS by every block */
     const int *initialRow;
     const uint32_t *gram3;
@@ -311,11 +314,12 @@ template <bool TEX> struct ChainCtx {
     const u32x4 *slots;
     __amdgpu_buffer_rsrc_t rsrc;
     const uint32_t *in32;
-    uint32_t rootRow, jumpBase, jumpShift, extDelta;
+    uint32_t rootRow, jumpBase, jumpShift, extDelta, jumpLongBase;
+    uint32_t hotAddr = 0, hotSlots = 0;                /* StageLane: the first hotSlots slot headers are in LDS at byte address hotAddr */
     __device__ ChainCtx(const ScanArgs &a)
         : slots(a.chainSlots),
           rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000)),
-          in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift), extDelta(a.extDelta) {}
+          in32(reinterpret_cast<const uint32_t *>(a.in)), rootRow(a.rootRow), jumpBase(a.jumpBase), jumpShift(a.jumpShift), extDelta(a.extDelta), jumpLongBase(a.jumpLongBase) {}
 };
 constexpr uint32_t kRootKs = pfac::kChainRootMeta;      /* the initial state's bucket: k = 128, S = 256 -- the slot of byte b is b */
 
@@ -339,18 +343,27 @@ constexpr uint32_t kEntryBytesFull = 36;       /* ... full-result kernel: 16 mor
 __device__ __forceinline__ uint32_t slotLen(uint32_t meta) { return __builtin_amdgcn_ubfe(meta, pfac::kSlotLenShift, 5u); }
 /* the low n (0..8) bytes of d are zero */
 __device__ __forceinline__ bool lowBytesZero(uint64_t d, uint32_t n) { return n >= 8u ? d == 0 : ((d << 8) << (56u - 8u * n)) == 0; }
-/* byte i (0..15) of the 16 bytes y0..y3 */
+/* byte i (0..15) of the 16 bytes y0..y3: v_perm_b32 takes its byte selector from a register */
 __device__ __forceinline__ uint32_t byteOf16(uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t i)
 {
-    const uint32_t lo = (i & 4u) ? y1 : y0, hi = (i & 4u) ? y3 : y2;
-    return (((i & 8u) ? hi : lo) >> (8u * (i & 3u))) & 0xFFu;
+    const bool up = (i & 8u) != 0;
+    return __builtin_amdgcn_perm(up ? y3 : y1, up ? y2 : y0, i & 7u) & 0xFFu;
 }
-/* chain bytes 8 .. len-1 of a long slot (extension unit e) against the input bytes 8 .. 23 behind the edge byte (y0..y3), 8 <= len <= 23 */
+/* bit number of the lowest set bit, 0xFFFFFFFF if there is none (v_ffbl_b32; __builtin_ctz is undefined for 0) */
+__device__ __forceinline__ uint32_t lowestBit(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+/* chain bytes 8 .. len-1 of a long slot (extension unit e) against the input bytes 8 .. 23 behind the edge byte (y0..y3), 8 <= len <= 23:
+ * the first bit in which the 16 bytes differ (the dword's number folded into the bit number; no difference: 0xFFFFFFFF) must lie
+ * behind the len - 8 bytes that count */
 __device__ __forceinline__ bool extensionEqual(const u32x4 &e, uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t len)
 {
-    const uint32_t n = len - 8u;                                   /* 0..15 bytes */
-    const uint64_t lo = ((uint64_t)(y1 ^ e.y) << 32) | (y0 ^ e.x), hi = ((uint64_t)(y3 ^ e.w) << 32) | (y2 ^ e.z);
-    return lowBytesZero(lo, n < 8u ? n : 8u) & lowBytesZero(hi, n > 8u ? n - 8u : 0u);
+    const uint32_t b0 = lowestBit(y0 ^ e.x), b1 = lowestBit(y1 ^ e.y) | 32u, b2 = lowestBit(y2 ^ e.z) | 64u, b3 = lowestBit(y3 ^ e.w) | 96u;
+    const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
+    return (m01 < m23 ? m01 : m23) >= 8u * (len - 8u);
 }
 
 template <bool TEX, uint32_t ENTRY> struct ChainLane {
@@ -566,6 +579,202 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
     }
 };
 
+/*
+ * StageLane -- the walker of the full-result kernel (round 5).  Same split-phase protocol and the same transitions as
+ * ChainLane, but the INPUT of a walk is read IN PLACE from the wave's LDS: a step reads the 12 (long slot: 28) bytes behind
+ * its edge byte with three (seven) aligned LDS reads.  That replaces the nine-dword register window with its
+ * 15-to-35-instruction shifter and every gathered window load.  Where in LDS depends on what the wave's stream looks like
+ * (the kernel switches at moments when no walk is under way):
+ *   TEXT mode   a queue entry is the candidate's offset in the staged chunk; when a lane takes it -- in the next trip of the
+ *               loop, before the next chunk is staged -- the candidate's first kWalkEntryBytes input bytes are copied to the
+ *               lane's own 32 bytes of LDS, and the walk reads those.  Text has few walks per chunk, all shallow, and a wave
+ *               filters a chunk per trip of its loop.
+ *   STAGE mode  (near-miss streams: BASELINE config 5) the wave keeps the last TWO chunks it filtered staged, each with the
+ *               kWalkHalo bytes behind it, an entry is just {buffer, offset}, a walk reads the stage however deep it goes; a
+ *               buffer is overwritten when no walk reads it any more.  There a chunk has dozens of walks 30 to 60 bytes deep:
+ *               on that stream a third of a walk's gathered loads were window loads, and gathered loads (the CU's address
+ *               path) and instruction issue are what the launch is bound by (profiles/r05_experiments.md).
+ * A walk that runs off its entry / its stage loads input from global memory, waited for on the spot (text mode: deeper than
+ * 19 bytes; stage mode: more than kWalkHalo bytes behind its chunk, i.e. patterns longer than ~100 bytes).
+ */
+#ifndef PFAC_STAGE_WALK
+#define PFAC_STAGE_WALK 1                      /* 0: the full-result kernel walks with ChainLane's register window (rounds 2-4) */
+#endif
+constexpr uint32_t kWalkHalo = 128;            /* bytes behind a chunk that are staged with it (full-result kernel) */
+constexpr uint32_t kWalkStageBytes = (uint32_t)pfac::kChunkTiles * 1024u + kWalkHalo;
+constexpr uint32_t kWalkEntryBytes = 32;       /* text mode: input bytes a queue entry carries */
+constexpr int kWalkReachShort = 13, kWalkReachLong = 29;   /* bytes from the edge byte on that a step reads (as whole dwords): 1 + 8 (+ 3), long slot: 1 + 24 (+ 3) */
+struct StageView {                             /* the wave's two stage buffers (wave-uniform); in text mode the second one holds the entries' bytes */
+    uint32_t addr[2];                          /* LDS byte address */
+    uint32_t base[2];                          /* position of the staged chunk's first byte in this launch's input */
+};
+__device__ __forceinline__ uint32_t ldsWord(uint32_t byteAddr) { return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(byteAddr); }
+
+template <bool TEX> struct StageLane {
+    using Ctx = ChainCtx<TEX>;
+    static constexpr bool kSpec = true;        /* wide buckets: header and extension unit can be fetched together (the wave decides: see the kernel) */
+    uint32_t pos = 0;
+    uint32_t sq = 0;                           /* LDS byte address of the edge byte */
+    int rem = 0;                               /* bytes that can be read from LDS from the edge byte on */
+    uint32_t delta = 0;                        /* position in the input = LDS address + delta */
+    uint32_t row = 0;                          /* first slot of the current state's bucket */
+    int match = 0;
+    uint32_t ks = 0, b0 = 0;
+    u32x4 t = {0, 0, 0, 0};
+    u32x4 E;                                   /* the extension unit of the slot in flight (no initial value: see ChainLane) */
+    bool inB = false;                          /* stage mode: which of the two stage buffers the walk reads */
+    bool needSlot = true;
+    bool haveE = false, needExt = false, usedE = false;
+    bool first = false;                        /* the slot in flight comes from the jump table */
+    bool ranOff = false;                       /* this step read its input from global memory */
+
+    __device__ __forceinline__ u32x4 loadSlot(const Ctx &c, uint32_t idx) const
+    {
+        if (TEX) return __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(idx * 16u), 0, PFAC_SLOT_AUX);
+        return c.slots[idx];
+    }
+    /* longJump (wave-uniform): the wave expects long slots: the walk starts in the LONG jump table, whose slots fold up to 23
+     * bytes behind the edge byte (the unit comes with the header: ks says "wide") */
+    __device__ __forceinline__ void begin(const Ctx &c, uint32_t key, const uint32_t *shortBits, bool longJump)
+    {
+        match = 0;
+        b0 = key & 0xFFu;
+        needSlot = true; haveE = false; needExt = false;
+        /* a pattern of one or two bytes matches here: the prefix passes a final state, so it has no jump slot (ChainLane::start) */
+        const bool viaRoot = shortBits != nullptr && testBit(shortBits, key & 0xFFFFu) != 0;
+        first = !viaRoot;
+        row = viaRoot ? c.rootRow : (longJump ? c.jumpLongBase : c.jumpBase) + ((key * pfac::kJumpMul) >> c.jumpShift);
+        ks = viaRoot ? kRootKs : (longJump ? pfac::kSlotWide : 0u);
+    }
+    /* stage mode: code = buffer << 31 | offset of the candidate in its chunk */
+    __device__ __forceinline__ void startStage(const Ctx &c, const StageView &v, uint32_t code, const uint32_t *shortBits, bool longJump)
+    {
+        inB = (code >> 31) != 0;
+        const uint32_t off = code & 0x7FFFFFFFu;
+        sq = (inB ? v.addr[1] : v.addr[0]) + off;
+        rem = (int)(kWalkStageBytes - off);
+        pos = (inB ? v.base[1] : v.base[0]) + off;
+        delta = pos - sq;
+        const uint32_t a4 = sq & ~3u;
+        begin(c, __builtin_amdgcn_alignbyte(ldsWord(a4 + 4u), ldsWord(a4), sq & 3u), shortBits, longJump);
+    }
+    /* text mode: off = offset of the candidate in the chunk staged at v.addr[0]; its first kWalkEntryBytes bytes are copied to
+     * the lane's own place `mine` (dword aligned), where the walk reads them however long the chunk stays staged */
+    __device__ __forceinline__ void startText(const Ctx &c, const StageView &v, uint32_t off, uint32_t mine, const uint32_t *shortBits, bool longJump)
+    {
+        inB = false;
+        const uint32_t src = v.addr[0] + off, a4 = src & ~3u, sh = src & 3u;
+        uint32_t d[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = ldsWord(a4 + 4u * (uint32_t)k);
+        u32x4 lo, hi;
+        lo.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh); lo.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+        lo.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh); lo.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+        hi.x = __builtin_amdgcn_alignbyte(d[5], d[4], sh); hi.y = __builtin_amdgcn_alignbyte(d[6], d[5], sh);
+        hi.z = __builtin_amdgcn_alignbyte(d[7], d[6], sh); hi.w = __builtin_amdgcn_alignbyte(d[8], d[7], sh);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(mine) = lo;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(mine + 16u) = hi;
+        sq = mine;
+        rem = (int)kWalkEntryBytes;
+        pos = v.base[0] + off;
+        delta = pos - mine;
+        begin(c, lo.x, shortBits, longJump);
+    }
+    __device__ __forceinline__ void issue(const Ctx &c, bool spec)
+    {
+        if (needSlot) {
+            const uint32_t idx = row + chainHashSlot(ks, b0);
+            /* the top of the table (breadth first) is in LDS, as far as the block's LDS reaches -- every bucket of a small pattern
+             * set --: such a header is read in consume(), with the input bytes (read here, into the registers a gathered load may
+             * still be writing, it would have to wait for that load) */
+            if (idx >= c.hotSlots) t = loadSlot(c, idx);
+            haveE = spec & ((ks & pfac::kSlotWide) != 0);
+            if (haveE) E = loadSlot(c, idx + c.extDelta);
+        } else if (needExt) {                                  /* the header in t is a long slot whose unit did not come with it */
+            E = loadSlot(c, row + chainHashSlot(ks, b0) + c.extDelta);
+            haveE = true;
+        }
+    }
+    /* 32 input bytes from position g on, from global memory, waited for on the spot: x0:x1 = bytes 0..7, y0..y3 = bytes 8..23 */
+    __device__ __forceinline__ void loadDeep(const Ctx &c, uint32_t g, uint32_t &x0, uint32_t &x1, uint32_t &y0, uint32_t &y1, uint32_t &y2, uint32_t &y3) const
+    {
+        const u32x4 g0 = loadWindow16(c.in32, g), g1 = loadWindow16(c.in32, g + 16u);
+        const uint32_t gs = g & 3u;
+        x0 = __builtin_amdgcn_alignbyte(g0.y, g0.x, gs); x1 = __builtin_amdgcn_alignbyte(g0.z, g0.y, gs);
+        y0 = __builtin_amdgcn_alignbyte(g0.w, g0.z, gs); y1 = __builtin_amdgcn_alignbyte(g1.x, g0.w, gs);
+        y2 = __builtin_amdgcn_alignbyte(g1.y, g1.x, gs); y3 = __builtin_amdgcn_alignbyte(g1.z, g1.y, gs);
+    }
+    __device__ __forceinline__ bool consume(const Ctx &c)
+    {
+        const uint32_t a = sq + 1u;                            /* first byte behind the edge byte */
+        const uint32_t a4 = a & ~3u, sh = a & 3u;
+        const uint32_t d0 = ldsWord(a4), d1 = ldsWord(a4 + 4u), d2 = ldsWord(a4 + 8u);
+        {   /* a header among the hot rows (issue() did not fetch it): row, ks and b0 still describe the bucket it is in */
+            const uint32_t idx = row + chainHashSlot(ks, b0);
+            if (idx < c.hotSlots) t = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(c.hotAddr + idx * 16u);
+        }
+        const uint32_t meta = t.x;
+        const uint32_t len = slotLen(meta);
+        const bool mine = (meta & (pfac::kSlotEmpty | 0xFFu)) == b0;
+        const bool isLong = len > (uint32_t)pfac::kChainMax;
+        const uint32_t lenIn = isLong ? (uint32_t)pfac::kChainMax : len;
+        uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        const bool deep = rem < kWalkReachShort;               /* the walk has run off its entry / its stage */
+        ranOff = deep;
+        if (__ballot(deep) != 0) {
+            asm volatile("; pfac_deep_sync" ::: "memory");
+            if (deep) loadDeep(c, a + delta, x0, x1, y0, y1, y2, y3);
+        }
+        const uint64_t diff = ((uint64_t)(x1 ^ t.w) << 32) | (x0 ^ t.z);
+        bool ok = mine & (((diff << 8) << (56u - 8u * lenIn)) == 0);
+        needExt = isLong & ok & !haveE;                        /* a long slot whose header bytes match, its unit not here: fetch it and come back */
+        usedE = haveE & mine & isLong;
+        needSlot = !needExt;
+        bool cont = true;
+        if (needExt) ok = true;
+        if (!needExt) {
+            uint32_t next = (uint32_t)((((uint64_t)x1 << 32) | x0) >> (8u * lenIn)) & 0xFFu;
+            if (__ballot(ok & isLong) != 0) {
+                /* long slots (wide buckets): header byte 7, then chain bytes 8 .. len-1 in the extension unit against the
+                 * input bytes 8 .. 23 behind the edge byte; the next edge byte is one of those */
+                const bool deepLong = (rem < kWalkReachLong) & !deep & ok & isLong;
+                ranOff |= deepLong;
+                if (__ballot(deepLong) != 0) {
+                    asm volatile("; pfac_deep_sync" ::: "memory");
+                    uint32_t u0, u1;
+                    if (deepLong) loadDeep(c, a + delta, u0, u1, y0, y1, y2, y3);
+                }
+                const uint32_t d3 = ldsWord(a4 + 12u), d4 = ldsWord(a4 + 16u), d5 = ldsWord(a4 + 20u), d6 = ldsWord(a4 + 24u);
+                const uint32_t f0 = __builtin_amdgcn_alignbyte(d3, d2, sh), f1 = __builtin_amdgcn_alignbyte(d4, d3, sh),
+                               f2 = __builtin_amdgcn_alignbyte(d5, d4, sh), f3 = __builtin_amdgcn_alignbyte(d6, d5, sh);
+                if (__ballot(ranOff) == 0) {                   /* the usual case: nobody's bytes came from global memory */
+                    y0 = f0; y1 = f1; y2 = f2; y3 = f3;
+                } else {
+                    const bool fromLds = rem >= kWalkReachLong;
+                    y0 = fromLds ? f0 : y0; y1 = fromLds ? f1 : y1; y2 = fromLds ? f2 : y2; y3 = fromLds ? f3 : y3;
+                }
+                const bool okLong = (((x1 ^ t.w) >> 24) == 0) & extensionEqual(E, y0, y1, y2, y3, len);
+                ok &= !isLong | okLong;
+                next = isLong ? byteOf16(y0, y1, y2, y3, len - 8u) : next;
+            }
+            const bool leaf = (meta & pfac::kSlotKMask) == 0;
+            const int id = (int)(leaf ? t.y : t.w);
+            match = (ok & ((meta & pfac::kSlotFinal) != 0)) ? id : match;
+            /* the jump table does not know these four bytes: the walk starts over in the initial state's bucket, on the same edge byte */
+            const bool restart = first & !ok;
+            row = restart ? c.rootRow : t.y;
+            ks = restart ? kRootKs : meta;
+            sq = restart ? sq : sq + 1u + len;
+            rem = restart ? rem : rem - (int)(1u + len);
+            b0 = restart ? b0 : next;
+            cont = restart | (ok & !leaf);
+        }
+        first = false;
+        return cont;
+    }
+};
+
 /* The longest pattern that starts at in[p], walked through the chained table from the initial state's bucket with every
  * read checked against `readable` (a pattern that would run past the input does not match: ref PFAC_CPU.cpp:60-100, the
  * walk stops at the last byte).  Same transition rule as ChainLane::advance, one byte compare at a time: for the few
@@ -712,6 +921,19 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
     return v;
 }
 
+/* minimum over the 64 lanes (same DPP ladder; lanes without a source keep their own value) */
+__device__ __forceinline__ uint32_t waveMin(uint32_t v)
+{
+    auto step = [](uint32_t x, uint32_t y) { return y < x ? y : x; };
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 /* vector registers the compiler may use in the filter kernel, HALVED (on gfx90a and later the attribute counts a
  * unified VGPR + AGPR budget of twice its value; the kernel uses no AGPRs): v0..v117.  v119..v127 hold the chunk
  * in flight (prefetchChunk). */
@@ -729,7 +951,13 @@ void pfac_scan_filter(ScanArgs a)
     constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
     using WCtx = ChainCtx<TEX>;
     constexpr uint32_t kEntry = REDUCE ? kEntryBytes : kEntryBytesFull;
-    using WLane = ChainLane<TEX, kEntry>;
+    /* full-result kernel: walks read their input from the wave's two staged chunks (StageLane), a queue entry is {buffer, offset};
+     * compacted-output kernel (16 scanning waves, no LDS to spare): the input travels with the entry and lives in registers */
+    constexpr bool kStageWalk = !REDUCE && PFAC_STAGE_WALK != 0;
+    using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry>>;
+    constexpr int kStageWordsK = kStageWalk ? (int)(kWalkStageBytes / 4) : kStageWords;     /* words of one stage buffer */
+    constexpr int kStageBufs = kStageWalk ? 2 : 1;
+    constexpr int kHaloDwords = kStageWalk ? (int)(kWalkHalo / 4) : 12;                      /* dwords behind the chunk that are staged with it */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int words3 = 1 << (a.log2Bits - 5), wordsLad = 1 << (a.log2BitsLad - 5), wordsF3 = 1 << (a.log2BitsF3 - 5);
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);
@@ -742,12 +970,13 @@ void pfac_scan_filter(ScanArgs a)
     Control *ctl = reinterpret_cast<Control *>(sShort + (HAS_SHORT ? 2048 : 0));
     uint32_t *sQueueAll = reinterpret_cast<uint32_t *>(ctl) + kControlWords;           /* 16-byte aligned */
     constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
-    uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * 4;            /* ... second part of the entries: input bytes 12..19 */
-    uint32_t *sQueueCAll = sQueueBAll + kScanners * kQCap * 2;           /* ... full-result kernel: input bytes 20..35 */
-    uint32_t *sStageAll = sQueueCAll + (REDUCE ? 0 : kScanners * kQCap * 4);   /* per scanning wave: the chunk being filtered + the 48 bytes behind it */
-    uint32_t *sListAll = sStageAll + kScanners * kStageWords;            /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
+    uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * (kStageWalk ? 1 : 4);   /* ... second part of the entries: input bytes 12..19 (kStageWalk: an entry is one word) */
+    uint32_t *sQueueCAll = sQueueBAll + (kStageWalk ? 0 : kScanners * kQCap * 2);  /* ... register-window walkers of a full-result build: input bytes 20..35 */
+    uint32_t *sStageAll = sQueueCAll + ((REDUCE || kStageWalk) ? 0 : kScanners * kQCap * 4);   /* per scanning wave: the chunk being filtered + the bytes behind it (kStageWalk: and the chunk before it) */
+    uint32_t *sListAll = sStageAll + kScanners * kStageWordsK * kStageBufs;   /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
     uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
     uint32_t *sDenseAll = sReduceAll + ((REDUCE || kStagedPatch) ? kScanners * 2 * kReduceCap : 0);   /* full-result kernel: per-wave staging of dense chunk numbers */
+    uint32_t *sHotAll = sDenseAll + (REDUCE ? 0 : kScanners * (int)kDenseStage);                         /* kStageWalk: the first a.hotSlots slot headers of the chained table */
 
     const int tid = threadIdx.x;
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   /* the level-1 bitmap is addressed by number: sGram3 must sit at LDS address 0 */
@@ -766,6 +995,7 @@ void pfac_scan_filter(ScanArgs a)
         }
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
+        if constexpr (!REDUCE && PFAC_STAGE_WALK != 0) copy16(sHotAll, a.chainSlots, (int)a.hotSlots * 4);
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
@@ -779,7 +1009,23 @@ void pfac_scan_filter(ScanArgs a)
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 *queueB = reinterpret_cast<u32x2 *>(sQueueBAll) + wave * kQCap;
     u32x4 *queueC = reinterpret_cast<u32x4 *>(sQueueCAll) + wave * kQCap;
-    uint32_t *stage = sStageAll + wave * kStageWords;
+    uint32_t *const stage0 = sStageAll + wave * (kStageWordsK * kStageBufs);
+    uint32_t *stage = stage0;                                  /* the buffer of the chunk being filtered */
+    uint32_t *queue32 = sQueueAll + wave * kQCap;              /* kStageWalk: entries {buffer << 31 | offset in the chunk} */
+    /* kStageWalk: the wave's two stage buffers.  `cur` holds the chunk being filtered, the other one the chunk before it, whose
+     * walks may still be queued or under way: it is overwritten only when they are through (qEnd: the queue counter behind
+     * the last entry of the chunk staged in each buffer). */
+    StageView view;
+    view.addr[0] = (uint32_t)(reinterpret_cast<unsigned char *>(stage0) - smem);
+    view.addr[1] = view.addr[0] + (uint32_t)kStageWordsK * 4u;
+    view.base[0] = view.base[1] = 0;
+    uint32_t cur = 0, qEnd[2] = {0, 0};
+    /* kStageWalk: the wave's stream mode (StageLane): text = entries carry their bytes (in the second buffer's place), stage =
+     * two staged chunks.  deepRecent: walks that ran off their LDS bytes lately */
+    /* a launch starts in the mode most waves of the handle's previous launch ended in (a stream rarely changes its nature
+     * between two calls; a wave that guesses wrong switches after a few chunks) */
+    bool modeStage = kStageWalk && __builtin_amdgcn_readfirstlane((int)a.work[pfac::kModeHintWord]) != 0;
+    uint32_t deepRecent = 0, stageHold = modeStage ? 64u : 0u;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sLadder, sFinal3, sShort,
@@ -789,7 +1035,11 @@ void pfac_scan_filter(ScanArgs a)
         const uint32_t idx = v >> lds.shiftLad;
         return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(((idx >> 3) & ~3u) + kLadderLdsOffset) >> (idx & 31u);
     };
-    const WCtx wctx(a);
+    WCtx wctx(a);
+    if constexpr (kStageWalk) {
+        wctx.hotAddr = (uint32_t)(reinterpret_cast<unsigned char *>(sHotAll) - smem);
+        wctx.hotSlots = a.hotSlots;
+    }
     WLane walk[kWalkSets];
     bool alive[kWalkSets];
 #pragma unroll
@@ -892,12 +1142,13 @@ void pfac_scan_filter(ScanArgs a)
 #ifndef PFAC_SPEC_FORCE
 #define PFAC_SPEC_FORCE -1                     /* measurement builds: 0 = never, 1 = always */
 #endif
-    bool specOn = PFAC_SPEC_FORCE == 1;
+    bool specOn = PFAC_SPEC_FORCE == 1 || (PFAC_SPEC_FORCE < 0 && kStageWalk && modeStage);
     uint32_t specScore = 0, specIdle = 0;
     auto walkIssue = [&]() {
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             if (alive[s]) walk[s].issue(wctx, specOn);
+            (void)view;
             stLaneSteps += (uint32_t)__popcll(__ballot(alive[s]));
         }
         stRounds++;
@@ -905,7 +1156,7 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             stSlotGathers += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needSlot));
-            stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
+            if constexpr (!kStageWalk) stWinLoads += (uint32_t)__popcll(__ballot(alive[s] && walk[s].needWin));
         }
 #endif
     };
@@ -913,7 +1164,11 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             bool cont = false;
-            if (alive[s]) cont = walk[s].consume(wctx, specOn);
+            if (alive[s]) {
+                if constexpr (kStageWalk) cont = walk[s].consume(wctx);
+                else cont = walk[s].consume(wctx, specOn);
+            }
+            if constexpr (kStageWalk) deepRecent += (uint32_t)__popcll(__ballot(alive[s] & walk[s].ranOff));
             if (kSpecKernel && PFAC_SPEC_FORCE < 0) {
                 if (!specOn) {
                     specScore += (uint32_t)__popcll(__ballot(alive[s] & walk[s].needExt));
@@ -936,16 +1191,34 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
         for (int s = 0; s < kWalkSets; s++) {
             const uint64_t idle = __ballot(!alive[s]);
-            if ((uint32_t)__popcll(idle) >= (uint32_t)PFAC_REFILL_MIN && qh != qv && (qv - qh >= kRefillBatch || flushWalks)) {
+            /* text mode (kStageWalk): a queued candidate copies its bytes out of the stage when a lane takes it, and the next chunk is
+             * not staged before that: the queue is handed out whenever the idle lanes can take all of it */
+            const bool drainNow = kStageWalk && !modeStage && (uint32_t)__popcll(idle) >= qv - qh;
+            /* stage mode: a buffer is overwritten when the last walk of its chunk has ended, so an entry should not wait for
+             * sixteen idle lanes, and starting a walk there is a code and two LDS reads */
+#ifndef PFAC_REFILL_MIN_STAGE
+#define PFAC_REFILL_MIN_STAGE 6
+#endif
+            const uint32_t refillMin = (kStageWalk && modeStage) ? (uint32_t)PFAC_REFILL_MIN_STAGE : (uint32_t)PFAC_REFILL_MIN;
+            if (((uint32_t)__popcll(idle) >= refillMin || drainNow) && qh != qv && (qv - qh >= kRefillBatch || flushWalks)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t rank = laneRankIn(idle);
                 const bool take = !alive[s] & (rank < qv - qh);
                 if (take) {
                     const uint32_t qi = (qh + rank) & kMask;
-                    const u32x2 eb = queueB[qi];
-                    u32x4 ec = {0, 0, 0, 0};
-                    if (!REDUCE) ec = queueC[qi];
-                    walk[s].start(wctx, queue[qi], eb.x, eb.y, ec, HAS_SHORT ? sShort : nullptr);
+                    if constexpr (kStageWalk) {
+#ifndef PFAC_LONG_JUMP
+#define PFAC_LONG_JUMP 1
+#endif
+                        const bool longJump = PFAC_LONG_JUMP != 0 && specOn;
+                        if (modeStage) walk[s].startStage(wctx, view, queue32[qi], HAS_SHORT ? sShort : nullptr, longJump);
+                        else walk[s].startText(wctx, view, queue32[qi] & 0x7FFFFFFFu, view.addr[1] + ((uint32_t)s * 64u + (uint32_t)lane) * kWalkEntryBytes, HAS_SHORT ? sShort : nullptr, longJump);
+                    } else {
+                        const u32x2 eb = queueB[qi];
+                        u32x4 ec = {0, 0, 0, 0};
+                        if (!REDUCE) ec = queueC[qi];
+                        walk[s].start(wctx, queue[qi], eb.x, eb.y, ec, HAS_SHORT ? sShort : nullptr);
+                    }
                 }
                 alive[s] = alive[s] | take;
                 const uint32_t idleLanes = (uint32_t)__popcll(idle);
@@ -1122,7 +1395,8 @@ void pfac_scan_filter(ScanArgs a)
          * from -- registers that the walkers' state needs) */
         uint32_t off, offHalo;
         asm volatile("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(off) : "v"(lane), "s"(c * (uint32_t)kChunkBytes));
-        asm volatile("v_and_b32 %0, 15, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
+        if constexpr (kStageWalk) asm volatile("v_and_b32 %0, 31, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
+        else asm volatile("v_and_b32 %0, 15, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
         static_assert(kTilesPerIter == 2, "two tile registers are reserved");
 #ifndef PFAC_INPUT_POLICY
 #define PFAC_INPUT_POLICY ""                   /* cache policy of the chunk loads (" nt", " sc1", ...): measurement builds */
@@ -1220,13 +1494,54 @@ void pfac_scan_filter(ScanArgs a)
         walkIssue();
         PFAC_TICK(2);
         if (listAt == listEnd && __ballot(hits != 0) == 0) {
+            /* kStageWalk: the next chunk goes into the buffer of the chunk before the one just filtered -- once no walk reads that
+             * one any more (none of its entries still queued, none of its walks alive); until then the trip just walks */
+            bool stageFree = true;
+            if constexpr (kStageWalk) {
+                /* which mode the stream asks for: stage mode while the wave meets long slots (specOn) or its walks run off their
+                 * entries, and for a while after; the region changes hands when nothing is queued and nothing walks */
+#ifndef PFAC_FORCE_MODE
+#define PFAC_FORCE_MODE -1                     /* measurement builds: 0 = text mode only, 1 = stage mode only */
+#endif
+                const bool wantStage = PFAC_FORCE_MODE >= 0 ? PFAC_FORCE_MODE == 1 : (specOn | (deepRecent >= 32u) | (stageHold != 0));
+                if (wantStage != modeStage) {
+                    if (qh == qv && !anyAlive()) {
+                        modeStage = wantStage;
+                        cur = 0;
+                        stage = stage0;
+                        qEnd[0] = qEnd[1] = qv;
+                        if (modeStage) stageHold = 64;
+                    } else {
+                        stageFree = false;                         /* no new chunk until the walks of the old mode are through */
+                    }
+                }
+                if (!modeStage) {
+                    stageFree = stageFree && qh == qv;             /* text mode: what is queued has not copied its bytes out of the stage yet */
+                } else if (stageFree) {
+                    const uint32_t qe = cur ? qEnd[0] : qEnd[1];
+                    bool reads = false;
+#pragma unroll
+                    for (int s = 0; s < kWalkSets; s++) reads |= alive[s] & (walk[s].inB == (cur == 0));
+                    stageFree = (int)(qe - qh) <= 0 && __ballot(reads) == 0;
+                }
+            }
             if (chunk == kEnd) {
                 if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
-            } else {
+            } else if (stageFree) {
                 /* ---- 3. next chunk: ask for the chunk after next; without writer waves: zero stores, 16 B per
                  *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
                  *         this chunk) */
                 const unsigned int afterNext = pop();
+                if constexpr (kStageWalk) {
+                    if (modeStage) {
+                        if (cur) qEnd[1] = qv; else qEnd[0] = qv;  /* whatever the chunk just filtered put on the queue lies in front of qv */
+                        cur ^= 1u;
+                        stage = stage0 + cur * (uint32_t)kStageWordsK;
+                        if (!specOn && deepRecent < 32u && stageHold != 0) stageHold--;
+                    }
+                    deepRecent -= (deepRecent + 3u) >> 2;           /* per chunk: a quarter of what is left */
+                    specScore -= (specScore + 3u) >> 2;
+                }
                 if (!REDUCE && !kWriters) {
                     i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
                     const i32x4 zero = {0, 0, 0, 0};
@@ -1248,7 +1563,7 @@ void pfac_scan_filter(ScanArgs a)
                         asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(at16) : "v"(lane), "s"(tileBase));
                         *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(at16) = dt;
                     }
-                    if (tt == kTilesPerIter - 1 && lane < 12) {
+                    if (tt == kTilesPerIter - 1 && lane < kHaloDwords) {
                         /* the address is computed on the spot (volatile: not hoisted out of the loop into a register
                          * that lives -- or is spilled -- across it) */
                         uint32_t at;
@@ -1303,6 +1618,7 @@ void pfac_scan_filter(ScanArgs a)
                     }
                 }
                 stagedBase = chunk * kChunkBytes;
+                if constexpr (kStageWalk) { if (cur) view.base[1] = stagedBase; else view.base[0] = stagedBase; }
                 freshChunk = true;
                 PFAC_TICK(3);
                 /* the chunk registers are free again: prefetch the next chunk.  Past the end the last chunk is
@@ -1393,8 +1709,10 @@ void pfac_scan_filter(ScanArgs a)
          * S node (walk), or neither an S nor a G node (its result is 0).  Survivors -> walk queue.  A batch takes up
          * to 64 candidates, fewer if the queue has less room (then at least 16, or all that are left). */
         for (;;) {
-            const uint32_t left = listEnd - listAt, room = kQCap - (qv - qh);
-            const uint32_t want = left < 64u ? left : 64u, take = room < want ? room : want;
+            const uint32_t left = listEnd - listAt;
+            const uint32_t want = left < 64u ? left : 64u;
+            const uint32_t room = kQCap - (qv - qh);
+            const uint32_t take = room < want ? room : want;
             if (left == 0 || (take != want && take < kAppendMin)) break;
             const bool act = (uint32_t)lane < take;
             const uint32_t code = act ? listCode(listAt) : 0u;
@@ -1446,9 +1764,12 @@ void pfac_scan_filter(ScanArgs a)
             const bool keep = walk != 0;
             const uint64_t keepMask = __ballot(keep);
             if (keep) {
+                const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
+                if constexpr (kStageWalk) {
+                    queue32[qi] = (cur << 31) | o;             /* the walk reads its input from the stage (text mode: copies its first bytes when it starts) */
+                } else {
                 const u32x4 entry = {stagedBase + o, x0, x1, x2};
                 const u32x2 entryB = {x3, x4};
-                const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
                 queue[qi] = entry;
                 queueB[qi] = entryB;
                 if (!REDUCE) {                                  /* bytes 20..35: read now, for the few that are kept */
@@ -1456,6 +1777,7 @@ void pfac_scan_filter(ScanArgs a)
                     const u32x4 entryC = {__builtin_amdgcn_alignbyte(e6, e5, sh), __builtin_amdgcn_alignbyte(e7, e6, sh),
                                           __builtin_amdgcn_alignbyte(e8, e7, sh), __builtin_amdgcn_alignbyte(e9, e8, sh)};
                     queueC[qi] = entryC;
+                }
                 }
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
@@ -1485,10 +1807,12 @@ void pfac_scan_filter(ScanArgs a)
     if (lane == 0) {
         atomicAdd(&sGram3[0], stRounds); atomicAdd(&sGram3[1], stLaneSteps);
         atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits); atomicAdd(&sGram3[4], stCand);
+        if (kStageWalk && modeStage && !(kWriters && wave >= kScanners)) atomicAdd(&sGram3[5], 1u);
     }
     __syncthreads();
     if (tid < 4) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
     if (tid == 5) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 5, (unsigned long long)sGram3[4]);
+    if (kStageWalk && tid == 6 && sGram3[5] != 0) atomicAdd(a.work + pfac::kModeVotesWord, sGram3[5]);
     /* The last block out leaves the counters as the next launch needs them -- zero -- and publishes the statistics: a
      * memset in front of every launch was 5 us of a call (profiles/r03_experiments.md section 7).  Every block counts
      * itself out after its own atomics have been performed; whoever counts last knows that all the others are done. */
@@ -1505,6 +1829,11 @@ void pfac_scan_filter(ScanArgs a)
             if (lane < pfac::kStatsCount) published[lane] = lane == 4 ? (unsigned long long)a.n : atomicExch(acc + lane, 0ull);
             if (lane == pfac::kStatsCount) published[lane] = REDUCE ? 0ull : (unsigned long long)atomicAdd(a.work + a.denseWord, 0u);   /* stays: the tiled kernel behind this launch reads it */
             if (lane == pfac::kStatsCount + 1) published[lane] = (unsigned long long)kWalkSets;
+            if (lane == pfac::kStatsCount + 2) {                  /* scanning waves that ended the launch in stage mode: published, and the next launch's starting mode */
+                const unsigned int votes = kStageWalk ? atomicExch(a.work + pfac::kModeVotesWord, 0u) : 0u;
+                published[lane] = (unsigned long long)votes;
+                if (kStageWalk) atomicExch(a.work + pfac::kModeHintWord, votes * 2u >= gridDim.x * (unsigned int)kScanners ? 1u : 0u);
+            }
             if (lane == 32) atomicExch(a.work + a.denseWordOther, 0u);
             if (lane == 33) atomicExch(a.work + pfac::kDoneWord, 0u);
         }
@@ -2047,7 +2376,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 /* the CU's 160 KiB: the prefilter bitmaps (<= kFilterLdsBudget, pattern_compiler.cpp) + control block + per scanning wave a
  * walk queue (24 B per entry), the staged chunk and the hit list (+ the pair staging of the compacted-output variant) */
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * (kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4 + kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
+constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * ((PFAC_STAGE_WALK ? kQueueCap * 4 + 2 * kWalkStageBytes : kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4) +
+                                                                              kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
 constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
 static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + kScannerLdsFull <= kLdsPerCu, "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
 static_assert(kGram1LdsOffset + kGram1LdsBytes + 1024 /* final3 */ + 8192 /* 2-byte bitmap */ + kControlWords * 4 + kScannerLdsReduce <= kLdsPerCu,
@@ -2060,7 +2390,8 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce)
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
-    bytes += scanners * ((reduce ? kReduceQueueCap * (4 + kEntryBytes) : kQueueCap * (4 + kEntryBytesFull)) + (kStageWords + kListCap / 2) * sizeof(uint32_t));
+    if (!reduce && PFAC_STAGE_WALK) bytes += scanners * (kQueueCap * 4 + 2 * kWalkStageBytes + (kListCap / 2) * sizeof(uint32_t));
+    else bytes += scanners * ((reduce ? kReduceQueueCap * (4 + kEntryBytes) : kQueueCap * (4 + kEntryBytesFull)) + (kStageWords + kListCap / 2) * sizeof(uint32_t));
     if (reduce || kStagedPatch) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     if (!reduce) bytes += scanners * kDenseStage * sizeof(uint32_t);
     return bytes;
@@ -2078,15 +2409,30 @@ constexpr int kMaxDevices = 64;
 struct ShapeCache { std::mutex lock; int perCU[kMaxDevices] = {}; };
 
 template <bool TEX, bool HAS_SHORT, bool REDUCE>
-hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a)
+hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a0)
 {
     auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL>;
     static ShapeCache cache;
-    const size_t lds = filterLdsBytes(c, REDUCE);
+    size_t lds = filterLdsBytes(c, REDUCE);
     int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
     hipError_t de = hipGetDevice(&dev);
     if (de != hipSuccess) return de;
     if (lds > kLdsPerCu || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidValue;
+    ScanArgs a = a0;
+    a.hotSlots = 0;
+    if (!REDUCE && PFAC_STAGE_WALK != 0) {
+        /* the LDS the bitmaps and the waves' buffers leave holds the top of the chained table (buckets breadth first, then the
+         * initial state's row): 50 KiB and more for a set of a few thousand patterns, nothing for a Snort-scale set */
+#ifndef PFAC_FILTER_HOT
+#define PFAC_FILTER_HOT 1
+#endif
+        size_t hot = PFAC_FILTER_HOT ? (kLdsPerCu - lds) / sizeof(pfac::ChainSlot) : 0;
+        const size_t top = (size_t)a.rootRow + (size_t)pfac::kCharSet;
+        if (hot > top) hot = top;
+        if (hot < 1024) hot = 0;                       /* not worth a test per step */
+        a.hotSlots = (uint32_t)hot;
+        lds += hot * sizeof(pfac::ChainSlot);
+    }
     int perCU;
     {
         std::lock_guard<std::mutex> g(cache.lock);
@@ -2260,7 +2606,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.chainSlots = reinterpret_cast<const u32x4 *>(c->d_chainSlots);
     a.jumpShift = 32u - (uint32_t)c->chainJumpLog2;
     a.extDelta = (uint32_t)(c->numChainSlots / 2);                         /* headers, then as many extension units (tables.cpp) */
-    a.jumpBase = (uint32_t)(c->numChainSlots / 2 - (size_t(1) << c->chainJumpLog2));
+    a.jumpBase = (uint32_t)(c->numChainSlots / 2 - (size_t(2) << c->chainJumpLog2));         /* the jump table, then the long jump table */
+    a.jumpLongBase = a.jumpBase + (uint32_t)(size_t(1) << c->chainJumpLog2);
     a.rootRow = a.jumpBase - (uint32_t)pfac::kCharSet;
     a.chainBytes = clampExtent(c->numChainSlots * sizeof(pfac::ChainSlot));
     a.initialRow = c->d_initialRow;
@@ -2306,7 +2653,7 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
         if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
     }
-    const size_t margin = (size_t)c->fa.maxPatternLen + 64;   /* a window load reads up to 35 bytes beyond a walk's deepest byte; the prefetch of a chunk reads the 64 bytes behind it */
+    const size_t margin = (size_t)c->fa.maxPatternLen + 64 + kWalkHalo;   /* a window load reads up to 35 bytes beyond a walk's deepest byte; the prefetch of a chunk reads the 64 (full-result kernel: kWalkHalo) bytes behind it */
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
     const size_t end = ownEnd < safeEnd ? ownEnd : safeEnd;
     return end > first ? (end - first) / chunkBytes(c) * chunkBytes(c) : 0;

@@ -136,6 +136,7 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
  * a long slot (or, by a walker that has found its stream to be full of near misses, together with the header).
  * Behind the buckets the headers carry two more regions:
  *   [rootRow, rootRow + 256)   the bucket of the initial state, indexed by the byte itself (hash k = 128, S = 256);
+ *   [jumpBase + 2^J, jumpBase + 2 * 2^J) the LONG jump table: the same slots with chains of up to kChainMaxWide bytes;
  *   [jumpBase, jumpBase + 2^J) the JUMP table: one slot per 4-byte pattern prefix whose first three states are not
  *                              final, at hash(prefix), encoded as a transition on the first byte with the other
  *                              three as the head of its chain.  A walk starts there -- the prefilter has just
@@ -305,7 +306,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         slots.clear();
         if (fa.numStates <= init) {                                /* no patterns: root row + smallest jump table, all empty */
             jumpLog2 = kJumpLog2Min;
-            slots.assign((size_t)kCharSet + (size_t(1) << jumpLog2), ChainBuilder::emptySlot());
+            slots.assign((size_t)kCharSet + (size_t(2) << jumpLog2), ChainBuilder::emptySlot());
             slots.resize(2 * slots.size(), ChainBuilder::zeroUnit());
             return PFAC_STATUS_SUCCESS;
         }
@@ -332,6 +333,9 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < (size_t)PFAC_JUMP_SPARSITY * prefixes.size()) jumpLog2++;
         ChainBuilder b(fa, slots);
         std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
+        /* the LONG jump table: the same prefixes in the same places, but a slot folds up to kChainMaxWide bytes (chain bytes 8.. in
+         * its extension unit): the start of a walker that expects long single-successor runs (scan_gfx950.hip: StageLane) */
+        std::vector<ChainSlot> jumpLong(jump.size(), ChainBuilder::emptySlot()), jumpLongUnits(jump.size(), ChainBuilder::zeroUnit());
         /* the top of the trie first: what the initial state's transitions land in, then what the jump slots land in,
          * then everything below, level by level */
         for (int e = fa.edgeBegin[init]; e < fa.edgeBegin[init + 1]; e++) root[fa.edgeCh[e]] = b.makeSlot(fa.edgeCh[e], fa.edgeNext[e], kChainMax).hdr;
@@ -340,13 +344,18 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
             if (!(dst.meta & kSlotEmpty)) continue;            /* taken: this prefix walks from the initial state */
             const unsigned char rest[3] = {(unsigned char)(p.key >> 8), (unsigned char)(p.key >> 16), (unsigned char)(p.key >> 24)};
             dst = b.makeSlot((int)(p.key & 0xFFu), p.state, kChainMax, rest, 3).hdr;
+            const BuiltSlot wide = b.makeSlot((int)(p.key & 0xFFu), p.state, PFAC_WIDE_BUCKETS ? kChainMaxWide : kChainMax, rest, 3);
+            jumpLong[jumpHash(p.key, jumpLog2)] = wide.hdr;
+            std::memcpy(&jumpLongUnits[jumpHash(p.key, jumpLog2)], wide.ext, sizeof(wide.ext));
         }
         b.drain();
         if (b.failed) return PFAC_STATUS_INTERNAL_ERROR;
         slots.insert(slots.end(), root.begin(), root.end());
         slots.insert(slots.end(), jump.begin(), jump.end());
-        /* the extension units, slot for slot: unit i belongs to slot i (root row and jump table never have one) */
+        /* the extension units, slot for slot: unit i belongs to slot i (root row and the short jump table never have one) */
         b.units.resize(slots.size(), ChainBuilder::zeroUnit());
+        slots.insert(slots.end(), jumpLong.begin(), jumpLong.end());
+        b.units.insert(b.units.end(), jumpLongUnits.begin(), jumpLongUnits.end());
         slots.insert(slots.end(), b.units.begin(), b.units.end());
     } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
     return PFAC_STATUS_SUCCESS;

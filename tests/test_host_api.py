@@ -548,12 +548,12 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
     J = info.chainJumpLog2
     assert 10 <= J <= 20 and info.chainSlots == len(slots) and len(slots) % 2 == 0
     ext_delta = len(slots) // 2                    # N slot headers, then N extension units: the unit of slot i at N + i
-    jump_base = ext_delta - (1 << J)
+    jump_base = ext_delta - (2 << J)               # the jump table; behind it the LONG jump table (same hash, chains of up to 23 bytes)
     root_row = jump_base - 256
     EMPTY, FINAL, WIDE = 1 << 14, 1 << 13, 1 << 15         # pfac_context.h: kSlotEmpty, kSlotFinal, kSlotWide; a leaf has k == 0
     long_steps = 0
 
-    def walk_all(stream, expect):
+    def walk_all(stream, expect, long_jump=False):
         nonlocal data
         n = len(stream)
         data = bytes(stream) + bytes(80)
@@ -562,7 +562,7 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
         for i in range(limit):
             x = int.from_bytes(data[i:i + 4], "little")
             match = 0
-            ok, leaf, ident, row, ks, used = step(jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J)), False, data[i], i + 1)
+            ok, leaf, ident, row, ks, used = step(jump_base + (long_jump << J) + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J)), long_jump, data[i], i + 1)
             if ok:
                 used_jump += 1
             else:                                  # restart in the initial state's bucket (k = 128, S = 256: the byte itself)
@@ -605,6 +605,8 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
         return ok, leaf, ident, int(slot[1]), meta, 1 + ln
 
     used_jump, fell_back = walk_all(w.data[:30000], oracle_results[name])
+    used_long, _ = walk_all(w.data[:30000], oracle_results[name], long_jump=True)     # the long jump table: same results (a slot that
+    assert used_long <= used_jump                                                    # compares more bytes sends more walks back to the root)
     if name in ("c2", "c3"):
         assert used_jump > 0                       # the stream does contain 4-byte pattern prefixes
     if name == "c5":

@@ -17,8 +17,9 @@ slots = h.table(api.PFACX_TABLE_CHAIN).reshape(-1, 4)
 info = h.info()
 J = info.chainJumpLog2
 N = len(slots) // 2                     # slot headers; as many extension units behind them
-jump_base = N - (1 << J)
-root_row = jump_base - 256
+LONG = len(sys.argv) > 2 and sys.argv[2] == 'long'
+jump_base = N - (2 << J) + ((1 << J) if LONG else 0)
+root_row = N - (2 << J) - 256
 print(f"{name}: states {info.numOfStates} chain slots {len(slots)} ({len(slots) * 16 / 1e6:.2f} MB), buckets {root_row * 16 / 1e6:.2f} MB, jump 2^{J}")
 data = bytes(cfg.input_slice(1 << 20)) + bytes(128)
 EMPTY, FINAL, WIDE = 1 << 14, 1 << 13, 1 << 15
@@ -36,6 +37,7 @@ for i in range(0, (1 << 20) - 200):
     x = int.from_bytes(data[i:i + 4], "little")
     n = 1; g = 1
     ok, leaf, row, ks, used = step(jump_base + (((x * 0x9E3779B1) & 0xFFFFFFFF) >> (32 - J)), 0, data[i], i + 1)
+    if LONG: g = 2
     if not ok:
         continue                     # only walks the jump table knows (what the prefilter lets through, roughly)
     depth = 0

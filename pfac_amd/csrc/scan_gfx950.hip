@@ -622,6 +622,8 @@ template <bool TEX> struct StageLane {
     uint32_t ks = 0, b0 = 0;
     u32x4 t = {0, 0, 0, 0};
     u32x4 E;                                   /* the extension unit of the slot in flight (no initial value: see ChainLane) */
+    uint32_t d0 = 0, d1 = 0, d2 = 0;           /* the three dwords that hold the 9 bytes behind the edge byte: read in issue(), like the slot, so that
+                                                * consume() does not begin with an LDS round trip */
     bool inB = false;                          /* stage mode: which of the two stage buffers the walk reads */
     bool needSlot = true;
     bool haveE = false, needExt = false, usedE = false;
@@ -682,6 +684,10 @@ template <bool TEX> struct StageLane {
     }
     __device__ __forceinline__ void issue(const Ctx &c, bool spec)
     {
+        {
+            const uint32_t a4 = (sq + 1u) & ~3u;
+            d0 = ldsWord(a4); d1 = ldsWord(a4 + 4u); d2 = ldsWord(a4 + 8u);
+        }
         if (needSlot) {
             const uint32_t idx = row + chainHashSlot(ks, b0);
             /* the top of the table (breadth first) is in LDS, as far as the block's LDS reaches -- every bucket of a small pattern
@@ -708,8 +714,7 @@ template <bool TEX> struct StageLane {
     {
         const uint32_t a = sq + 1u;                            /* first byte behind the edge byte */
         const uint32_t a4 = a & ~3u, sh = a & 3u;
-        const uint32_t d0 = ldsWord(a4), d1 = ldsWord(a4 + 4u), d2 = ldsWord(a4 + 8u);
-        {   /* a header among the hot rows (issue() did not fetch it): row, ks and b0 still describe the bucket it is in */
+        if (c.hotSlots != 0) {   /* a header among the hot rows (issue() did not fetch it): row, ks and b0 still describe the bucket it is in */
             const uint32_t idx = row + chainHashSlot(ks, b0);
             if (idx < c.hotSlots) t = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(c.hotAddr + idx * 16u);
         }
@@ -1168,11 +1173,16 @@ void pfac_scan_filter(ScanArgs a)
                 if constexpr (kStageWalk) cont = walk[s].consume(wctx);
                 else cont = walk[s].consume(wctx, specOn);
             }
-            if constexpr (kStageWalk) deepRecent += (uint32_t)__popcll(__ballot(alive[s] & walk[s].ranOff));
             if (kSpecKernel && PFAC_SPEC_FORCE < 0) {
                 if (!specOn) {
-                    specScore += (uint32_t)__popcll(__ballot(alive[s] & walk[s].needExt));
-                    if (specScore >= kSpecOnScore) { specOn = true; specScore = 0; specIdle = 0; }
+                    /* on text nothing below ever happens: one test for all of it */
+                    bool odd = walk[s].needExt;
+                    if constexpr (kStageWalk) odd |= walk[s].ranOff;
+                    if (__ballot(alive[s] & odd) != 0) {
+                        if constexpr (kStageWalk) deepRecent += (uint32_t)__popcll(__ballot(alive[s] & walk[s].ranOff));
+                        specScore += (uint32_t)__popcll(__ballot(alive[s] & walk[s].needExt));
+                        if (specScore >= kSpecOnScore) { specOn = true; specScore = 0; specIdle = 0; }
+                    }
                 } else {
                     const uint32_t loaded = (uint32_t)__popcll(__ballot(alive[s] & walk[s].haveE)), used = (uint32_t)__popcll(__ballot(alive[s] & walk[s].usedE));
                     if (loaded >= 8u) specIdle = used * 4u < loaded ? specIdle + 1u : 0u;
@@ -1395,7 +1405,8 @@ void pfac_scan_filter(ScanArgs a)
          * from -- registers that the walkers' state needs) */
         uint32_t off, offHalo;
         asm volatile("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(off) : "v"(lane), "s"(c * (uint32_t)kChunkBytes));
-        if constexpr (kStageWalk) asm volatile("v_and_b32 %0, 31, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
+        /* the bytes behind the chunk: 64 of them (lanes 0..15: 48 are staged) -- in stage mode kWalkHalo, a dword in each of the lanes 0..31 */
+        if constexpr (kStageWalk) asm volatile("v_and_b32 %0, %3, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes), "s"(modeStage ? 31u : 15u));
         else asm volatile("v_and_b32 %0, 15, %1\n\tv_lshl_or_b32 %0, %0, 2, %2" : "=&v"(offHalo) : "v"(lane), "s"((c + 1u) * (uint32_t)kChunkBytes));
         static_assert(kTilesPerIter == 2, "two tile registers are reserved");
 #ifndef PFAC_INPUT_POLICY
@@ -1510,7 +1521,12 @@ void pfac_scan_filter(ScanArgs a)
                         cur = 0;
                         stage = stage0;
                         qEnd[0] = qEnd[1] = qv;
-                        if (modeStage) stageHold = 64;
+                        if (modeStage) {
+                            stageHold = 64;
+                            /* the chunk in flight was fetched with text mode's 64 bytes behind it: fetch it again with kWalkHalo, stage
+                             * it in the next trip (behind the loop's wait) */
+                            if (chunk != kEnd) { prefetchChunk(chunk); stageFree = false; }
+                        }
                     } else {
                         stageFree = false;                         /* no new chunk until the walks of the old mode are through */
                     }
@@ -1539,8 +1555,10 @@ void pfac_scan_filter(ScanArgs a)
                         stage = stage0 + cur * (uint32_t)kStageWordsK;
                         if (!specOn && deepRecent < 32u && stageHold != 0) stageHold--;
                     }
-                    deepRecent -= (deepRecent + 3u) >> 2;           /* per chunk: a quarter of what is left */
-                    specScore -= (specScore + 3u) >> 2;
+                    if ((deepRecent | specScore) != 0) {            /* per chunk: a quarter of what is left */
+                        deepRecent -= (deepRecent + 3u) >> 2;
+                        specScore -= (specScore + 3u) >> 2;
+                    }
                 }
                 if (!REDUCE && !kWriters) {
                     i32x4 *o4 = reinterpret_cast<i32x4 *>(a.out + (size_t)chunk * kChunkBytes);
@@ -1563,7 +1581,7 @@ void pfac_scan_filter(ScanArgs a)
                         asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(at16) : "v"(lane), "s"(tileBase));
                         *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(at16) = dt;
                     }
-                    if (tt == kTilesPerIter - 1 && lane < kHaloDwords) {
+                    if (tt == kTilesPerIter - 1 && lane < (kStageWalk ? (modeStage ? kHaloDwords : 16) : kHaloDwords)) {
                         /* the address is computed on the spot (volatile: not hoisted out of the loop into a register
                          * that lives -- or is spilled -- across it) */
                         uint32_t at;
@@ -1581,7 +1599,10 @@ void pfac_scan_filter(ScanArgs a)
                      * (a shift or v_alignbyte), v_mul_u32_u24, shift + AND = dword address, ds_read_b32, a shift by the
                      * gram (mod 32: the bit), v_alignbit to push the bit into the mask.  Plain VOP2 instructions
                      * wherever possible: they issue twice as fast as VOP3 ones here (tools/valu_probe.hip). */
-                    constexpr int kBatch = 8;
+#ifndef PFAC_L1_BATCH
+#define PFAC_L1_BATCH 8                        /* ... of the full-result kernel, whose walkers (StageLane) leave it the registers for more */
+#endif
+                    constexpr int kBatch = kStageWalk ? PFAC_L1_BATCH : 8;
 #pragma unroll
                     for (int b0 = 0; b0 < 16; b0 += kBatch) {
                         uint32_t word[kBatch], xs[kBatch + 1];

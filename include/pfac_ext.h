@@ -105,6 +105,16 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
                              size_t *bytes);
 
 /* Kernel variants of the GPU match path. */
+/* The walker of the full-result filter kernel (PFACX_setWalker).  WINDOW: a walk's input travels with its queue entry and
+ * lives in registers (fastest on text); STAGE: walks read their input in place from the chunks a wave keeps staged in LDS and
+ * take 24 bytes per step through long single-successor runs (fastest when the stream is full of near misses of long
+ * patterns: BASELINE config 5, 19 % over WINDOW); AUTO (default): whatever the handle's previous full-result launch found its
+ * stream to be -- the first launch on a handle runs WINDOW.  Results are identical. */
+#define PFACX_WALKER_AUTO   0
+#define PFACX_WALKER_WINDOW 1
+#define PFACX_WALKER_STAGE  2
+PFAC_status_t PFACX_setWalker(PFAC_handle_t handle, int walker);
+
 #define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
 #define PFACX_KERNEL_NAIVE  1   /* the tiled kernel alone: one position per thread slot, tile + halo and the
                                    hottest transition rows in LDS, coalesced result lines (any alignment)   */
@@ -160,9 +170,11 @@ typedef struct {
                                              compacted-output launch, which lists none)                         */
     double filterKernelMs;                /* GPU time of that launch of the filter kernel alone (HIP events around it);
                                              -1 unless PFACX_setKernelTiming(handle, 1) was in force           */
-    unsigned long long stageModeWaves;    /* full-result launch: scanning waves that ended it in STAGE mode (their stream was full
-                                             of deep walks -- near misses of long patterns --, so they kept two chunks staged and
-                                             walked out of LDS); the next launch on the handle starts in the majority's mode  */
+    unsigned long long stageModeWaves;    /* full-result launch: scanning waves that ended it finding their stream full of near misses
+                                             (STAGE walker: in stage mode, two chunks staged, walking out of LDS; WINDOW walker:
+                                             fetching extension units ahead); a majority makes PFACX_WALKER_AUTO give the handle's
+                                             next launch the STAGE walker                                          */
+    int walker;                           /* PFACX_WALKER_WINDOW / PFACX_WALKER_STAGE: what that launch ran with */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);

@@ -25,6 +25,7 @@ PFAC_AUTOMATIC, PFAC_TEXTURE_ON, PFAC_TEXTURE_OFF = 0, 1, 2
 PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO, PFACX_KERNEL_REFTABLE = 0, 1, 2, 3
+PFACX_WALKER_AUTO, PFACX_WALKER_WINDOW, PFACX_WALKER_STAGE = 0, 1, 2
 PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
@@ -73,7 +74,7 @@ class PFACX_scan_stats(C.Structure):
     _fields_ = [("structSize", C.c_size_t), ("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
                 ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
                 ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong), ("filterKernelMs", C.c_double),
-                ("stageModeWaves", C.c_ulonglong)]
+                ("stageModeWaves", C.c_ulonglong), ("walker", C.c_int)]
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
@@ -88,7 +89,7 @@ EXPORTED_SYMBOLS = (
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
     "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
-    "PFACX_setKernelTiming",
+    "PFACX_setKernelTiming", "PFACX_setWalker",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -97,7 +98,8 @@ MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
 
 
 def library_paths() -> Tuple[str, str]:
-    return os.path.join(_LIB_DIR, "libpfac.so"), os.path.join(_LIB_DIR, "libpfac_gfx950.so")
+    # PFAC_HOST_LIB: another build of the HOST library (the sanitizer builds of `make -C pfac_amd/csrc san`: tests/test_sanitizers.py)
+    return os.environ.get("PFAC_HOST_LIB") or os.path.join(_LIB_DIR, "libpfac.so"), os.path.join(_LIB_DIR, "libpfac_gfx950.so")
 
 
 def load_library() -> C.CDLL:
@@ -130,6 +132,8 @@ def load_library() -> C.CDLL:
     lib.PFACX_getInfo.argtypes = [H, C.POINTER(PFACX_info)]
     lib.PFACX_getTable.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.PFACX_setKernelVariant.argtypes = [H, C.c_int]
+    if hasattr(lib, "PFACX_setWalker"):                  # (tools/ab.py also loads the libraries of earlier revisions)
+        lib.PFACX_setWalker.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
     lib.PFACX_trim.argtypes = [H]
     lib.PFACX_setKernelTiming.argtypes = [H, C.c_int]
@@ -140,6 +144,8 @@ def load_library() -> C.CDLL:
     lib.PFACX_loadCompiled.argtypes = [H, C.c_char_p]
     lib.PFACX_matchFromHostMultiGPU.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     for name in EXPORTED_SYMBOLS:
+        if os.environ.get("PFAC_AB_OLD_LIBS") and not hasattr(lib, name):     # tools/ab.py: the library of an earlier revision
+            continue
         fn = getattr(lib, name)
         if name != "PFAC_getErrorString":
             fn.restype = C.c_int
@@ -182,6 +188,10 @@ class PFAC:
             return obj
         obj = cls(h)
         obj.create_status = 0
+        # test harness: PFAC_TEST_WALKER=window|stage runs a whole test session with one walker of the full-result kernel
+        forced = {"window": PFACX_WALKER_WINDOW, "stage": PFACX_WALKER_STAGE}.get(os.environ.get("PFAC_TEST_WALKER", "").lower())
+        if forced is not None:
+            obj.setWalker(forced)
         return obj
 
     @classmethod
@@ -225,6 +235,10 @@ class PFAC:
 
     def setKernelVariant(self, variant: int, check: bool = True) -> int:
         return self._ret(self._lib.PFACX_setKernelVariant(self._h, variant), "PFACX_setKernelVariant", check)
+
+    def setWalker(self, walker: int, check: bool = True) -> int:
+        """PFACX_WALKER_AUTO / _WINDOW / _STAGE: the walker of the full-result filter kernel (include/pfac_ext.h)"""
+        return self._ret(self._lib.PFACX_setWalker(self._h, walker), "PFACX_setWalker", check)
 
     def readPatternFromFile(self, filename, check: bool = True) -> int:
         name = None if filename is None else os.fsencode(filename)

@@ -17,7 +17,7 @@ import re
 import sys
 
 RESERVED = {f"v{i}" for i in range(119, 128)}
-INSTANCES = 8                                           # TEX x HAS_SHORT x REDUCE
+INSTANCES = 12                                          # TEX x HAS_SHORT x {compacted output, full result with the window walker, ... with the stage walker}
 
 
 class ContractError(Exception):
@@ -75,7 +75,7 @@ def check_registers(text):
                 raise ContractError(f"{name}: reserved register in `{code}` (the compiler allocated it: kCompilerVgprs is too large)")
         # prefetch sites x 3 loads: in front of the loop and behind level 1; the full-result instances fetch the chunk in flight once
         # more when a wave changes to stage mode (wider halo); 5 + 5 copies
-        want_loads = 9 if re.search(r"ELb0ELi\dE", name) else 6
+        want_loads = 9 if re.search(r"ELb0ELi\dELb1E", name) else 6        # REDUCE = false, STAGE = true
         if (loads, copies) != (want_loads, 10):
             raise ContractError(f"{name}: {loads} prefetch loads and {copies} copies of reserved registers, expected {want_loads} and 10")
 
@@ -115,7 +115,7 @@ def check_waits(text):
         top = {loop[i + 1].strip() for i in waits if i not in after_atomic}
         if not (len(top) == 1 and 1 <= len(waits) - len(after_atomic) <= 2):
             raise ContractError(f"{name}: waits for vector memory inside the scan loop: " + "; ".join(loop[i].strip() + " / " + loop[i + 1].strip() for i in waits))
-        if re.search(r"ELb0ELi\dE", name) and len(after_atomic) > 1:      # REDUCE = false: one atomic, the append to the list of pattern-dense chunks
+        if re.search(r"ELb0ELi\dELb[01]E", name) and len(after_atomic) > 1:      # REDUCE = false: one atomic, the append to the list of pattern-dense chunks
             raise ContractError(f"{name}: {len(after_atomic)} waits behind atomics in the full-result scan loop")
 
 

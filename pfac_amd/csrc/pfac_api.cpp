@@ -86,6 +86,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_gram1);
     devFree(c->d_prefix4);
     devFree(c->d_workCounters);
+    if (c->h_modeHint) { (void)hipHostFree(c->h_modeHint); c->h_modeHint = c->d_modeHint = nullptr; }
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
     devFree(c->d_hostReduce);
@@ -138,17 +139,21 @@ PFAC_status_t uploadChainedHashTable(PFAC_context *c)
 /* The reference-layout table of the perf mode on the HOST: the dense table is materialised on first use -- PFACX_getTable,
  * the CPU platforms, PFACX_KERNEL_REFTABLE -- because neither GPU kernel of the product path reads it (both walk the
  * chained table) and it is S KiB: 498 MB for a Snort-scale set.  The hashed tables (a few MB) are built with the set. */
-PFAC_status_t ensureHostRefTable(PFAC_context *c)
+PFAC_status_t ensureHostRefTable(PFAC_context *c, bool tablesLocked = false)
 {
-    if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) return pfac::buildDenseTable(c->fa, c->h_dense);
+    if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) {
+        if (tablesLocked) return pfac::buildDenseTable(c->fa, c->h_dense);
+        std::unique_lock<std::shared_mutex> w(c->tablesInUse);         /* (the caller holds c->lock) */
+        return pfac::buildDenseTable(c->fa, c->h_dense);
+    }
     return PFAC_STATUS_SUCCESS;
 }
 
 /* ... and on the DEVICE: only the reference-shaped kernel (PFACX_KERNEL_REFTABLE) reads it there */
-PFAC_status_t ensureDeviceRefTable(PFAC_context *c)
+PFAC_status_t ensureDeviceRefTable(PFAC_context *c, bool tablesLocked = false)
 {
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
-    PFAC_status_t st = ensureHostRefTable(c);
+    PFAC_status_t st = ensureHostRefTable(c, tablesLocked);
     if (st != PFAC_STATUS_SUCCESS) return st;
     if (c->perfMode == PFAC_TIME_DRIVEN) {
         if (!c->d_dense) st = upload(c->d_dense, c->h_dense.data(), c->h_dense.size());
@@ -180,7 +185,7 @@ PFAC_status_t bindTable(PFAC_context *c)
     c->sizeOfTableInBytes = c->numOfTableEntry * c->sizeOfTableEntry;
     if (c->hasDevice && !c->d_chainSlots) {
         st = uploadChainedHashTable(c);
-        if (st == PFAC_STATUS_SUCCESS && c->kernelVariant == PFACX_KERNEL_REFTABLE) st = ensureDeviceRefTable(c);
+        if (st == PFAC_STATUS_SUCCESS && c->kernelVariant == PFACX_KERNEL_REFTABLE) st = ensureDeviceRefTable(c, /*tablesLocked=*/true);   /* every caller of bindTable holds tablesInUse */
         if (st != PFAC_STATUS_SUCCESS) { freeTables(c); return st; }
     }
     return PFAC_STATUS_SUCCESS;
@@ -204,6 +209,19 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build = true)
     if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
         const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
         st = upload(c->d_workCounters, zeros.data(), zeros.size());
+    }
+    if (st == PFAC_STATUS_SUCCESS && !c->h_modeHint) {
+        /* the word the scan kernel tells the host through what the stream looked like (pfac_context.h); without it AUTO means
+         * the register-window walker */
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            c->h_modeHint = static_cast<unsigned int *>(h);
+            c->d_modeHint = static_cast<unsigned int *>(d);
+            *c->h_modeHint = 0;
+        } else {
+            if (h) (void)hipHostFree(h);
+            (void)hipGetLastError();
+        }
     }
     return st;
 }
@@ -255,6 +273,8 @@ PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, 
     }
     bool omp = false;
     if (c->platform == PFAC_PLATFORM_CPU_OMP) omp = (std::getenv("OMP_NUM_THREADS") != nullptr);
+    std::shared_lock<std::shared_mutex> r(c->tablesInUse);             /* a setter on another thread waits until the match is through */
+    if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) return PFAC_STATUS_PATTERNS_NOT_READY;   /* ... or has just replaced the set: its tables are built on the next call */
     return pfac::matchOnCpu(c, reinterpret_cast<const unsigned char *>(in), n, out, omp);
 }
 
@@ -330,6 +350,7 @@ PFAC_status_t PFAC_setPerfMode(PFAC_handle_t handle, PFAC_perfMode_t perfModeSel
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (perfModeSel != PFAC_TIME_DRIVEN && perfModeSel != PFAC_SPACE_DRIVEN) return PFAC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> guard(handle->lock);
+    std::unique_lock<std::shared_mutex> tables(handle->tablesInUse);
     const bool rebuild = handle->isPatternsReady && (int)perfModeSel != handle->perfMode;
     handle->perfMode = (int)perfModeSel;
     if (rebuild) {                                         /* ref PFAC.cpp:794-814 */
@@ -394,6 +415,7 @@ static PFAC_status_t readFromFile(PFAC_handle_t handle, const char *filename, un
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if (!filename || (flags & ~(PFACX_READ_STRICT | PFACX_READ_STRIP_CR))) return PFAC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> guard(handle->lock);
+    std::unique_lock<std::shared_mutex> tables(handle->tablesInUse);
     if (handle->isPatternsReady) freeResources(handle);            /* ref PFAC.cpp:663-666 */
     if (std::strlen(filename) >= (size_t)pfac::kFileNameLen) return PFAC_STATUS_INTERNAL_ERROR;  /* ref :668-672 */
     handle->patternFile = filename;
@@ -412,6 +434,7 @@ static PFAC_status_t readFromMemory(PFAC_handle_t handle, const char *patterns, 
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
     if ((!patterns && size) || (flags & ~(PFACX_READ_STRICT | PFACX_READ_STRIP_CR))) return PFAC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> guard(handle->lock);
+    std::unique_lock<std::shared_mutex> tables(handle->tablesInUse);
     if (handle->isPatternsReady) freeResources(handle);
     handle->patternFile.clear();
     PFAC_status_t st;
@@ -1197,6 +1220,7 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     if (!ok) return PFAC_STATUS_INVALID_PARAMETER;
 
     std::lock_guard<std::mutex> guard(handle->lock);
+    std::unique_lock<std::shared_mutex> tables(handle->tablesInUse);
     PFAC_context *c = handle;
     if (c->isPatternsReady) freeResources(c);
     c->patternFile = filename;
@@ -1260,7 +1284,8 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     }
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = (int)v[pfac::kStatsCount + 1];     /* of the launch the counters describe: the full-result and the compacted-output kernel differ */
-    stats->stageModeWaves = v[pfac::kStatsCount + 2];
+    stats->stageModeWaves = v[pfac::kStatsCount + 2] & 0xFFFFFFFFull;
+    stats->walker = (v[pfac::kStatsCount + 2] >> 32) ? PFACX_WALKER_STAGE : PFACX_WALKER_WINDOW;
     return PFAC_STATUS_SUCCESS;
 }
 
@@ -1279,6 +1304,15 @@ PFAC_status_t PFACX_setKernelTiming(PFAC_handle_t handle, int on)
             }
     }
     handle->kernelTiming = on != 0;
+    return PFAC_STATUS_SUCCESS;
+}
+
+PFAC_status_t PFACX_setWalker(PFAC_handle_t handle, int walker)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (walker != PFACX_WALKER_AUTO && walker != PFACX_WALKER_WINDOW && walker != PFACX_WALKER_STAGE) return PFAC_STATUS_INVALID_PARAMETER;
+    std::lock_guard<std::mutex> guard(handle->lock);
+    handle->walker = walker;
     return PFAC_STATUS_SUCCESS;
 }
 

@@ -14,6 +14,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -239,6 +240,10 @@ struct PFAC_context {
     mutable bool evTimeRecorded = false;
     void *evUp[2] = {nullptr, nullptr}, *evScan[2] = {nullptr, nullptr}, *evDown[2] = {nullptr, nullptr};   /* hipEvent_t */
     unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
+    /* one word of mapped host memory the last block of a full-result filter launch writes: 1 = the stream was full of near misses
+     * (scan_gfx950.hip: launchChained picks the next launch's walker from it); h_: the host's pointer, d_: the device's */
+    unsigned int *h_modeHint = nullptr, *d_modeHint = nullptr;
+    int walker = PFACX_WALKER_AUTO;
     uint32_t *d_final3 = nullptr;
 
     /* ref numOfTableEntry / sizeOfTableEntry / sizeOfTableInBytes, PFAC_P.h:131-133 */
@@ -262,6 +267,10 @@ struct PFAC_context {
      * PFAC.cpp:37-56): every entry point that touches per-handle device state -- chunk counters, the counter and
      * scratch of the compacted-output path, the host staging buffers -- holds this lock for the call. */
     std::mutex lock;
+    /* ... and the CPU platforms read the host tables for the whole of a match without it (several threads may match on the CPU
+     * platforms at once): they hold this one shared; whoever frees or rebuilds the pattern set or its tables (readPattern*,
+     * setPerfMode, loadCompiled, the dense table's first use) holds `lock` AND this one exclusively */
+    std::shared_mutex tablesInUse;
     /* per-device handles of PFACX_matchFromHostMultiGPU, created on first use: (device, handle) */
     std::vector<std::pair<int, PFAC_context *>> children;
     /* chunks the filter kernel found pattern-dense and left to the simple kernel (scan_gfx950.hip): grow-only, one entry per chunk of a launch */

@@ -160,6 +160,7 @@ struct ScanArgs {
     int numFinal;
     int initialState;
     unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
+    unsigned int *hostHint;                            /* host memory (mapped): 1 = most scanning waves of this full-result launch ended in stage mode / expecting long slots */
     /* compacted output (PFAC_matchFromDeviceReduce): unordered append, sorted by position afterwards */
     int *reducePos;
     unsigned int *reduceCount;
@@ -597,9 +598,10 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
  * A walk that runs off its entry / its stage loads input from global memory, waited for on the spot (text mode: deeper than
  * 19 bytes; stage mode: more than kWalkHalo bytes behind its chunk, i.e. patterns longer than ~100 bytes).
  */
-#ifndef PFAC_STAGE_WALK
-#define PFAC_STAGE_WALK 1                      /* 0: the full-result kernel walks with ChainLane's register window (rounds 2-4) */
-#endif
+/* The full-result kernel exists with BOTH walkers (template parameter STAGE): the register-window walker of rounds 2-4
+ * (ChainLane: on text it is 1 % faster -- fewer scalar instructions and branches per trip of the loop, no copy when a walk
+ * starts) and this one (19 % faster on the near-miss stream).  The host picks per launch from what the handle's last launch
+ * found (ScanArgs::hostHint, written by the last block out): waves that ended in stage mode / with speculation on. */
 constexpr uint32_t kWalkHalo = 128;            /* bytes behind a chunk that are staged with it (full-result kernel) */
 constexpr uint32_t kWalkStageBytes = (uint32_t)pfac::kChunkTiles * 1024u + kWalkHalo;
 constexpr uint32_t kWalkEntryBytes = 32;       /* text mode: input bytes a queue entry carries */
@@ -948,7 +950,7 @@ __device__ __forceinline__ uint32_t waveMin(uint32_t v)
 constexpr int kCompilerVgprs = PFAC_COMPILER_VGPRS;
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 64 readable input bytes follow it */
-template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets, bool STAGE>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(kCompilerVgprs)))
 void pfac_scan_filter(ScanArgs a)
 {
@@ -958,7 +960,7 @@ void pfac_scan_filter(ScanArgs a)
     constexpr uint32_t kEntry = REDUCE ? kEntryBytes : kEntryBytesFull;
     /* full-result kernel: walks read their input from the wave's two staged chunks (StageLane), a queue entry is {buffer, offset};
      * compacted-output kernel (16 scanning waves, no LDS to spare): the input travels with the entry and lives in registers */
-    constexpr bool kStageWalk = !REDUCE && PFAC_STAGE_WALK != 0;
+    constexpr bool kStageWalk = !REDUCE && STAGE;
     using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry>>;
     constexpr int kStageWordsK = kStageWalk ? (int)(kWalkStageBytes / 4) : kStageWords;     /* words of one stage buffer */
     constexpr int kStageBufs = kStageWalk ? 2 : 1;
@@ -1000,7 +1002,7 @@ void pfac_scan_filter(ScanArgs a)
         }
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
-        if constexpr (!REDUCE && PFAC_STAGE_WALK != 0) copy16(sHotAll, a.chainSlots, (int)a.hotSlots * 4);
+        if constexpr (kStageWalk) copy16(sHotAll, a.chainSlots, (int)a.hotSlots * 4);
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
@@ -1030,7 +1032,7 @@ void pfac_scan_filter(ScanArgs a)
     /* a launch starts in the mode most waves of the handle's previous launch ended in (a stream rarely changes its nature
      * between two calls; a wave that guesses wrong switches after a few chunks) */
     bool modeStage = kStageWalk && __builtin_amdgcn_readfirstlane((int)a.work[pfac::kModeHintWord]) != 0;
-    uint32_t deepRecent = 0, stageHold = modeStage ? 64u : 0u;
+    uint32_t deepRecent = 0, stageHold = modeStage ? 8u : 0u;
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sLadder, sFinal3, sShort,
@@ -1139,14 +1141,18 @@ void pfac_scan_filter(ScanArgs a)
     /* Does this wave expect LONG slots (pfac_context.h: wide buckets)?  Wave-uniform, decided from what its own walks meet:
      * off, a long slot whose header bytes match costs its walk one more trip (the unit is fetched then); once kSpecOnScore
      * walks have paid that, the units of wide buckets' slots are fetched with the headers and the window is kept 24 bytes
-     * ahead -- until, eight rounds in a row, fewer than a quarter of the units fetched were looked at.  Near-miss streams
+     * ahead -- until, 16 rounds in a row, fewer than a quarter of the units fetched were looked at (or hardly any was fetched).  Near-miss streams
      * (BASELINE config 5) run with it on from their first rounds; on text it stays off: a unit fetched for a walk that
      * dies on its edge byte is a gathered load of a cold line (Snort-style stream, always on: +2.8 % launch time). */
     constexpr bool kSpecKernel = WLane::kSpec;
-    constexpr uint32_t kSpecOnScore = 16, kSpecOffRounds = 8;
+    constexpr uint32_t kSpecOnScore = 16, kSpecOffRounds = 16;
 #ifndef PFAC_SPEC_FORCE
 #define PFAC_SPEC_FORCE -1                     /* measurement builds: 0 = never, 1 = always */
 #endif
+    /* the wave's vote on the walker of the handle's next launch: chunks during which eight or more of its walks went through long
+     * slots or ran off their LDS bytes (near misses of long patterns: text has one such walk per chunk or so) minus the others */
+    int advBalance = 0;
+    uint32_t chunkEvents = 0;
     bool specOn = PFAC_SPEC_FORCE == 1 || (PFAC_SPEC_FORCE < 0 && kStageWalk && modeStage);
     uint32_t specScore = 0, specIdle = 0;
     auto walkIssue = [&]() {
@@ -1179,13 +1185,16 @@ void pfac_scan_filter(ScanArgs a)
                     bool odd = walk[s].needExt;
                     if constexpr (kStageWalk) odd |= walk[s].ranOff;
                     if (__ballot(alive[s] & odd) != 0) {
+                        chunkEvents += (uint32_t)__popcll(__ballot(alive[s] & odd));
                         if constexpr (kStageWalk) deepRecent += (uint32_t)__popcll(__ballot(alive[s] & walk[s].ranOff));
                         specScore += (uint32_t)__popcll(__ballot(alive[s] & walk[s].needExt));
                         if (specScore >= kSpecOnScore) { specOn = true; specScore = 0; specIdle = 0; }
                     }
                 } else {
                     const uint32_t loaded = (uint32_t)__popcll(__ballot(alive[s] & walk[s].haveE)), used = (uint32_t)__popcll(__ballot(alive[s] & walk[s].usedE));
-                    if (loaded >= 8u) specIdle = used * 4u < loaded ? specIdle + 1u : 0u;
+                    /* a round in which fewer than a quarter of the units fetched were looked at -- or hardly any was fetched at all: text -- */
+                    chunkEvents += used;
+                    specIdle = (loaded < 8u || used * 4u < loaded) ? specIdle + 1u : 0u;
                     if (specIdle >= kSpecOffRounds) { specOn = false; specIdle = 0; }
                 }
             }
@@ -1522,7 +1531,7 @@ void pfac_scan_filter(ScanArgs a)
                         stage = stage0;
                         qEnd[0] = qEnd[1] = qv;
                         if (modeStage) {
-                            stageHold = 64;
+                            stageHold = 8;
                             /* the chunk in flight was fetched with text mode's 64 bytes behind it: fetch it again with kWalkHalo, stage
                              * it in the next trip (behind the loop's wait) */
                             if (chunk != kEnd) { prefetchChunk(chunk); stageFree = false; }
@@ -1548,6 +1557,7 @@ void pfac_scan_filter(ScanArgs a)
                  *         lane, 1 KiB contiguous per instruction (older than every load of a walk that starts in
                  *         this chunk) */
                 const unsigned int afterNext = pop();
+                if (!REDUCE) { advBalance += chunkEvents >= 8u ? 1 : -1; chunkEvents = 0; }
                 if constexpr (kStageWalk) {
                     if (modeStage) {
                         if (cur) qEnd[1] = qv; else qEnd[0] = qv;  /* whatever the chunk just filtered put on the queue lies in front of qv */
@@ -1828,12 +1838,12 @@ void pfac_scan_filter(ScanArgs a)
     if (lane == 0) {
         atomicAdd(&sGram3[0], stRounds); atomicAdd(&sGram3[1], stLaneSteps);
         atomicAdd(&sGram3[2], stStarts); atomicAdd(&sGram3[3], stHits); atomicAdd(&sGram3[4], stCand);
-        if (kStageWalk && modeStage && !(kWriters && wave >= kScanners)) atomicAdd(&sGram3[5], 1u);
+        if (!REDUCE && advBalance > 0 && !(kWriters && wave >= kScanners)) atomicAdd(&sGram3[5], 1u);
     }
     __syncthreads();
     if (tid < 4) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + tid, (unsigned long long)sGram3[tid]);
     if (tid == 5) atomicAdd(reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 5, (unsigned long long)sGram3[4]);
-    if (kStageWalk && tid == 6 && sGram3[5] != 0) atomicAdd(a.work + pfac::kModeVotesWord, sGram3[5]);
+    if (!REDUCE && tid == 6 && sGram3[5] != 0) atomicAdd(a.work + pfac::kModeVotesWord, sGram3[5]);
     /* The last block out leaves the counters as the next launch needs them -- zero -- and publishes the statistics: a
      * memset in front of every launch was 5 us of a call (profiles/r03_experiments.md section 7).  Every block counts
      * itself out after its own atomics have been performed; whoever counts last knows that all the others are done. */
@@ -1851,9 +1861,14 @@ void pfac_scan_filter(ScanArgs a)
             if (lane == pfac::kStatsCount) published[lane] = REDUCE ? 0ull : (unsigned long long)atomicAdd(a.work + a.denseWord, 0u);   /* stays: the tiled kernel behind this launch reads it */
             if (lane == pfac::kStatsCount + 1) published[lane] = (unsigned long long)kWalkSets;
             if (lane == pfac::kStatsCount + 2) {                  /* scanning waves that ended the launch in stage mode: published, and the next launch's starting mode */
-                const unsigned int votes = kStageWalk ? atomicExch(a.work + pfac::kModeVotesWord, 0u) : 0u;
-                published[lane] = (unsigned long long)votes;
-                if (kStageWalk) atomicExch(a.work + pfac::kModeHintWord, votes * 2u >= gridDim.x * (unsigned int)kScanners ? 1u : 0u);
+                const unsigned int votes = !REDUCE ? atomicExch(a.work + pfac::kModeVotesWord, 0u) : 0u;
+                published[lane] = (unsigned long long)votes | ((unsigned long long)(kStageWalk ? 1u : 0u) << 32);
+                if (!REDUCE) {
+                    const unsigned int hint = votes * 2u >= gridDim.x * (unsigned int)kScanners ? 1u : 0u;
+                    atomicExch(a.work + pfac::kModeHintWord, hint);
+                    /* ... and where the host sees it without asking (host memory): which walker the handle's next launch gets */
+                    if (a.hostHint != nullptr) __hip_atomic_store(a.hostHint, hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             if (lane == 32) atomicExch(a.work + a.denseWordOther, 0u);
             if (lane == 33) atomicExch(a.work + pfac::kDoneWord, 0u);
@@ -2397,21 +2412,22 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 /* the CU's 160 KiB: the prefilter bitmaps (<= kFilterLdsBudget, pattern_compiler.cpp) + control block + per scanning wave a
  * walk queue (24 B per entry), the staged chunk and the hit list (+ the pair staging of the compacted-output variant) */
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * ((PFAC_STAGE_WALK ? kQueueCap * 4 + 2 * kWalkStageBytes : kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4) +
+constexpr size_t kScannerLdsStage = kQueueCap * 4 + 2 * kWalkStageBytes, kScannerLdsWindow = kQueueCap * (4 + kEntryBytesFull) + kStageWords * 4;
+constexpr size_t kScannerLdsFull = (size_t)(kWavesPerBlock - PFAC_WRITERS) * ((kScannerLdsStage > kScannerLdsWindow ? kScannerLdsStage : kScannerLdsWindow) +
                                                                               kListCap * 2 + (kStagedPatch ? kReduceCap * 8 : 0) + kDenseStage * 4);
 constexpr size_t kScannerLdsReduce = (size_t)kReduceScanners * (kReduceQueueCap * 24 + kStageWords * 4 + kListCap * 2 + kReduceCap * 8);
 static_assert(pfac::kFilterLdsBudget + kControlWords * 4 + kScannerLdsFull <= kLdsPerCu, "prefilter bitmaps + scanning waves' buffers must fit the CU's LDS");
 static_assert(kGram1LdsOffset + kGram1LdsBytes + 1024 /* final3 */ + 8192 /* 2-byte bitmap */ + kControlWords * 4 + kScannerLdsReduce <= kLdsPerCu,
               "compacted-output kernel: gram1 + prefix4 + final3 + short bitmap + scanning waves' buffers must fit the CU's LDS");
 
-size_t filterLdsBytes(const PFAC_context *c, bool reduce)
+size_t filterLdsBytes(const PFAC_context *c, bool reduce, bool stage)
 {
     size_t bytes = reduce ? (size_t)kGram1LdsOffset + kGram1LdsBytes + (size_t(1) << c->filter.log2BitsF3) / 8
                           : kLadderLdsOffset + ((size_t(1) << c->filter.log2BitsLad) + (size_t(1) << c->filter.log2BitsF3)) / 8;   /* the level-1 bitmap has its 32 KiB whatever its size */
     if (c->filter.hasShort) bytes += 65536 / 8;
     const size_t scanners = reduce ? (size_t)kReduceScanners : (size_t)kWavesPerBlock - PFAC_WRITERS;
     bytes += kControlWords * sizeof(uint32_t);
-    if (!reduce && PFAC_STAGE_WALK) bytes += scanners * (kQueueCap * 4 + 2 * kWalkStageBytes + (kListCap / 2) * sizeof(uint32_t));
+    if (!reduce && stage) bytes += scanners * (kQueueCap * 4 + 2 * kWalkStageBytes + (kListCap / 2) * sizeof(uint32_t));
     else bytes += scanners * ((reduce ? kReduceQueueCap * (4 + kEntryBytes) : kQueueCap * (4 + kEntryBytesFull)) + (kStageWords + kListCap / 2) * sizeof(uint32_t));
     if (reduce || kStagedPatch) bytes += scanners * kReduceCap * 2 * sizeof(uint32_t);
     if (!reduce) bytes += scanners * kDenseStage * sizeof(uint32_t);
@@ -2429,19 +2445,19 @@ size_t chunkBytes(const PFAC_context *) { return kChunkBytesHost; }
 constexpr int kMaxDevices = 64;
 struct ShapeCache { std::mutex lock; int perCU[kMaxDevices] = {}; };
 
-template <bool TEX, bool HAS_SHORT, bool REDUCE>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, bool STAGE>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a0)
 {
-    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL>;
+    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL, STAGE>;
     static ShapeCache cache;
-    size_t lds = filterLdsBytes(c, REDUCE);
+    size_t lds = filterLdsBytes(c, REDUCE, STAGE);
     int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
     hipError_t de = hipGetDevice(&dev);
     if (de != hipSuccess) return de;
     if (lds > kLdsPerCu || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidValue;
     ScanArgs a = a0;
     a.hotSlots = 0;
-    if (!REDUCE && PFAC_STAGE_WALK != 0) {
+    if (!REDUCE && STAGE) {
         /* the LDS the bitmaps and the waves' buffers leave holds the top of the chained table (buckets breadth first, then the
          * initial state's row): 50 KiB and more for a set of a few thousand patterns, nothing for a Snort-scale set */
 #ifndef PFAC_FILTER_HOT
@@ -2595,12 +2611,26 @@ hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
 template <bool REDUCE>
 hipError_t launchChained(const PFAC_context *c, const ScanArgs &a, bool tex)
 {
+    /* the full-result kernel's walker (PFACX_setWalker): by default what the handle's last full-result launch found -- near
+     * misses all over (most of its scanning waves ended it in stage mode / expecting long slots) -> StageLane, text -> the
+     * register-window walker.  The word is host memory the last block of a launch writes: nothing is waited for, a launch
+     * still under way simply has not voted yet */
+    bool stage = false;
+    if (!REDUCE) {
+        stage = c->walker == PFACX_WALKER_STAGE ||
+                (c->walker == PFACX_WALKER_AUTO && c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0);
+    }
 #ifdef PFAC_QUICK      /* development builds (register / ISA inspection): the bench instances only */
     if (REDUCE || !tex) return hipErrorNotSupported;
-    return c->filter.hasShort ? launchFilter<true, true, false>(c, a) : launchFilter<true, false, false>(c, a);
+    if (stage) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);
+    return c->filter.hasShort ? launchFilter<true, true, false, false>(c, a) : launchFilter<true, false, false, false>(c, a);
 #else
-    if (tex) return c->filter.hasShort ? launchFilter<true, true, REDUCE>(c, a) : launchFilter<true, false, REDUCE>(c, a);
-    return c->filter.hasShort ? launchFilter<false, true, REDUCE>(c, a) : launchFilter<false, false, REDUCE>(c, a);
+    if (!REDUCE && stage) {
+        if (tex) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);
+        return c->filter.hasShort ? launchFilter<false, true, false, true>(c, a) : launchFilter<false, false, false, true>(c, a);
+    }
+    if (tex) return c->filter.hasShort ? launchFilter<true, true, REDUCE, false>(c, a) : launchFilter<true, false, REDUCE, false>(c, a);
+    return c->filter.hasShort ? launchFilter<false, true, REDUCE, false>(c, a) : launchFilter<false, false, REDUCE, false>(c, a);
 #endif
 }
 
@@ -2644,6 +2674,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.numFinal = c->fa.numPatterns;
     a.maxWalk = (uint32_t)c->fa.maxPatternLen;
     a.work = c->d_workCounters;
+    a.hostHint = c->d_modeHint;
     a.denseWord = (uint32_t)pfac::kDenseCountWord;
     a.denseWordOther = (uint32_t)pfac::kDenseCountWordB;
     a.initialState = c->fa.initialState;

@@ -21,8 +21,9 @@ MODES = [
     (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_OFF, "hash-global"),
     (api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, "hash-buffer"),
 ]
-VARIANTS = [(api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto"),
-            (api.PFACX_KERNEL_REFTABLE, "reftable")]
+STAGE = api.PFACX_WALKER_STAGE << 8             # make_handle: the walker of the full-result filter kernel rides in the variant's second byte
+VARIANTS = [(api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_FILTER | STAGE, "filter-stage"), (api.PFACX_KERNEL_NAIVE, "naive"),
+            (api.PFACX_KERNEL_AUTO, "auto"), (api.PFACX_KERNEL_REFTABLE, "reftable")]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -35,7 +36,9 @@ def make_handle(pattern_file, perf, tex, variant=api.PFACX_KERNEL_FILTER):
     h = api.PFAC.create()
     h.setPerfMode(perf)
     h.setTextureMode(tex)
-    h.setKernelVariant(variant)
+    h.setKernelVariant(variant & 0xFF)
+    if variant >> 8:
+        h.setWalker(variant >> 8)                  # (a whole session under one walker: PFAC_TEST_WALKER, pfac_amd/api.py)
     h.readPatternFromFile(pattern_file)
     return h
 

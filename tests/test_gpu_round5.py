@@ -1,0 +1,211 @@
+"""GPU parity tests, round 5: long slots of wide buckets (chains of up to 23 bytes per step, pfac_context.h), the two walkers of the
+full-result filter kernel (PFACX_setWalker: register window / LDS stage), the stage walker's two stream modes and the
+changes between them inside one launch, walks that run off their LDS bytes, and PFACX_WALKER_AUTO's choice from what the
+handle's previous launch found.
+
+Reference model: the walk of PFAC/src/PFAC_kernel.cu:255-299 (one transition per byte, longest match wins) -- whatever a
+walker folds into one step, the result at every position is the oracle's, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from pfac_amd import api  # noqa: E402
+from pfac_amd import workloads as wl  # noqa: E402
+from tests.test_gpu_parity import MODES, assert_same, device_match, make_handle  # noqa: E402
+
+WALKERS = [(api.PFACX_WALKER_WINDOW, "window"), (api.PFACX_WALKER_STAGE, "stage")]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("round5"))
+
+
+def _oracle(pf, data, omp=False):
+    from oracle import binding as ob
+    o = ob.Oracle(pf, hashed=False)
+    want = o.match(data, omp=omp)
+    o.close()
+    return want
+
+
+@pytest.fixture(scope="module")
+def longset(workdir):
+    """Patterns whose tries are long single-successor runs cut in every way a slot can be cut: lengths 9 .. 64 in steps of one
+    (chains of every length 0 .. 23 behind a branch), one 300-byte and one 700-byte pattern (several long slots in a row; deeper
+    than the 128 bytes staged behind a chunk), patterns that are prefixes of patterns at depths 8, 9, 24, 25 (a final state with
+    successors ends a slot early), a shared 24-byte prefix with 40 tails (BASELINE config 5's shape) and a few short ones."""
+    rng = np.random.Generator(np.random.PCG64(55))
+    low = np.arange(97, 123, dtype=np.uint8)
+    def word(n):
+        return low[rng.integers(0, low.size, n)].tobytes()
+    pats = set()
+    for n in range(9, 65):
+        pats.add(word(n))
+    p300, p700 = word(300), word(700)
+    pats.update([p300, p700, p300[:8], p300[:9], p300[:24], p300[:25], p700[:100], p700[:101] + b"X"])
+    prefix = word(24)
+    tails = [word(int(rng.integers(8, 41))) for _ in range(40)]
+    pats.update(prefix + t for t in tails)
+    pats.update([b"zq", b"q", b"zqzqzq"])
+    pats = sorted(pats)
+    pf = wl.write_pattern_file(os.path.join(workdir, "longset.pat"), pats)
+    return pf, pats, prefix, tails, p300, p700
+
+
+def _plant_stream(pats, prefix, tails, p300, p700, n, seed, density):
+    """filler that matches nothing but 'q' now and then, with complete patterns, near misses (last 1..4 bytes wrong) and truncated
+    patterns planted every `density` bytes on average, at offsets that sweep the chunk / tile / lane boundaries"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    data = (rng.integers(0, 6, n, dtype=np.uint8) + 48).astype(np.uint8)           # '0'..'5'
+    data[rng.integers(0, n, n // 997)] = ord("q")
+    pool = [p for p in pats if len(p) >= 9] + [prefix + t for t in tails] * 3 + [p300, p700]
+    at = 7
+    k = 0
+    while at + 800 < n:
+        p = pool[int(rng.integers(0, len(pool)))]
+        kind = k % 4
+        if kind == 1:
+            cut = int(rng.integers(1, 5))
+            p = p[:-cut] + b"#" * cut                                               # near miss: walked almost to the end
+        elif kind == 2:
+            p = p[:int(rng.integers(1, len(p)))]                                    # truncated: the input goes on with filler
+        data[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        at += len(p) + int(rng.integers(0, 2 * density))
+        k += 1
+    return data
+
+
+@pytest.mark.parametrize("perf,tex,mode_name", MODES)
+@pytest.mark.parametrize("variant,variant_name", [(api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_WINDOW << 8), "filter-window"),
+                                                  (api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_STAGE << 8), "filter-stage"),
+                                                  (api.PFACX_KERNEL_NAIVE, "tiled"), (api.PFACX_KERNEL_REFTABLE, "reftable")])
+def test_long_slots_in_every_kernel(workdir, longset, perf, tex, mode_name, variant, variant_name):
+    pf, pats, prefix, tails, p300, p700 = longset
+    n = 2048 * 150 + 333
+    data = _plant_stream(pats, prefix, tails, p300, p700, n, seed=1, density=40)
+    # patterns across every 2 KiB chunk boundary at every distance 0 .. 99, and up against the end of the input
+    for j in range(100):
+        at = 2048 * (10 + j) - j
+        p = (prefix + tails[j % len(tails)]) if j % 3 else (p300 if j % 2 else p700[:200])
+        data[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    data[n - 300:] = np.frombuffer(p300, dtype=np.uint8)
+    want = _oracle(pf, data)
+    assert np.count_nonzero(want) > 2000
+    h = make_handle(pf, perf, tex, variant)
+    try:
+        assert_same(device_match(h, data), want, f"long slots/{mode_name}/{variant_name}")
+        # compacted output walks the same table (register window; extension units fetched on demand)
+        d_in = torch.from_numpy(data).to("cuda:0")
+        d_ids = torch.full((n,), -3, dtype=torch.int32, device="cuda:0")
+        d_pos = torch.full((n,), -3, dtype=torch.int32, device="cuda:0")
+        _, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_ids.data_ptr(), d_pos.data_ptr())
+        nz = np.nonzero(want)[0]
+        assert count == nz.size
+        assert np.array_equal(d_pos[:count].cpu().numpy(), nz) and np.array_equal(d_ids[:count].cpu().numpy(), want[nz])
+    finally:
+        h.destroy()
+
+
+@pytest.fixture(scope="module")
+def switching(workdir, longset):
+    """48 MiB in which stretches of plain filler (a few MiB: text mode) alternate with stretches full of near misses of long
+    patterns (a walk every ~60 bytes, 30..60 bytes deep: stage mode), so that every scanning wave changes its mode several
+    times inside ONE launch of the filter kernel; patterns straddle the places where the stream changes its nature."""
+    pf, pats, prefix, tails, p300, p700 = longset
+    n = (48 << 20) + 4099
+    parts = []
+    seed = 100
+    left = n
+    while left > 0:
+        for density, size in ((4000, 5 << 20), (12, 3 << 20), (100000, 2 << 20), (6, 1 << 20)):
+            size = min(size, left)
+            if size <= 0:
+                break
+            parts.append(_plant_stream(pats, prefix, tails, p300, p700, size, seed, density) if size > 2000 else np.full(size, 48, np.uint8))
+            seed += 1
+            left -= size
+    data = np.concatenate(parts)
+    assert data.size == n
+    want = _oracle(pf, data, omp=True)
+    return pf, data, want
+
+
+@pytest.mark.parametrize("walker,walker_name", [(api.PFACX_WALKER_AUTO, "auto")] + WALKERS)
+def test_stream_that_changes_its_nature_inside_one_launch(switching, walker, walker_name):
+    pf, data, want = switching
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO | (walker << 8))
+    try:
+        for call in range(3):                      # AUTO: the first call runs the window walker, the next ones what the votes say
+            assert_same(device_match(h, data), want, f"changing stream/{walker_name}/call {call}")
+            st = h.scanStats()
+            if walker == api.PFACX_WALKER_STAGE:
+                assert st["walker"] == api.PFACX_WALKER_STAGE
+            if walker == api.PFACX_WALKER_WINDOW or (walker == api.PFACX_WALKER_AUTO and call == 0):
+                assert st["walker"] == api.PFACX_WALKER_WINDOW
+    finally:
+        h.destroy()
+
+
+def test_auto_walker_follows_the_stream(workdir):
+    """PFACX_WALKER_AUTO: a handle's first full-result launch runs the register-window walker; after a launch over a stream full
+    of near misses (most scanning waves end it expecting long slots) the next one runs the stage walker, and after a launch
+    over text the window walker again.  Results are the oracle's throughout (here: the committed small C5 / C3 generators,
+    64 MiB each, against the oracle)."""
+    cfg5, cfg3 = wl.make_config("c5"), wl.make_config("c3")
+    # one pattern set for both streams: the near-miss patterns + a slice of the Snort-style set
+    pats = list(cfg5.patterns) + [p for p in cfg3.patterns[:2000] if p not in set(cfg5.patterns)]
+    pf = wl.write_pattern_file(os.path.join(workdir, "auto.pat"), pats)
+    n = 64 << 20
+    near, text = cfg5.input_slice(n, 0), cfg3.input_slice(n, 0)
+    want_near, want_text = _oracle(pf, near, omp=True), _oracle(pf, text, omp=True)
+    h = make_handle(pf, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    try:
+        seen = []
+        for stream, want, name in ((text, want_text, "text"), (near, want_near, "near"), (near, want_near, "near"), (near, want_near, "near"),
+                                   (text, want_text, "text"), (text, want_text, "text"), (text, want_text, "text")):
+            assert_same(device_match(h, stream), want, f"auto walker/{name}")
+            st = h.scanStats()
+            seen.append((name, st["walker"], st["stageModeWaves"]))
+        walkers = [w for _, w, _ in seen]
+        W, S = api.PFACX_WALKER_WINDOW, api.PFACX_WALKER_STAGE
+        assert walkers[0] == W and walkers[1] == W, seen      # text first; the near-miss stream's first launch still has the text verdict
+        assert walkers[2] == S and walkers[3] == S, seen      # ... its next launches run the stage walker
+        assert walkers[4] == S, seen                          # the first text launch behind it: still the near-miss verdict
+        assert walkers[5] == W and walkers[6] == W, seen      # and back
+        assert seen[1][2] > 0 and seen[3][2] > 0 and seen[6][2] == 0, seen
+    finally:
+        h.destroy()
+
+
+@pytest.mark.parametrize("walker,walker_name", WALKERS)
+def test_full_size_near_miss_stream_equals_reference_digest(workdir, walker, walker_name):
+    """BASELINE config 5 at full size (1 GiB) under both walkers: count, checksum and FNV-1a-64 of the result vector equal the
+    reference's PFAC_CPU_OMP digest (tests/golden/full_digests.json); steps per walk as the round's target asks (<= 4.5)."""
+    from tests.test_gpu_round2 import _digest_record
+    ref = _digest_record("c5", 0, 1024)["last"]
+    cfg = wl.make_config("c5")
+    pf = wl.write_pattern_file(os.path.join(workdir, "c5full.pat"), cfg.patterns)
+    n = 1 << 30
+    d_in = torch.from_numpy(cfg.input_slice(n, 0)).to("cuda:0")
+    d_out = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    h = make_handle(pf, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO | (walker << 8))
+    try:
+        for _ in range(2):
+            h.matchFromDevice(d_in.data_ptr(), n, d_out.data_ptr())
+        torch.cuda.synchronize()
+        st = h.scanStats()
+        assert st["walker"] == walker
+        out = d_out.cpu().numpy()
+        pos = np.flatnonzero(out)
+        assert int(pos.size) == ref["match_count"]
+        assert wl.fnv1a_sparse_i32(pos, out[pos], n) == ref["fnv1a64"]
+        steps = st["laneSteps"] / max(st["walksStarted"], 1)
+        assert steps <= (4.5 if walker == api.PFACX_WALKER_STAGE else 5.0), steps
+    finally:
+        h.destroy()

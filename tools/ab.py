@@ -41,6 +41,8 @@ def main():
                     if os.path.exists(os.path.join(src, f)):
                         shutil.copy2(os.path.join(src, f), os.path.join(LIB, f))
                 env = dict(os.environ)
+                if name != "tree":
+                    env["PFAC_AB_OLD_LIBS"] = "1"
                 env.update(e.split("=", 1) for e in envs)
                 for w in a.workloads.split(","):
                     ww, extra = (("c5", ["--perf-mode", "hash"]) if w == "c5h" else (w, []))

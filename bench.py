@@ -58,6 +58,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 
 ALGO_BYTES_PER_INPUT_BYTE = 5    # 1 B input read + 4 B int32 result written
 SETTLE_STEPS = 32                # untimed launches after host-side checks, before the warmup steps
 OTHER_STEPS = 10                 # timed launches per entry of "other_configs"
+HOST_CALLS = 20                  # timed PFAC_matchFromHost / ...Reduce calls per buffer kind (median, best, p90)
 DIGESTS = os.path.join(ROOT, "tests", "golden", "full_digests.json")
 SCRATCH = os.path.join(ROOT, "gpurun_out", "bench")
 
@@ -755,6 +756,7 @@ def strong_rank_main(args):
                 "texture_mode": int(run0.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname, "build": build_info(),
                 "platform": args.platform, "bytes_total": facts["total_bytes"], "slices_per_rank": len(sset.runs), "matches": facts["matches"],
                 "bit_exact": facts["bit_exact"], "bit_exact_method": method, "dist_backend": args.dist_backend if use_dist else None,
+                "ranks_seen": sorted(int(r) for r in allf[:, 4]),
                 "folded_result": facts["folded_result"], "folded_reference": facts["folded_reference"],
             },
             "roofline": roofline_block(per_launch, run0.n_read, kname),
@@ -956,16 +958,38 @@ def rank_main(args):
                     first_ms = (time.perf_counter() - t0h) * 1e3
                     run.handle.matchFromHost(h_in.data_ptr(), hn, h_out.data_ptr())
                     times = []
-                    for _ in range(5):
+                    for _ in range(HOST_CALLS):
                         t0h = time.perf_counter()
                         run.handle.matchFromHost(h_in.data_ptr(), hn, h_out.data_ptr())
                         times.append(time.perf_counter() - t0h)
                     th = float(np.median(times))
                     keep = pos < hn - info.maxPatternLen
                     hp = np.flatnonzero(h_out.numpy()[: hn - info.maxPatternLen])
-                    host_path[kind] = {"input_GBps": round(hn / th / 1e9, 2), "ms_per_call": round(th * 1e3, 3), "statistic": "median of 5 calls after 2",
-                                       "best_ms": round(min(times) * 1e3, 3), "first_call_ms": round(first_ms, 3),
+                    host_path[kind] = {"input_GBps": round(hn / th / 1e9, 2), "ms_per_call": round(th * 1e3, 3), "statistic": f"median of {HOST_CALLS} calls after 2",
+                                       "best_ms": round(min(times) * 1e3, 3), "p90_ms": round(float(np.percentile(times, 90)) * 1e3, 3),
+                                       "worst_ms": round(max(times) * 1e3, 3), "first_call_ms": round(first_ms, 3),
                                        "same_result": bool(np.array_equal(hp, pos[keep]))}
+                    if kind == "pinned":
+                        # PFAC_matchFromHostReduce through the same pieces (upload of piece i + 1 beside the compacted scan of piece i, the
+                        # pairs appended in position order): 1 B per position over the link, no result vector to fill
+                        r_ids = torch.empty(hn, dtype=torch.int32).pin_memory()
+                        r_pos = torch.empty(hn, dtype=torch.int32).pin_memory()
+                        for _ in range(2):
+                            _, cnt = run.handle.matchFromHostReduce(h_in.data_ptr(), hn, r_ids.data_ptr(), r_pos.data_ptr())
+                        rtimes = []
+                        for _ in range(HOST_CALLS):
+                            t0h = time.perf_counter()
+                            _, cnt = run.handle.matchFromHostReduce(h_in.data_ptr(), hn, r_ids.data_ptr(), r_pos.data_ptr())
+                            rtimes.append(time.perf_counter() - t0h)
+                        tr = float(np.median(rtimes))
+                        kp = pos < hn - info.maxPatternLen
+                        got_pos = r_pos.numpy()[:cnt]
+                        sel = got_pos < hn - info.maxPatternLen
+                        host_path["reduce"] = {"input_GBps": round(hn / tr / 1e9, 2), "ms_per_call": round(tr * 1e3, 3), "statistic": f"median of {HOST_CALLS} calls after 2, pinned buffers",
+                                               "best_ms": round(min(rtimes) * 1e3, 3), "p90_ms": round(float(np.percentile(rtimes, 90)) * 1e3, 3), "pairs": int(cnt),
+                                               "same_result": bool(np.array_equal(got_pos[sel], pos[kp]) and np.array_equal(r_ids.numpy()[:cnt][sel], ids[kp])),
+                                               "device_bytes_tables_plus_scratch": int(run.handle.info().deviceTableBytes + run.handle.info().deviceScratchBytes)}
+                        del r_ids, r_pos
                     del h_in, h_out
                 # what bounds it: the upload (1 B per position over the link) and the zero fill of the caller's vector by
                 # the call's helper threads (4 B per position of host memory bandwidth)
@@ -984,7 +1008,7 @@ def rank_main(args):
                 host_path["bound"] = "per position: 1 B over the host link + 4 B of zero fill in host memory (2-8 helper threads, streaming stores, piece by piece) " \
                                      "+ the pairs of the matches, scattered piece by piece; the uploads are queued by a thread of their own, the scan of a " \
                                      "32 Mi-position piece runs beside the upload of the next.  Fill and link share the host's memory channels."
-                host_path["of_the_link"] = {k: round(host_path[k]["input_GBps"] / host_path["link_h2d_GBps_pinned"], 3) for k in ("pageable", "pinned")}
+                host_path["of_the_link"] = {k: round(host_path[k]["input_GBps"] / host_path["link_h2d_GBps_pinned"], 3) for k in ("pageable", "pinned", "reduce")}
                 del probe_in, fill
                 out["host_path_pcie_inclusive"] = host_path
             # What this part sustains for the traffic shape of the path with nothing else in it ("also

@@ -77,6 +77,9 @@ typedef struct {
     size_t trailingBytesIgnored; /* bytes behind the last '\n' of the pattern file that were ignored (0: none)  */
     size_t deviceTableBytes;  /* device memory the pattern set holds: chained table, initial row, prefilter bitmaps,
                                  launch counters; the reference-layout table only while PFACX_KERNEL_REFTABLE is selected */
+    size_t deviceScratchBytes; /* device memory the handle's calls have left allocated (grow-only; PFACX_trim frees it): the two staging
+                                 pieces of PFAC_matchFromHost / ...Reduce (9 bytes per position of a piece), the ordering scratch of the
+                                 compacted output, the list of pattern-dense chunks */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);

@@ -66,7 +66,7 @@ class PFACX_info(C.Structure):
         ("filterLog2BitsLadder", C.c_int), ("filterLog2BitsFinal3", C.c_int), ("filterBitsSetLadder", C.c_size_t),
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
-        ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t),
+        ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
     ]
 
 

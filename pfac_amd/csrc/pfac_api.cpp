@@ -13,7 +13,9 @@
 #include <sched.h>
 #include <hip/hip_runtime_api.h>
 
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -89,8 +91,6 @@ void freeResources(PFAC_context *c)
     if (c->h_modeHint) { (void)hipHostFree(c->h_modeHint); c->h_modeHint = c->d_modeHint = nullptr; }
     devFree(c->d_reduceScratch);
     c->reduceScratchBytes = 0;
-    devFree(c->d_hostReduce);
-    c->hostReduceBytes = 0;
     freeHostStage(c);
     for (auto &e : c->evTime) { if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e)); e = nullptr; }
     c->kernelTiming = c->evTimeRecorded = false;
@@ -557,6 +557,10 @@ static PFAC_status_t matchHostFullVector(PFAC_context *c, char *h_inputString, s
  * that nothing reads before the caller does) */
 static void fillZeroStreaming(int *p, size_t n)
 {
+#if !defined(__SSE2__)
+    std::memset(p, 0, n * sizeof(int));                        /* hosts without SSE2 (aarch64, ppc64 nodes with AMD GPUs): plain stores */
+    return;
+#else
     static const bool plain = std::getenv("PFAC_HOST_FILL_MEMSET") != nullptr;
     if (plain) { std::memset(p, 0, n * sizeof(int)); return; }
     while (n && (reinterpret_cast<uintptr_t>(p) & 63u)) { *p++ = 0; n--; }
@@ -569,6 +573,7 @@ static void fillZeroStreaming(int *p, size_t n)
     }
     while (n) { *p++ = 0; n--; }
     _mm_sfence();
+#endif
 }
 
 PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result)
@@ -602,17 +607,22 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
     (void)hipGetDevice(&device);
     std::thread uploader;
     bool ok = true;
-    try {
-        uploader = std::thread([&]() {
-            if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
-            for (size_t i = 0; i < numPieces; i++) {
-                while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
-                if (stopUploads.load(std::memory_order_relaxed)) return;
-                if (!uploadPiece(i)) { uploadFailed.store(true); return; }
-                uploadsQueued.store(i + 1, std::memory_order_release);
-            }
-        });
-    } catch (...) { ok = false; }
+    if (numPieces == 1) {                                      /* nothing to overlap with: no thread (tens of microseconds of a small call) */
+        ok = uploadPiece(0);
+        uploadsQueued.store(1);
+    } else {
+        try {
+            uploader = std::thread([&]() {
+                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
+                for (size_t i = 0; i < numPieces; i++) {
+                    while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (stopUploads.load(std::memory_order_relaxed)) return;
+                    if (!uploadPiece(i)) { uploadFailed.store(true); return; }
+                    uploadsQueued.store(i + 1, std::memory_order_release);
+                }
+            });
+        } catch (...) { ok = false; }
+    }
     const double tUp0 = since();
 
     /* Zero fill of the caller's vector, in parallel with everything below: 4 bytes of host memory per position against 1 byte
@@ -668,7 +678,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
             if (filled[k].load(std::memory_order_relaxed) == 0) { std::memset(h_matched_result + lo, 0, (hi - lo) * sizeof(int)); filled[k].store(1, std::memory_order_relaxed); }
             return;
         }
-        if (filled[k].load(std::memory_order_relaxed) < helpers) {
+        if (filled[k].load(std::memory_order_acquire) < helpers) {          /* acquire: the pairs are scattered onto words the fillers wrote */
             for (unsigned t = started; t < helpers; t++) {          /* the shares of threads that could not be started */
                 size_t lo, hi;
                 share(k, t, helpers, lo, hi);
@@ -728,6 +738,87 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
         if (st != PFAC_STATUS_SUCCESS) return st;
     }
     return PFAC_STATUS_SUCCESS;
+}
+
+/*
+ * PFAC_matchFromHostReduce on the GPU (ref PFAC.cpp:1010-1128: one allocation of size + 8 * size device bytes, one blocking
+ * copy, one scan, two copies back).  Same pipeline as PFAC_matchFromHost: the stream goes through the handle's staging
+ * buffers in pieces of kHostReducePiece positions, piece i + 1 is uploaded (by a thread of its own: see matchHostOnGpu) while
+ * piece i is scanned by the compacted-output kernel -- together with the maxPatternLen bytes behind it -- and its pairs, in
+ * position order, are copied straight behind those of the pieces before it: pieces are in stream order, so the whole list
+ * is.  A pair whose position lies in the overlap belongs to the next piece, which finds it again.  Device memory: two
+ * pieces (9 bytes per position) instead of 9 bytes for every position of the stream.
+ */
+constexpr size_t kHostReducePiece = size_t(16) << 20;
+PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, int *h_matched_result, int *h_pos, int *h_num_matched)
+{
+    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
+    const size_t overlap = (size_t)c->fa.maxPatternLen;
+    const size_t piece = size < kHostReducePiece ? size : kHostReducePiece;
+    PFAC_status_t st = ensureHostStage(c, piece + overlap);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    correctTextureMode(c);
+    PFAC_reduce_kernel_protoType reduce = c->perfMode == PFAC_TIME_DRIVEN ? c->reduce_kernel_ptr : c->reduce_inplace_kernel_ptr;
+    hipStream_t up = static_cast<hipStream_t>(c->stageUp);
+    const size_t numPieces = (size + piece - 1) / piece;
+    auto uploadPiece = [&](size_t i) -> bool {               /* into buffer i & 1, on the upload stream */
+        const size_t off = i * piece;
+        const size_t mine = size - off < piece ? size - off : piece;
+        const size_t scanned = size - off < mine + overlap ? size - off : mine + overlap;
+        return hipMemcpyAsync(c->d_stageIn[i & 1], h_inputString + off, scanned, hipMemcpyHostToDevice, up) == hipSuccess &&
+               hipEventRecord(static_cast<hipEvent_t>(c->evUp[i & 1]), up) == hipSuccess;
+    };
+    std::atomic<size_t> scansDone{0}, uploadsQueued{0};
+    std::atomic<bool> uploadFailed{false}, stopUploads{false};
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::thread uploader;
+    bool ok = true;
+    if (numPieces == 1) {                                      /* nothing to overlap: no thread */
+        ok = uploadPiece(0);
+        uploadsQueued.store(1);
+    } else {
+        try {
+            uploader = std::thread([&]() {
+                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
+                for (size_t i = 0; i < numPieces; i++) {
+                    while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (stopUploads.load(std::memory_order_relaxed)) return;
+                    if (!uploadPiece(i)) { uploadFailed.store(true); return; }
+                    uploadsQueued.store(i + 1, std::memory_order_release);
+                }
+            });
+        } catch (...) { ok = false; }
+    }
+    size_t total = 0;
+    for (size_t i = 0; i < numPieces && ok && st == PFAC_STATUS_SUCCESS; i++) {
+        const int b = (int)(i & 1);
+        const size_t off = i * piece;
+        const size_t mine = size - off < piece ? size - off : piece;
+        const size_t scanned = size - off < mine + overlap ? size - off : mine + overlap;
+        while (uploadsQueued.load(std::memory_order_acquire) <= i && !uploadFailed.load(std::memory_order_relaxed)) std::this_thread::yield();
+        ok = !uploadFailed.load(std::memory_order_relaxed) && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
+        if (!ok) break;
+        int count = 0;
+        st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)scanned, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
+        if (st != PFAC_STATUS_SUCCESS) break;
+        scansDone.store(i + 1, std::memory_order_release);     /* the scan is synchronous: its input buffer may take piece i + 2 */
+        if (count == 0) continue;
+        /* total <= off (a position has at most one pair) and count <= scanned <= size - off: the caller's arrays (size entries) hold them */
+        if (hipMemcpy(h_pos + total, c->d_stagePos[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        size_t keep = (size_t)count;                           /* positions ascend: those in the overlap are a suffix */
+        while (keep > 0 && (size_t)h_pos[total + keep - 1] >= mine) keep--;
+        if (keep && hipMemcpy(h_matched_result + total, c->d_stageOut[b], keep * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (off) for (size_t k = 0; k < keep; k++) h_pos[total + k] += (int)off;
+        total += keep;
+    }
+    if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
+    stopUploads.store(true);
+    if (uploader.joinable()) uploader.join();
+    const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+    if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
+    if (st == PFAC_STATUS_SUCCESS) *h_num_matched = (int)total;
+    return st;
 }
 
 } // namespace
@@ -884,26 +975,7 @@ PFAC_status_t PFAC_matchFromHostReduce(PFAC_handle_t handle, char *h_inputString
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
     std::lock_guard<std::mutex> guard(handle->lock);
 
-    /* one handle-owned block: input (padded to 16 bytes) | ids | positions */
-    const size_t inBytes = (size + 15) & ~size_t(15);
-    const size_t need = inBytes + 2 * size * sizeof(int);
-    if (handle->hostReduceBytes < need) {
-        devFree(handle->d_hostReduce);
-        handle->hostReduceBytes = 0;
-        if (hipMalloc(&handle->d_hostReduce, need) != hipSuccess) {
-            (void)hipGetLastError();
-            handle->d_hostReduce = nullptr;
-            return PFAC_STATUS_CUDA_ALLOC_FAILED;
-        }
-        handle->hostReduceBytes = need;
-    }
-    char *d_in = static_cast<char *>(handle->d_hostReduce);
-    int *d_out = reinterpret_cast<int *>(d_in + inBytes), *d_pos = d_out + size;
-    if (hipMemcpy(d_in, h_inputString, size, hipMemcpyHostToDevice) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
-    correctTextureMode(handle);
-    PFAC_reduce_kernel_protoType fn =
-        handle->perfMode == PFAC_TIME_DRIVEN ? handle->reduce_kernel_ptr : handle->reduce_inplace_kernel_ptr;
-    return fn(handle, reinterpret_cast<int *>(d_in), (int)size, d_out, d_pos, h_num_matched, h_matched_result, h_pos);
+    return matchHostReduceOnGpu(handle, h_inputString, size, h_matched_result, h_pos, h_num_matched);
 }
 
 /* ------------------------------------------------------------- extensions */
@@ -961,6 +1033,13 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         if (handle->d_prefix4) dev += handle->filter.prefix4.size() * sizeof(uint32_t);
         if (handle->d_workCounters) dev += pfac::kWorkCounterWords * sizeof(unsigned int);
         v.deviceTableBytes = dev;
+        /* ... and what its calls have left allocated (grow-only, PFACX_trim gives it back): the two staging pieces of the host
+         * paths (input + ids + positions: 9 bytes per position), the scratch the compacted output is ordered through, the list
+         * of pattern-dense chunks */
+        size_t scratch = 0;
+        if (handle->hostStagePositions) scratch += 2 * (((handle->hostStagePositions + 3) & ~size_t(3)) + 2 * handle->hostStagePositions * sizeof(int));
+        scratch += handle->reduceScratchBytes + handle->denseListEntries * sizeof(unsigned int);
+        v.deviceScratchBytes = scratch;
     }
     v.structSize = callerSize < sizeof(v) ? callerSize : sizeof(v);
     std::memcpy(info, &v, v.structSize);
@@ -1226,11 +1305,15 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename)
     c->patternFile = filename;
     c->perfMode = (int)h.perfMode;
     c->fa = std::move(fa);
-    c->filter = std::move(f);
+    /* The prefilter bitmaps are rebuilt from the checked trie as well, like every table (30 ms for a Snort-scale set): a stale or
+     * crafted file with a valid checksum could not make a kernel read outside a bitmap (addresses are masked), but a cleared
+     * bit silently drops matches, and the full-result path (gram3 / ladder from the file) could disagree with the compacted-
+     * output path (gram1 / prefix4, always rebuilt).  The file's copies are read, size-checked and dropped. */
+    c->filter = pfac::Filter();
     c->isPatternsReady = true;
     pfac::buildInitialRow(c->fa, c->h_initialRow);
-    try { pfac::buildReduceFilter(c->fa, c->filter); } catch (const std::bad_alloc &) { freeResources(c); return PFAC_STATUS_ALLOC_FAILED; }
-    PFAC_status_t st = bindCommon(c, /*build=*/false);
+    PFAC_status_t st;
+    try { st = bindCommon(c, /*build=*/true); } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
     if (st == PFAC_STATUS_SUCCESS) st = bindTable(c);
     if (st != PFAC_STATUS_SUCCESS) { freeResources(c); return st; }
     return PFAC_STATUS_SUCCESS;
@@ -1245,8 +1328,6 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle)
     freeHostStage(handle);
     devFree(handle->d_reduceScratch);
     handle->reduceScratchBytes = 0;
-    devFree(handle->d_hostReduce);
-    handle->hostReduceBytes = 0;
     devFree(handle->d_denseList);
     handle->denseListEntries = 0;
     for (auto &child : handle->children) if (child.second) (void)PFACX_trim(child.second);

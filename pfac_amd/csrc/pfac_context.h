@@ -220,11 +220,7 @@ struct PFAC_context {
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;
     size_t reduceScratchBytes = 0;
-    /* device copies of PFAC_matchFromHostReduce (input, ids, positions): grow-only as well (the reference
-     * allocates and frees the three per call, PFAC.cpp:1075-1124) */
-    void *d_hostReduce = nullptr;
-    size_t hostReduceBytes = 0;
-    /* staging of PFAC_matchFromHost on the GPU platform (pfac_api.cpp): two input and two result
+    /* staging of PFAC_matchFromHost / PFAC_matchFromHostReduce on the GPU platform (pfac_api.cpp): two input and two result
      * buffers of hostStageChunk (+ overlap) positions, two copy streams, events; created on first use */
     char *d_stageIn[2] = {nullptr, nullptr};
     int *d_stageOut[2] = {nullptr, nullptr};

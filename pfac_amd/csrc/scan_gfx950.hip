@@ -337,8 +337,10 @@ constexpr uint32_t kEntryBytes = 20;           /* input bytes a queue entry brin
 constexpr uint32_t kEntryBytesFull = 36;       /* ... full-result kernel: 16 more, so that a walk 21..36 bytes deep (near misses of long patterns) needs no
                                                 * gathered input load: those were 40 % of the gathered loads of BASELINE config 5 */
 #ifndef PFAC_WIDE_SPEC
-#define PFAC_WIDE_SPEC 1                       /* full-result kernel: 1 = the extension unit of a wide bucket's slot is fetched WITH the header (four more registers
-                                                * per lane); 0 = fetched when a header's first 8 chain bytes have matched, and waited for on the spot */
+#define PFAC_WIDE_SPEC 0                       /* register-window walker of a full-result kernel: 1 = the extension unit of a wide bucket's slot can be fetched WITH
+                                                * the header (four more registers per lane, 0.5 % of the text stream's launch time); 0 = fetched when a header's first
+                                                * 8 chain bytes have matched, and waited for on the spot.  The window walker is the one for text (a stream full of
+                                                * near misses gets the stage walker from its second launch on: launchChained), so it does not speculate */
 #endif
 
 __device__ __forceinline__ uint32_t slotLen(uint32_t meta) { return __builtin_amdgcn_ubfe(meta, pfac::kSlotLenShift, 5u); }
@@ -387,6 +389,7 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
     uint32_t wend = 0;
     bool needWin = false, needSlot = true;
     bool haveE = false, needExt = false, usedE = false;   /* kSpec: the unit in E belongs to the slot in t; a long slot's header matched without it; ... and it was looked at */
+    bool tookLong = false;                     /* !kSpec: this step went through a long slot (its unit fetched on the spot) */
     bool first = false;                        /* the slot in flight comes from the jump table */
     bool longWalk = false;                     /* a walk that outran its window once fetches a new one with every step from then on */
 
@@ -506,6 +509,7 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
         bool ok = mine & (((diff << 8) << (56u - 8u * lenIn)) == 0);
         /* a matching slot whose bytes are not all in the window: fetch them and come back.  A long slot whose header bytes
          * match (kSpec) needs all 24 bytes in the window (windowBytesExt shifts by at most three dwords) and its unit */
+        tookLong = false;
         const bool longGo = kSpec && (isLong & ok & coveredIn);
         needWin = mine & (!coveredIn | (longGo & (q + 24u > wend)));
         needExt = longGo & !haveE;
@@ -544,6 +548,7 @@ template <bool TEX, uint32_t ENTRY> struct ChainLane {
                     y2 = __builtin_amdgcn_alignbyte(in4.w, in4.z, sh);
                     y3 = __builtin_amdgcn_alignbyte(in1, in4.w, sh);
                     longWalk |= ok & isLong;                   /* the window is behind the walk now */
+                    tookLong = ok & isLong;
                 }
                 const bool okLong = (((x1 ^ t.w) >> 24) == 0) & extensionEqual(e, y0, y1, y2, y3, len);
                 ok &= !isLong | okLong;
@@ -1197,6 +1202,11 @@ void pfac_scan_filter(ScanArgs a)
                     specIdle = (loaded < 8u || used * 4u < loaded) ? specIdle + 1u : 0u;
                     if (specIdle >= kSpecOffRounds) { specOn = false; specIdle = 0; }
                 }
+            }
+            if constexpr (!REDUCE && !kStageWalk && !kSpecKernel) {
+                /* the window walker's evidence that its stream is full of near misses: walks through long slots, walks that outran their window */
+                const bool odd = walk[s].tookLong | walk[s].needWin;
+                if (__ballot(alive[s] & odd) != 0) chunkEvents += (uint32_t)__popcll(__ballot(alive[s] & odd));
             }
             report(alive[s] & !cont, walk[s], s);
             alive[s] = cont;

@@ -209,3 +209,44 @@ def test_full_size_near_miss_stream_equals_reference_digest(workdir, walker, wal
         assert steps <= (4.5 if walker == api.PFACX_WALKER_STAGE else 5.0), steps
     finally:
         h.destroy()
+
+
+# ------------------------------------------------------------------------------------- PFAC_matchFromHostReduce through the pieces
+
+def test_match_from_host_reduce_pieces_equal_oracle(workdir):
+    """PFAC_matchFromHostReduce on the GPU platform (ref PFAC.cpp:1010-1128; known answer user guide r1.2 p.29) goes through the
+    same staged pieces as PFAC_matchFromHost -- 16 Mi positions each, piece i + 1 uploading while piece i is scanned -- and the
+    pairs come back in position order across the pieces.  A 70 MiB text stream (five pieces) with the longest pattern planted
+    across every cut, and a 42 MiB stream whose end matches at every position (3.4 M pairs from one piece), against the
+    oracle's result vector; the device memory the call leaves allocated is two pieces, not 9 bytes for every position."""
+    from oracle import binding as ob
+    pats = [b"a", b"aa", b"aaa", b"aaaa", b"ab", b"b" * 7, b"abc" * 5] + wl.snort_patterns(2000)
+    pf = wl.write_pattern_file(os.path.join(workdir, "hostreduce.pat"), pats)
+    longest = max(pats, key=len)
+    piece = 16 << 20
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    try:
+        for which, n in (("text", (70 << 20) + 12345), ("dense end", (42 << 20) + 77), ("one small piece", 100003)):
+            data = wl.http_stream(n, wl.http_message_pool(pats[7:], pool_size=256, embed_fraction=0.3)).copy()
+            data[data == ord("a")] = ord("e")
+            if which == "dense end":
+                data[(39 << 20):] = ord("a")
+            for k in range(1, n // piece + 1):
+                for at in (k * piece - 1, k * piece - len(longest) // 2, k * piece - len(longest)):
+                    if 0 <= at and at + len(longest) <= n:
+                        data[at:at + len(longest)] = np.frombuffer(longest, dtype=np.uint8)
+            want = o.match(data, hashed=True, omp=True)
+            nz = np.flatnonzero(want)
+            ids = np.full(n, -9, dtype=np.int32)
+            pos = np.full(n, -9, dtype=np.int32)
+            for trial in range(2):
+                _, count = h.matchFromHostReduce(data.ctypes.data, n, ids.ctypes.data, pos.ctypes.data)
+                assert count == nz.size, (which, count, nz.size)
+                assert np.array_equal(pos[:count], nz) and np.array_equal(ids[:count], want[nz]), which
+            info = h.info()
+            # two staged pieces (9 bytes per position) + the scratch the pairs of one piece are ordered through (grows with the densest piece seen)
+            assert info.deviceTableBytes + info.deviceScratchBytes <= (300 << 20 if which == "text" else 400 << 20), (which, info.deviceTableBytes, info.deviceScratchBytes)
+    finally:
+        h.destroy()
+        o.close()

@@ -476,6 +476,38 @@ def test_trailing_bytes_survive_a_compiled_set(tmp_path):
     b.destroy()
 
 
+def test_compiled_set_with_cleared_filter_bitmaps_still_matches(workloads, oracle_results, tmp_path):
+    """The prefilter bitmaps in a compiled set are not believed either (round 4 advice: a stale or crafted file with a valid
+    checksum could clear bits -- no out-of-bounds read, addresses are masked, but matches silently dropped, and the
+    full-result path, gram3 / ladder from the file, could disagree with the compacted-output path, gram1 / prefix4 always
+    rebuilt).  They are rebuilt from the checked trie at load: a file whose 3-gram, ladder, length-3 and 2-byte bitmaps are
+    all zero -- checksum recomputed -- loads, reports the bitmaps a fresh compile would, and matches like it."""
+    w = workloads["c3"]
+    a = api.PFAC.createHostOnly()
+    a.setPerfMode(api.PFAC_SPACE_DRIVEN)
+    a.readPatternFromFile(w.pattern_file)
+    path = str(tmp_path / "set.pfacx")
+    a.saveCompiled(path)
+    raw = bytearray(open(path, "rb").read())
+    head, payload = raw[:40], raw[40:]
+    cleared = 0
+    for tag, off, size in _sections(payload):
+        if tag in (10, 11, 12, 13):                                 # kSecGram3, kSecLadder, kSecFinal3, kSecShort
+            payload[off:off + size] = bytes(size)
+            cleared += 1
+    assert cleared == 4
+    head[32:40] = _fnv1a64(bytes(payload)).to_bytes(8, "little")
+    open(path, "wb").write(bytes(head) + bytes(payload))
+    b = api.PFAC.createHostOnly()
+    b.loadCompiled(path)
+    for which in (api.PFACX_TABLE_FILTER_GRAM3, api.PFACX_TABLE_FILTER_LADDER, api.PFACX_TABLE_FILTER_FINAL3, api.PFACX_TABLE_FILTER_SHORT):
+        assert np.array_equal(a.table(which), b.table(which)) and (which == api.PFACX_TABLE_FILTER_SHORT or a.table(which).any())
+    assert a.info().filterBitsSet == b.info().filterBitsSet and a.info().filterBitsSetLadder == b.info().filterBitsSetLadder
+    assert np.array_equal(b.match_host_array(w.data), oracle_results["c3"])
+    a.destroy()
+    b.destroy()
+
+
 def test_info_struct_is_versioned_by_its_size():
     """PFACX_info_t / PFACX_scan_stats_t carry their size: a caller built against an older, shorter header is never written past,
     a caller that forgot to set the size is refused."""

@@ -180,3 +180,31 @@ def test_strong_scaling_mode_deals_the_slices_round_robin():
         folded[gpus] = out["config"]["folded_result"]
     assert folded[1] == folded[2]
     assert sharding.rank_slices(8, 1, 2) == [1, 3, 5, 7]
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_one_slice_each_fold_to_the_reference():
+    """The rank count the driver's scaling run ends at: `bench.py --gpus 8 --scaling strong` at toy size -- eight gloo ranks on the
+    CPU_OMP platform, one 8 MiB slice of the c3 stream each (rank r scans slice r with the head of slice r + 1:
+    PFAC/test/omp_PFAC.cpp:324,351-355).  Every slice equals its reference digest, rank 0 folds eight (count, checksum) pairs
+    into the folded digests of all eight slices and sees every rank; a world of eight under --gpus 4 is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--scaling", "strong", "--total-mib", "64", "--size-mib", "8",
+                        "--platform", "cpu_omp", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0", "--workload", "c3"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 8 and out["config"]["slices_per_rank"] == 1
+    assert out["config"]["ranks_seen"] == list(range(8))
+    assert out["config"]["bit_exact"] is True and out["config"]["folded_reference"]["equal"] is True
+    assert out["config"]["folded_result"]["match_count"] == 4579 + 4590 + 4579 + 4571 + 4454 + 4655 + 4583 + 4493   # tests/golden/full_digests.json
+    env2 = dict(env, RANK="0", WORLD_SIZE="8", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--platform", "cpu_omp", "--dist-backend", "gloo",
+                        "--size-mib", "8", "--steps", "1", "--warmup", "0"], cwd=root, env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 2 and b"refusing" in p.stderr

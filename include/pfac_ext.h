@@ -80,6 +80,10 @@ typedef struct {
     size_t deviceScratchBytes; /* device memory the handle's calls have left allocated (grow-only; PFACX_trim frees it): the two staging
                                  pieces of PFAC_matchFromHost / ...Reduce (9 bytes per position of a piece), the ordering scratch of the
                                  compacted output, the list of pattern-dense chunks */
+    int streamNearMisses;      /* what the handle's last big full-result launch said about its stream (host memory the launch's last block
+                                 writes; nothing is waited for): 1 = full of near misses of long patterns -> PFACX_WALKER_AUTO picks STAGE ... */
+    int streamDense;           /* ... 1 = most of it pattern-dense (short patterns over text, runs of a pattern byte) -> PFACX_KERNEL_AUTO
+                                 sends the next big call to the tiled kernel alone */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);

@@ -67,6 +67,7 @@ class PFACX_info(C.Structure):
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
         ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
+        ("streamNearMisses", C.c_int), ("streamDense", C.c_int),
     ]
 
 

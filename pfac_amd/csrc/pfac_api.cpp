@@ -1040,6 +1040,10 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         if (handle->hostStagePositions) scratch += 2 * (((handle->hostStagePositions + 3) & ~size_t(3)) + 2 * handle->hostStagePositions * sizeof(int));
         scratch += handle->reduceScratchBytes + handle->denseListEntries * sizeof(unsigned int);
         v.deviceScratchBytes = scratch;
+        if (handle->h_modeHint) {
+            v.streamNearMisses = (int)static_cast<volatile const unsigned int *>(handle->h_modeHint)[0];
+            v.streamDense = (int)static_cast<volatile const unsigned int *>(handle->h_modeHint)[1];
+        }
     }
     v.structSize = callerSize < sizeof(v) ? callerSize : sizeof(v);
     std::memcpy(info, &v, v.structSize);

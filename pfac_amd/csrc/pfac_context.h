@@ -44,6 +44,8 @@ constexpr int kDoneWord = 33 * 32;               /* blocks of the running filter
 constexpr int kModeHintWord = 35 * 32;           /* full-result filter kernel: 1 = most scanning waves of the last launch ended it in stage mode (near-miss stream): the next
                                                     launch on this handle starts there (scan_gfx950.hip: StageLane); kModeVotesWord counts them during a launch */
 constexpr int kModeVotesWord = 36 * 32;
+constexpr int kTiledDenseWord = 37 * 32;         /* tiled kernel scanning a whole big call: groups it walked in dense mode, groups in all, waves that are through (three words);
+                                                    the last wave out tells the host whether the stream is pattern-dense (hostHint[1]) and leaves them zero */
 constexpr int kStatsPublishedWord = 48 * 32;     /* 64-bit: the kStatsCount statistics of the last finished filter launch, then its dense chunks */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */

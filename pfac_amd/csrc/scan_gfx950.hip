@@ -160,7 +160,9 @@ struct ScanArgs {
     int numFinal;
     int initialState;
     unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
-    unsigned int *hostHint;                            /* host memory (mapped): 1 = most scanning waves of this full-result launch ended in stage mode / expecting long slots */
+    unsigned int *hostHint;                            /* host memory (mapped): [0] 1 = most scanning waves of this full-result launch found their stream full of near misses;
+                                                          [1] 1 = most of the launch's chunks (tiled kernel: groups) were pattern-dense */
+    uint32_t reportDense;                              /* tiled kernel: this launch is a whole call: report [1] */
     /* compacted output (PFAC_matchFromDeviceReduce): unordered append, sorted by position afterwards */
     int *reducePos;
     unsigned int *reduceCount;
@@ -1868,7 +1870,13 @@ void pfac_scan_filter(ScanArgs a)
             unsigned long long *published = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsPublishedWord);
             if (lane < 32) atomicExch(a.work + lane * 32, 0u);                              /* the parts' claim counters */
             if (lane < pfac::kStatsCount) published[lane] = lane == 4 ? (unsigned long long)a.n : atomicExch(acc + lane, 0ull);
-            if (lane == pfac::kStatsCount) published[lane] = REDUCE ? 0ull : (unsigned long long)atomicAdd(a.work + a.denseWord, 0u);   /* stays: the tiled kernel behind this launch reads it */
+            if (lane == pfac::kStatsCount) {
+                const unsigned int denseChunks = REDUCE ? 0u : atomicAdd(a.work + a.denseWord, 0u);   /* stays: the tiled kernel behind this launch reads it */
+                published[lane] = (unsigned long long)denseChunks;
+                /* most chunks pattern-dense: the handle's next big call goes to the tiled kernel alone (scan(): PFACX_KERNEL_AUTO), which
+                 * walks such input in place and reports in turn when the stream stops being dense */
+                if (!REDUCE && a.hostHint != nullptr) __hip_atomic_store(a.hostHint + 1, denseChunks * 2u > numChunks ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (lane == pfac::kStatsCount + 1) published[lane] = (unsigned long long)kWalkSets;
             if (lane == pfac::kStatsCount + 2) {                  /* scanning waves that ended the launch in stage mode: published, and the next launch's starting mode */
                 const unsigned int votes = !REDUCE ? atomicExch(a.work + pfac::kModeVotesWord, 0u) : 0u;
@@ -2006,11 +2014,16 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     constexpr bool kLdsResults = TILES == 1;               /* a sparse group's results are assembled in LDS and stored once, as whole lines */
     uint32_t *pairPos = reinterpret_cast<uint32_t *>(waveBase + kStage + kTiledList * 2), *pairId = pairPos + kTiledPairs;
     int *res = reinterpret_cast<int *>(waveBase + kStage + kTiledList * 2 + kTiledPairs * 8);
+    /* ScanArgs::reportDense: the block's dense groups, groups, waves that are through -- in the pair staging of the block's first wave */
+    uint32_t *blockAcc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + kStage + kTiledList * 2);
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
     {
         const u32x4 *g3 = reinterpret_cast<const u32x4 *>(a.gram3);
         u32x4 *s3 = reinterpret_cast<u32x4 *>(sGram3);
         for (int i = tid; i < words3 / 4; i += (int)blockDim.x) s3[i] = g3[i];
+#ifndef PFAC_NO_DENSE_REPORT
+        if (tid < 4) blockAcc[tid] = 0;
+#endif
         for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) sRoot[i] = a.chainSlots[a.rootRow + (uint32_t)i];
         for (uint32_t i = (uint32_t)tid; i < a.hotSlots; i += blockDim.x) sHot[i] = a.chainSlots[i];
     }
@@ -2252,10 +2265,8 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #pragma unroll
         for (int t = 0; t < TILES; t++) cnt += (uint32_t)__builtin_popcount(hits[t]);
         const uint32_t survivors = (uint32_t)__builtin_amdgcn_readlane((int)waveInclusiveScan(cnt), 63);
-#if PFAC_TILED_STATS
         tsGroups++;
         if (survivors * 2u >= hi - lo) tsDense++;
-#endif
         if (survivors * 2u >= hi - lo) {
             /* ---- DENSE group (half of its positions or more survive: short patterns over text, runs of a pattern byte):
              * compaction would cost more than idle lanes.  Position p = 256 r + 64 k + lane walks in round r, walk k: the
@@ -2406,6 +2417,31 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
         }
     }
     if (reduce) flushPairs();
+    /* a whole big call through this kernel (PFACX_KERNEL_AUTO sent it here because the handle's last launch found its stream
+     * pattern-dense): is it still?  Every wave adds its groups; the last one out tells the host and leaves the words zero */
+#ifndef PFAC_NO_DENSE_REPORT
+    if (a.reportDense != 0 && a.hostHint != nullptr) {
+        /* through LDS first (the pair staging of the block's first wave, unused in a full-result launch): 4096 waves adding to one line of
+         * device memory were 130 us of a 480 us launch; one wave per block does it for its block */
+        if (lane == 0) {
+            atomicAdd(&blockAcc[0], tsDense);
+            atomicAdd(&blockAcc[1], tsGroups);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (atomicAdd(&blockAcc[2], 1u) == waves - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                atomicAdd(a.work + pfac::kTiledDenseWord, blockAcc[0]);
+                atomicAdd(a.work + pfac::kTiledDenseWord + 1, blockAcc[1]);
+                __threadfence();
+                if (atomicAdd(a.work + pfac::kTiledDenseWord + 2, 1u) == gridDim.x - 1u) {
+                    __threadfence();
+                    const unsigned int dense = atomicExch(a.work + pfac::kTiledDenseWord, 0u), all = atomicExch(a.work + pfac::kTiledDenseWord + 1, 0u);
+                    atomicExch(a.work + pfac::kTiledDenseWord + 2, 0u);
+                    __hip_atomic_store(a.hostHint + 1, dense * 2u > all ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
+#endif
 #if PFAC_TILED_STATS
     if (lane == 0) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 26;   /* behind the PFAC_TIMING words */
@@ -2714,6 +2750,10 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE || c->kernelVariant == PFACX_KERNEL_REFTABLE) return 0;
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
         if (ownEnd - first < kSmallInput) return 0;        /* filling ~90 KiB of LDS tables per block costs more than scanning this */
+        /* the handle's last big launch found most of its stream pattern-dense (short patterns over text, runs of a pattern byte):
+         * the filter kernel would list nearly every chunk for the tiled kernel after testing it; the tiled kernel takes the call
+         * alone (snort-length set with 1-byte patterns: 133 -> 166 GB/s) and reports when the stream stops being dense */
+        if (c->h_modeHint != nullptr && static_cast<volatile const unsigned int *>(c->h_modeHint)[1] != 0) return 0;
     }
     const size_t margin = (size_t)c->fa.maxPatternLen + 64 + kWalkHalo;   /* a window load reads up to 35 bytes beyond a walk's deepest byte; the prefetch of a chunk reads the 64 (full-result kernel: kWalkHalo) bytes behind it */
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
@@ -2819,6 +2859,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             rest.owned = ownEnd - first + back;
             rest.n = input_size - first + back;
             headDone = true;
+            rest.reportDense = (c->kernelVariant == PFACX_KERNEL_AUTO && vectorOk && ownEnd - first >= kSmallInput) ? 1u : 0u;   /* a big call sent here for its density: say if it still is */
             e = launchSimple(c, hashed, tex, rest);
         }
     }

@@ -199,13 +199,17 @@ def test_snort_length_distribution_with_1_and_2_byte_patterns(workdir, capsys):
                 h.destroy()
     with capsys.disabled():
         print("\n[snort-length set, 64 MiB, 1-byte patterns present] input GB/s:", rates)
-    # the floor under pattern-dense text, in every table mode (round 3: 60-118 GB/s through the reference-shaped kernel): the
-    # tiled kernel is bound by instruction issue here (profiles/r04_hostile_pmc.txt: 1.9e8 VALU instructions per launch = 85 %
-    # of its time), measured 160-174; through the filter kernel every chunk of this text goes on the dense list (fifteen 1-byte patterns
-    # saturate the 3-gram bitmap: 98 % of the positions pass it) and comes back to the tiled kernel: 127-137.  The floors leave 20-25 % for a slow box
+    # Pattern-dense text in every table mode.  The tiled kernel is bound by instruction issue here (profiles/r04_hostile_pmc.txt: 1.9e8 VALU
+    # instructions per launch = 85 % of its time): 160-174 GB/s; through the filter kernel every chunk of this text goes on the dense list
+    # (fifteen 1-byte patterns saturate the 3-gram bitmap: 98 % of the positions pass it) and comes back to the tiled kernel: 127-138.  The
+    # default variant (AUTO) learns it from the first launch -- most chunks dense: the last block out says so in host memory -- and sends the
+    # handle's next calls to the tiled kernel alone: what is asserted on every box is that AUTO is never much slower than the better
+    # of the two; absolute floors (a slow box, a shared box: not for a correctness run) only with PFAC_PERF_FLOORS=1
     for mode_name in ("dense-global", "dense-buffer", "hash-global", "hash-buffer"):
-        assert rates[f"{mode_name}/naive"] >= 125.0, rates
-        assert rates[f"{mode_name}/auto"] >= 95.0 and rates[f"{mode_name}/filter"] >= 95.0, rates
+        best = max(rates[f"{mode_name}/naive"], rates[f"{mode_name}/filter"])
+        assert rates[f"{mode_name}/auto"] >= 0.85 * best, rates
+        if os.environ.get("PFAC_PERF_FLOORS"):
+            assert rates[f"{mode_name}/naive"] >= 150.0 and rates[f"{mode_name}/auto"] >= 150.0 and rates[f"{mode_name}/filter"] >= 115.0, rates
 
 
 @pytest.mark.parametrize("perf,tex,mode_name", MODES)
@@ -281,12 +285,14 @@ def test_every_position_matches_256_mib(workdir, capsys):
         h.destroy()
     with capsys.disabled():
         print("\n[every position matches, 256 MiB] input GB/s:", rates)
-    # no cliff: the filter variant (every chunk goes on the dense list) within a fifth of the tiled kernel alone, and a floor
-    # under both in either perf mode: eight dependent one-byte transitions per position (every state on the way is final, so
-    # no chain folds them) are 4.2e8 VALU instructions per 64 MiB, which is all of the launch's time
-    # (profiles/r04_hostile_pmc.txt); measured 84-94 GB/s
+    # no cliff: the filter variant (every chunk goes on the dense list) within a fifth of the tiled kernel alone, AUTO (which sends the calls
+    # behind the first one to the tiled kernel alone) never much slower than the better of the two.  Eight dependent one-byte transitions per
+    # position (every state on the way is final, so no chain folds them) are 4.2e8 VALU instructions per 64 MiB, which is all of the launch's
+    # time (profiles/r04_hostile_pmc.txt): 84-94 GB/s; the absolute floor only with PFAC_PERF_FLOORS=1
     assert rates["hash-buffer/filter"] >= 0.8 * rates["hash-buffer/naive"] and rates["dense-buffer/filter"] >= 0.8 * rates["dense-buffer/naive"], rates
-    assert min(rates["hash-buffer/naive"], rates["dense-buffer/naive"], rates["auto"]) >= 65.0, rates
+    assert rates["auto"] >= 0.85 * max(rates["hash-buffer/naive"], rates["hash-buffer/filter"]), rates
+    if os.environ.get("PFAC_PERF_FLOORS"):
+        assert min(rates["hash-buffer/naive"], rates["dense-buffer/naive"], rates["auto"]) >= 75.0, rates
 
 
 # ------------------------------------------------------------------------------------- pattern ingest

@@ -250,3 +250,35 @@ def test_match_from_host_reduce_pieces_equal_oracle(workdir):
     finally:
         h.destroy()
         o.close()
+
+
+def test_auto_kernel_follows_the_density_of_the_stream(workdir):
+    """PFACX_KERNEL_AUTO: a big call whose filter launch finds most chunks pattern-dense (1-byte patterns over text) makes the
+    handle's next big call go to the tiled kernel alone -- which walks dense input in place, reports whether the stream is still
+    dense, and hands back to the filter kernel when it is not.  Results are the oracle's on both streams, whoever scans."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 /.-_=&%:", dtype=np.uint8)
+    pats = sorted({b"aaa", b"aaaa", b"aaaaaaa"} | {alpha[rng.integers(0, alpha.size, int(rng.integers(4, 30)))].tobytes() for _ in range(800)})
+    pf = wl.write_pattern_file(os.path.join(workdir, "density.pat"), pats)
+    n = 48 << 20
+    sparse = alpha[rng.integers(1, alpha.size, n)].copy()           # text without an 'a'
+    dense = np.full(n, ord("a"), dtype=np.uint8)                    # every position matches: every chunk is pattern-dense
+    dense[rng.integers(0, n, n >> 12)] = ord("b")
+    dense[:1 << 20] = sparse[:1 << 20]
+    want_dense, want_sparse = _oracle(pf, dense, omp=True), _oracle(pf, sparse, omp=True)
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    try:
+        assert_same(device_match(h, sparse), want_sparse, "sparse, first call")
+        filter_launches = [h.scanStats()["level1Hits"]]
+        assert h.info().streamDense == 0
+        assert_same(device_match(h, dense), want_dense, "dense through the filter kernel")
+        assert h.info().streamDense == 1 and h.scanStats()["denseChunks"] > (n >> 11) // 2
+        mark = h.scanStats()["level1Hits"]
+        assert_same(device_match(h, dense), want_dense, "dense through the tiled kernel alone")
+        assert h.scanStats()["level1Hits"] == mark and h.info().streamDense == 1      # no new filter launch; still dense
+        assert_same(device_match(h, sparse), want_sparse, "sparse through the tiled kernel alone")
+        assert h.info().streamDense == 0                                               # ... which says so
+        assert_same(device_match(h, sparse), want_sparse, "sparse, back in the filter kernel")
+        assert h.scanStats()["level1Hits"] != mark and h.scanStats()["denseChunks"] == 0
+    finally:
+        h.destroy()

@@ -557,7 +557,7 @@ class SliceSet:
 def kernel_name(args, run):
     """The kernel a launch of this run goes to (the library default takes the filter kernel from 32 MiB up)."""
     if args.variant == "reftable":
-        return "pfac_scan_naive"
+        return "pfac_scan_tiled<REF>"          # the tiled frame over the reference-layout table (scan_gfx950.hip: launchTiledRef)
     if args.variant == "naive" or (args.variant == "auto" and run.n_read < (32 << 20)):
         return "pfac_scan_tiled"
     return "pfac_scan_filter"
@@ -566,7 +566,7 @@ def kernel_name(args, run):
 def walker_table(args, run):
     """What the kernel walks: the filter kernel and the tiled kernel walk the device-only chained table in BOTH perf modes;
     only the reference-shaped kernel (--variant reftable) walks the reference-layout table that `table` names."""
-    return "chained (device-only, both perf modes)" if kernel_name(args, run) != "pfac_scan_naive" else ("hashed" if run.perf_mode else "dense")
+    return "chained (device-only, both perf modes)" if args.variant != "reftable" else ("hashed rowPtr/valPtr (reference layout)" if run.perf_mode else "dense int[S][256] (reference layout)")
 
 
 _BUILD = None
@@ -611,7 +611,11 @@ def other_configs(args, device, buffers):
             ("c5_dense", "c5", api.PFAC_TIME_DRIVEN, "auto", None), ("c5_hashed", "c5", api.PFAC_SPACE_DRIVEN, "auto", None),
             # BASELINE config 2 names the dense 2-D table: the filter kernel walks the chained table in both perf modes, so this is the
             # entry in which a kernel really walks int[S][256] -- the reference-shaped one (PFACX_KERNEL_REFTABLE), and the tiled kernel alone
-            ("c2_dense_table_reference_shaped_kernel", "c2", api.PFAC_TIME_DRIVEN, "on", "reftable"), ("c2_tiled_kernel", "c2", None, "auto", "naive")]
+            ("c2_dense_table_reference_shaped_kernel", "c2", api.PFAC_TIME_DRIVEN, "on", "reftable"),
+            ("c2_dense_table_reference_shaped_kernel_texture_off", "c2", api.PFAC_TIME_DRIVEN, "off", "reftable"),
+            # ... and BASELINE config 3's hashed rowPtr / valPtr pair, walked with two dependent loads per byte (PFAC_kernel_spaceDriven.cu:76-124)
+            ("c3_hashed_table_reference_shaped_kernel", "c3", api.PFAC_SPACE_DRIVEN, "on", "reftable"),
+            ("c2_tiled_kernel", "c2", None, "auto", "naive")]
     for key, name, perf, tex, variant in todo:
         t0 = time.perf_counter()
         if variant is not None:

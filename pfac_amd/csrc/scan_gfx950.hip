@@ -1989,9 +1989,16 @@ constexpr uint32_t kTiledFar = 0x40000000u;            /* "the input ends nowher
 constexpr uint32_t kTiledPairs = 32;                   /* compacted output: (position, id) pairs a wave stages in LDS before it appends them with one atomic */
 constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + kTiledPairs * 8 + (tiles == 1 ? kTiledTile * 4 : 0); }
 
-template <bool TEX, int WALKS, int TILES, bool HOTALL>
+/* REF >= 0 (a TableMode): the same frame -- 16-byte loads, group + halo and the initial state's row in LDS, 3-gram early-out, whole
+ * zero lines, compacted survivors, __ballot loop exit -- over the REFERENCE-layout table of the perf mode instead of the chained
+ * one: a walk takes one byte per step through Lookup<REF> (dense: one gathered word, PFAC_kernel.cu:291; hashed: two dependent
+ * loads, PFAC_kernel_spaceDriven.cu:76-124).  This is what PFACX_KERNEL_REFTABLE launches: the byte-compared tables of the
+ * reference walked the way its kernels walk them (PFAC_kernel.cu:377-458), the independent implementation every parity test runs
+ * beside the product kernels. */
+template <bool TEX, int WALKS, int TILES, bool HOTALL, int REF = -1>
 __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 {
+    constexpr bool kRef = REF >= 0;
     constexpr uint32_t kGroup = (uint32_t)TILES * kTiledTile, kStage = kGroup + kTiledHalo;
     static_assert(kGroup <= 4096, "a position's code is 12 bits of offset in 16");
     static_assert(kTiledList >= 64u * (uint32_t)TILES, "dense mode parks the lanes' hit masks in the list's place");
@@ -2024,10 +2031,16 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #ifndef PFAC_NO_DENSE_REPORT
         if (tid < 4) blockAcc[tid] = 0;
 #endif
-        for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) sRoot[i] = a.chainSlots[a.rootRow + (uint32_t)i];
-        for (uint32_t i = (uint32_t)tid; i < a.hotSlots; i += blockDim.x) sHot[i] = a.chainSlots[i];
+        if constexpr (kRef) {
+            for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) reinterpret_cast<int *>(sRoot)[i] = a.initialRow[i];   /* ref: the initial state's row in shared memory, PFAC_kernel.cu:396-403 */
+        } else {
+            for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) sRoot[i] = a.chainSlots[a.rootRow + (uint32_t)i];
+            for (uint32_t i = (uint32_t)tid; i < a.hotSlots; i += blockDim.x) sHot[i] = a.chainSlots[i];
+        }
     }
     __syncthreads();
+    const int *sInit = reinterpret_cast<const int *>(sRoot);
+    (void)sInit;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000);
     const uint32_t shift3 = 35u - (uint32_t)a.log2Bits;
@@ -2151,7 +2164,49 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
         };
 
         /* WALKS walks per lane from the group offsets o[] (alive[]: the lane has one), to the end: match[] = result */
-        auto runWalks = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
+        /* REF: one byte per step through the reference-layout table (byte q of the group from the stage, or -- beyond the halo -- from
+         * global memory; a byte at or behind `limit` does not exist).  The lookups of all WALKS walks are issued before the first is used. */
+        auto byteAt = [&](uint32_t q) -> uint32_t {
+            uint32_t w;
+            if (q < kStage) w = stage[q >> 2];
+            else w = (q & ~3u) < span32 ? *reinterpret_cast<const uint32_t *>(g16 + (q & ~3u)) : 0u;
+            return (w >> (8u * (q & 3u))) & 0xFFu;
+        };
+        auto runWalksRef = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
+            if constexpr (kRef) {
+                const Lookup<kRef ? REF : 0> lookup(a);
+                uint32_t q[WALKS];
+                int state[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    q[k] = o[k]; match[k] = 0; state[k] = kTrap;
+                    if (alive[k]) state[k] = sInit[byteAt(q[k])];
+                    alive[k] = alive[k] & (state[k] != kTrap);
+                    match[k] = (alive[k] && state[k] <= a.numFinal) ? state[k] : 0;
+                    q[k]++;
+                }
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++) { alive[k] = alive[k] & (q[k] < limit); any |= alive[k]; }
+                    if (__ballot(any) == 0) break;             /* every walk of the wave is in the trap state (ref: per thread, PFAC_kernel.cu:299) */
+                    int next[WALKS];
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++) {
+                        next[k] = kTrap;
+                        if (alive[k]) next[k] = lookup(state[k], (int)byteAt(q[k]));
+                    }
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++) {
+                        alive[k] = alive[k] & (next[k] != kTrap);
+                        match[k] = (alive[k] && next[k] <= a.numFinal) ? next[k] : match[k];
+                        state[k] = next[k];
+                        q[k]++;
+                    }
+                }
+            }
+        };
+        auto runWalksChained = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
             uint32_t q[WALKS], row[WALKS], ks[WALKS];
             /* one transition through slot s on the edge byte at q, w0:w1 = bytes q .. q+7 (ChainLane::advance, with the
              * end of the input checked: edge byte and chain must lie in front of `limit`) */
@@ -2237,6 +2292,10 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                 for (int k = 0; k < WALKS; k++)
                     if (__ballot(alive[k]) != 0) step(k, s[k], w0[k], w1[k]);
             }
+        };
+        auto runWalks = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
+            if constexpr (kRef) runWalksRef(o, alive, match);
+            else runWalksChained(o, alive, match);
         };
         /* compacted output: the matches of a walk set join the wave's staged pairs */
         auto appendPairs = [&](const uint32_t (&o)[WALKS], const int (&match)[WALKS]) {
@@ -2643,6 +2702,45 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
     return hipGetLastError();
 }
 
+/* PFACX_KERNEL_REFTABLE: the tiled frame over the reference-layout table of the perf mode (pfac_scan_tiled<..., REF = MODE>) */
+template <int MODE>
+hipError_t launchTiledRef(const PFAC_context *c, ScanArgs a)
+{
+    auto kernelBig = pfac_scan_tiled<false, kTiledWalks, kTiledTilesBig, false, MODE>;
+    auto kernelSmall = pfac_scan_tiled<false, PFAC_TILED_WALKS_SMALL, 1, false, MODE>;
+    static ShapeCache cache;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidValue;
+    {
+        std::lock_guard<std::mutex> g(cache.lock);
+        if (cache.perCU[dev] == 0) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernelBig), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernelSmall), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+            if (e != hipSuccess) return e;
+            cache.perCU[dev] = 1;
+        }
+    }
+    const size_t head = reinterpret_cast<uintptr_t>(a.in) & 15u;
+    const bool big = a.owned >= kTiledBigBytes;
+    const size_t group = (big ? (size_t)kTiledTilesBig : 1) * kTiledTile;
+    const size_t groups = a.owned ? (head + a.owned + group - 1) / group : 0;
+    const unsigned threads = big ? 1024u : 256u;
+    const size_t waves = threads / 64;
+    const size_t cus = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256);
+    const size_t lds = (size_t(1) << c->filter.log2Bits) / 8 + (size_t)pfac::kCharSet * sizeof(pfac::ChainSlot) + waves * tiledWaveLds(big ? kTiledTilesBig : 1);
+    if (lds > kLdsPerCu) return hipErrorInvalidValue;
+    a.hotSlots = 0;
+    a.denseList = nullptr;
+    size_t blocks = (groups + waves - 1) / waves;
+    if (blocks > (big ? cus : cus * 16)) blocks = big ? cus : cus * 16;
+    if (blocks < 1) blocks = 1;
+    if (big) hipLaunchKernelGGL(kernelBig, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+    else hipLaunchKernelGGL(kernelSmall, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
+    return hipGetLastError();
+}
+
 template <int MODE>
 hipError_t launchNaive(const PFAC_context *c, const ScanArgs &a)
 {
@@ -2775,8 +2873,13 @@ size_t headPositions(const unsigned char *in, size_t input_size)
 
 hipError_t launchNaiveFor(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part)
 {
+#ifdef PFAC_REFTABLE_PER_BYTE          /* measurement builds: round 4's one-thread-per-byte kernel behind PFACX_KERNEL_REFTABLE */
     if (hashed) return tex ? launchNaive<HASH_BUFFER>(c, part) : launchNaive<HASH_GLOBAL>(c, part);
     return tex ? launchNaive<DENSE_BUFFER>(c, part) : launchNaive<DENSE_GLOBAL>(c, part);
+#else
+    if (hashed) return tex ? launchTiledRef<HASH_BUFFER>(c, part) : launchTiledRef<HASH_GLOBAL>(c, part);
+    return tex ? launchTiledRef<DENSE_BUFFER>(c, part) : launchTiledRef<DENSE_GLOBAL>(c, part);
+#endif
 }
 
 /* what is not the filter kernel's: the tiled kernel (chained table, both perf modes), or -- PFACX_KERNEL_REFTABLE -- the

@@ -10,7 +10,10 @@
  * (scan_gfx950.hip).
  */
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 
 #if defined(__SSE2__)
@@ -553,6 +556,47 @@ static PFAC_status_t matchHostFullVector(PFAC_context *c, char *h_inputString, s
  * and the pairs are scattered on top at the end.  A piece in which more than one position in eight matches takes the
  * full-vector route above instead (after the zero fill, so the two never write the same words at the same time).
  */
+/* The NUMA node a host page lives on (-1: unknown, not faulted in yet, or no such system call): move_pages with no target only reports. */
+static int numaNodeOf(const void *p)
+{
+#if defined(__linux__) && defined(SYS_move_pages)
+    void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
+    int status = -1;
+    if (syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0) == 0 && status >= 0) return status;
+#else
+    (void)p;
+#endif
+    return -1;
+}
+/* the CPUs of a NUMA node that this thread may run on (empty: unknown) */
+static bool cpusOfNumaNode(int node, cpu_set_t &out)
+{
+    CPU_ZERO(&out);
+    char path[96];
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t got = std::fread(buf, 1, sizeof(buf) - 1, f);
+    std::fclose(f);
+    buf[got] = 0;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    int any = 0;
+    for (char *q = buf; *q;) {
+        char *end = nullptr;
+        const long a = std::strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') { q = end + 1; b = std::strtol(q, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &out); any++; }
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    return any > 0;
+}
+
 /* zeros without reading the lines first: streaming stores, 64 bytes per trip (the result vector of a 1 GiB call is 4 GiB
  * that nothing reads before the caller does) */
 static void fillZeroStreaming(int *p, size_t n)
@@ -652,8 +696,19 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
         filled.reset(new std::atomic<unsigned>[numPieces]);
         for (size_t k = 0; k < numPieces; k++) filled[k].store(0, std::memory_order_relaxed);
         fillers.reserve(helpers);
+        /* The fill threads run on the NUMA node the caller's result vector lives on: 4 bytes per position of streaming stores that
+         * cross the sockets' link meet the link's own reads of the input there (2 x EPYC 9575F, GPU on node 0, pinned buffers
+         * first-touched on node 1: p50 7.4 ms, p90 11.4 ms per 256 MiB call against 5.5 / 6.2 ms with the buffers on node 0 --
+         * the driver's round-4 line: 29 GB/s median; tools/host_numa_probe.py).  PFAC_HOST_FILL_ANYWHERE=1 leaves them to the OS. */
+        cpu_set_t fillCpus;
+        bool bindFill = false;
+        if (helpers && std::getenv("PFAC_HOST_FILL_ANYWHERE") == nullptr) {
+            const int node = numaNodeOf(h_matched_result + owned / 2);
+            bindFill = node >= 0 && cpusOfNumaNode(node, fillCpus);
+        }
         for (unsigned t = 0; t < helpers; t++)
             fillers.emplace_back([&, t]() {
+                if (bindFill) (void)pthread_setaffinity_np(pthread_self(), sizeof(fillCpus), &fillCpus);
                 for (size_t k = 0; k < numPieces; k++) {
                     size_t lo, hi;
                     share(k, t, helpers, lo, hi);

@@ -557,7 +557,7 @@ class SliceSet:
 def kernel_name(args, run):
     """The kernel a launch of this run goes to (the library default takes the filter kernel from 32 MiB up)."""
     if args.variant == "reftable":
-        return "pfac_scan_tiled<REF>"          # the tiled frame over the reference-layout table (scan_gfx950.hip: launchTiledRef)
+        return "pfac_scan_tiled<REF>"          # the tiled frame over the reference-layout table (scan_tiled.hip: launchTiledRef)
     if args.variant == "naive" or (args.variant == "auto" and run.n_read < (32 << 20)):
         return "pfac_scan_tiled"
     return "pfac_scan_filter"

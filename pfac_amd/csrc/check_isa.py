@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""check_isa.py <device ISA of scan_gfx950.hip>  -- the register contract of the filter kernel, checked on what the compiler made.
+"""check_isa.py <device ISA of scan_*.hip>  -- the register contract of the filter kernel, checked on what the compiler made.
 
 The filter kernel keeps the chunk in flight in nine vector registers that the compiler is told not to use
-(scan_gfx950.hip: prefetchChunk / kCompilerVgprs: v119..v127, inline assembly).  That contract is between the source and
+(scan_*.hip: prefetchChunk / kCompilerVgprs: v119..v127, inline assembly).  That contract is between the source and
 ONE compiler version, so the build checks it on the generated ISA and fails if it does not hold (pfac_amd/csrc/Makefile;
 tests/test_kernel_isa.py runs the same functions):
   * every pfac_scan_filter instance owns 128 vector registers and has no scratch (a scratch reload is a vector-memory

@@ -1,0 +1,118 @@
+/*
+ * multi_gpu.cpp -- PFACX_matchFromHostMultiGPU (include/pfac_ext.h): one call shards a host stream over several GPUs of the node.
+ */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <hip/hip_runtime_api.h>
+
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <system_error>
+#include <thread>
+#include <vector>
+
+#include "pfac_host.h"
+
+using namespace pfac_internal;
+
+extern "C" {
+
+/*
+ * pfac_ext.h: one call shards a host stream over several GPUs (what every user of the
+ * reference re-writes from PFAC/test/omp_PFAC.cpp:257-394 or SimpleMultiGPU_pthread.cpp:50-174).  One worker
+ * thread per listed device: hipSetDevice, a per-device handle with this handle's pattern set and modes (kept in
+ * the handle for the next call), a contiguous slice of the stream scanned together with the maxPatternLen bytes
+ * behind it, only the slice's own results written (omp_PFAC.cpp:324,377).  No exchange between devices.
+ */
+PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result,
+                                          int numDevices, const int *devices)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!h_inputString || !h_matched_result || numDevices < 0) return PFAC_STATUS_INVALID_PARAMETER;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
+    std::vector<int> devs;
+    if (numDevices == 0) {
+        for (int d = 0; d < visible; d++) devs.push_back(d);
+    } else {
+        for (int i = 0; i < numDevices; i++) {
+            const int d = devices ? devices[i] : i;
+            if (d < 0 || d >= visible) return PFAC_STATUS_INVALID_PARAMETER;
+            devs.push_back(d);
+        }
+    }
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    const size_t workers = devs.size();
+    /* the i-th worker's handle: bound to devs[i]; a device listed twice gets two handles (two streams of work) */
+    while (c->children.size() < workers) c->children.emplace_back(-1, nullptr);
+    std::vector<PFAC_status_t> status(workers, PFAC_STATUS_SUCCESS);
+    /* slice boundaries: contiguous, rounded to the 1 KiB tile (pfac_amd/sharding.py plan_slices is the Python mirror) */
+    std::vector<size_t> bound(workers + 1, 0);
+    for (size_t i = 1; i < workers; i++) {
+        size_t b = (size * i / workers) / 1024 * 1024;
+        bound[i] = b > bound[i - 1] ? b : bound[i - 1];
+    }
+    bound[workers] = size;
+    auto work = [&](size_t i) {
+        if (bound[i + 1] == bound[i]) return;
+        if (hipSetDevice(devs[i]) != hipSuccess) { status[i] = PFAC_STATUS_INTERNAL_ERROR; return; }
+        auto &child = c->children[i];
+        if (child.second && child.first != devs[i]) { (void)PFAC_destroy(child.second); child.second = nullptr; }
+        if (!child.second) {
+            PFAC_handle_t h = nullptr;
+            PFAC_status_t st = PFAC_create(&h);                    /* binds the current device */
+            if (st == PFAC_STATUS_SUCCESS) st = PFAC_setPerfMode(h, (PFAC_perfMode_t)c->perfMode);
+            if (st == PFAC_STATUS_SUCCESS) st = PFAC_setTextureMode(h, (PFAC_textureMode_t)c->textureMode);
+            if (st == PFAC_STATUS_SUCCESS) st = PFACX_setKernelVariant(h, c->kernelVariant);
+            if (st == PFAC_STATUS_SUCCESS)
+                st = PFACX_readPatternFromMemory(h, reinterpret_cast<const char *>(c->fa.file.data()), c->fa.file.size());
+            if (st != PFAC_STATUS_SUCCESS) { if (h) (void)PFAC_destroy(h); status[i] = st; return; }
+            child = {devs[i], h};
+        }
+        PFAC_context *w = child.second;
+        /* a child created by an earlier call: the parent's modes may have changed since */
+        if (w->perfMode != c->perfMode) {
+            const PFAC_status_t st = PFAC_setPerfMode(w, (PFAC_perfMode_t)c->perfMode);
+            if (st != PFAC_STATUS_SUCCESS) { status[i] = st; return; }
+        }
+        if (w->kernelVariant != c->kernelVariant) {
+            const PFAC_status_t st = PFACX_setKernelVariant(w, c->kernelVariant);
+            if (st != PFAC_STATUS_SUCCESS) { status[i] = st; return; }
+        }
+        std::lock_guard<std::mutex> g(w->lock);
+        w->textureMode = c->textureMode;
+        status[i] = matchHostOnGpu(w, h_inputString + bound[i], bound[i + 1] - bound[i], size - bound[i], h_matched_result + bound[i]);
+    };
+    int callerDevice = 0;
+    (void)hipGetDevice(&callerDevice);
+    std::vector<std::thread> threads;
+    try {
+        for (size_t i = 1; i < workers; i++) threads.emplace_back(work, i);
+    } catch (...) {
+        for (auto &t : threads) t.join();
+        return PFAC_STATUS_ALLOC_FAILED;
+    }
+    work(0);
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(callerDevice);
+    for (PFAC_status_t st : status)
+        if (st != PFAC_STATUS_SUCCESS) return st;
+    return PFAC_STATUS_SUCCESS;
+}
+
+} /* extern "C" */

@@ -327,7 +327,7 @@ void buildFilter(const Automaton &fa, Filter &f)
 
     /* Level 1 is tested for every position and each false positive costs list and ladder work: up to 32 KiB, two bits
      * per 3-gram.  The ladder gets up to 64 KiB.  Everything lives in LDS next to the scanning waves' queues and
-     * stages (scan_gfx950.hip: filterLdsBytes), so the bitmaps share kFilterLdsBudget. */
+     * stages (scan_filter.hip: filterLdsBytes), so the bitmaps share kFilterLdsBudget. */
     f.log2Bits = sizeLog2(depth3, 13, 18);
     f.log2BitsF3 = sizeLog2(len3, 10, 13);
     f.log2BitsLad = 19;

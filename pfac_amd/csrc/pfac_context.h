@@ -42,14 +42,14 @@ constexpr int kDenseCountWordB = 34 * 32;
 constexpr int kDoneWord = 33 * 32;               /* blocks of the running filter launch that have finished: the last one publishes the statistics and leaves
                                                     every counter zero for the next launch (no memset in front of a launch) */
 constexpr int kModeHintWord = 35 * 32;           /* full-result filter kernel: 1 = most scanning waves of the last launch ended it in stage mode (near-miss stream): the next
-                                                    launch on this handle starts there (scan_gfx950.hip: StageLane); kModeVotesWord counts them during a launch */
+                                                    launch on this handle starts there (scan_common.h: StageLane); kModeVotesWord counts them during a launch */
 constexpr int kModeVotesWord = 36 * 32;
 constexpr int kTiledDenseWord = 37 * 32;         /* tiled kernel scanning a whole big call: groups it walked in dense mode, groups in all, waves that are through (three words);
                                                     the last wave out tells the host whether the stream is pattern-dense (hostHint[1]) and leaves them zero */
 constexpr int kStatsPublishedWord = 48 * 32;     /* 64-bit: the kStatsCount statistics of the last finished filter launch, then its dense chunks */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
-/* shape of the scan kernel (scan_gfx950.hip), reported by PFACX_getScanStats */
+/* shape of the scan kernel (scan_*.hip), reported by PFACX_getScanStats */
 #ifndef PFAC_WALK_SETS
 #define PFAC_WALK_SETS 2                       /* independent walks per lane, compacted-output kernel (every candidate behind the level-4 test walks there) */
 #endif
@@ -81,7 +81,7 @@ struct ChainSlot {
 };
 constexpr size_t kGram3LdsBytes = 32 * 1024;     /* LDS set aside for the level-1 bitmap (2^18 bits at most): the ladder behind it sits at a compile-time address */
 constexpr size_t kFilterLdsBudget = 97 * 1024;   /* LDS bytes the prefilter bitmaps may take together (pattern_compiler.cpp); the rest of the
-                                                    CU's 160 KiB is the scanning waves' queues and stages (scan_gfx950.hip checks the sum) */
+                                                    CU's 160 KiB is the scanning waves' queues and stages (scan_*.hip checks the sum) */
 constexpr uint32_t kSlotLenShift = 8, kSlotLenMask = 0x1Fu;   /* chain length: bits 8..12 */
 constexpr uint32_t kSlotFinal = 1u << 13;     /* the end state is a final state                         */
 constexpr uint32_t kSlotEmpty = 1u << 14;     /* no transition in this slot                             */
@@ -149,7 +149,7 @@ constexpr int kGram1Log2 = 19, kPrefix4Log2 = 17;
 
 /* the ladder's hash: h(4) = (first four bytes, little endian) * kLadMul0; h(d) = (h(d-2) ^ (bytes d-2, d-1 as a 16-bit
  * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
- * bit), of h * kLadMulG (G) and, at depth 4 only, of h * kLadMulG2 (G, second bit).  scan_gfx950.hip evaluates exactly this. */
+ * bit), of h * kLadMulG (G) and, at depth 4 only, of h * kLadMulG2 (G, second bit).  scan_*.hip evaluates exactly this. */
 constexpr int kLadderFirst = 4, kLadderStep = 2, kLadderLast = 20;
 constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
 constexpr uint32_t kLadMul0 = 0x9E3779B1u, kLadMul = 0x85EBCA77u, kLadMulS = 0xC2B2AE3Du, kLadMulG = 0x27D4EB2Fu, kLadMulG2 = 0x165667B1u;
@@ -168,7 +168,7 @@ constexpr uint32_t kGram3Mul = 0x8B92C5u;     /* 24-bit odd multiplier of the 3-
  * Snort-style stream, and leaves the prefix ladder half the LDS).  The dword comes from the top bits of the 24 x 24 ->
  * 32 bit product, the first bit from the low five bits of the first byte, the second from those of the second byte --
  * the kernel gets the dword address with a shift and an AND and the bits with the implicit mod-32 of a shift by the
- * gram itself and by the gram >> 8 (scan_gfx950.hip). */
+ * gram itself and by the gram >> 8 (scan_*.hip). */
 inline uint32_t gram3Word(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits); }
 inline uint32_t gram3Bit1(uint32_t key24) { return key24 & 31u; }
 inline uint32_t gram3Bit2(uint32_t key24) { return (key24 >> 8) & 31u; }
@@ -239,7 +239,7 @@ struct PFAC_context {
     void *evUp[2] = {nullptr, nullptr}, *evScan[2] = {nullptr, nullptr}, *evDown[2] = {nullptr, nullptr};   /* hipEvent_t */
     unsigned int *d_workCounters = nullptr;   /* kWorkCounterWords: next-chunk counters of the scan kernel (one per 128 B) */
     /* one word of mapped host memory the last block of a full-result filter launch writes: 1 = the stream was full of near misses
-     * (scan_gfx950.hip: launchChained picks the next launch's walker from it); h_: the host's pointer, d_: the device's */
+     * (scan_filter.hip: launchChained picks the next launch's walker from it); h_: the host's pointer, d_: the device's */
     unsigned int *h_modeHint = nullptr, *d_modeHint = nullptr;
     int walker = PFACX_WALKER_AUTO;
     uint32_t *d_final3 = nullptr;
@@ -271,7 +271,7 @@ struct PFAC_context {
     std::shared_mutex tablesInUse;
     /* per-device handles of PFACX_matchFromHostMultiGPU, created on first use: (device, handle) */
     std::vector<std::pair<int, PFAC_context *>> children;
-    /* chunks the filter kernel found pattern-dense and left to the simple kernel (scan_gfx950.hip): grow-only, one entry per chunk of a launch */
+    /* chunks the filter kernel found pattern-dense and left to the simple kernel (scan_*.hip): grow-only, one entry per chunk of a launch */
     unsigned int *d_denseList = nullptr;
     size_t denseListEntries = 0;
 

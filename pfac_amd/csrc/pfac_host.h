@@ -28,4 +28,48 @@ PFAC_status_t matchOnCpu(const PFAC_context *ctx, const unsigned char *in, size_
 
 } // namespace pfac
 
+/* ---- internals of libpfac.so shared by pfac_api.cpp, host_pipeline.cpp, multi_gpu.cpp, compiled_set.cpp ---- */
+#include <hip/hip_runtime_api.h>
+namespace pfac_internal {
+
+template <class T>
+void devFree(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+template <class T>
+PFAC_status_t upload(T *&dst, const T *src, size_t count)
+{
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (hipMalloc(reinterpret_cast<void **>(&dst), bytes) != hipSuccess) {
+        dst = nullptr;
+        (void)hipGetLastError();
+        return PFAC_STATUS_CUDA_ALLOC_FAILED;
+    }
+    if (count && hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        devFree(dst);
+        return PFAC_STATUS_INTERNAL_ERROR;
+    }
+    return PFAC_STATUS_SUCCESS;
+}
+
+/* positions per piece of the pipelined PFAC_matchFromHost: 32 Mi positions = 32 MiB up, 128 MiB down */
+constexpr size_t kHostPiece = size_t(32) << 20;
+
+/* pfac_api.cpp */
+void freeTables(PFAC_context *c);
+void freeHostStage(PFAC_context *c);
+void freeResources(PFAC_context *c);
+PFAC_status_t bindTable(PFAC_context *c);
+PFAC_status_t bindCommon(PFAC_context *c, bool build = true);
+void correctTextureMode(PFAC_context *c);
+PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, int *out);
+/* host_pipeline.cpp: the caller holds c->lock */
+PFAC_status_t matchDeviceLocked(PFAC_context *c, char *d_inputString, size_t size, int *d_matched_result);
+PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result);
+PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, int *h_matched_result, int *h_pos, int *h_num_matched);
+
+} // namespace pfac_internal
+
 #endif

@@ -106,7 +106,7 @@ PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
 }
 
 /*
- * Device-only "chained" transition table for the gfx950 walker (scan_gfx950.hip), used in BOTH perf modes.
+ * Device-only "chained" transition table for the gfx950 walker (scan_*.hip), used in BOTH perf modes.
  *
  * The reference's hashed layout (above) answers one transition with two dependent loads (rowPtr[state], then
  * valPtr[...], PFAC_kernel_spaceDriven.cu:76-124) and gives every state a bucket.  The walker's table is hashed per state
@@ -334,7 +334,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         ChainBuilder b(fa, slots);
         std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
         /* the LONG jump table: the same prefixes in the same places, but a slot folds up to kChainMaxWide bytes (chain bytes 8.. in
-         * its extension unit): the start of a walker that expects long single-successor runs (scan_gfx950.hip: StageLane) */
+         * its extension unit): the start of a walker that expects long single-successor runs (scan_common.h: StageLane) */
         std::vector<ChainSlot> jumpLong(jump.size(), ChainBuilder::emptySlot()), jumpLongUnits(jump.size(), ChainBuilder::zeroUnit());
         /* the top of the trie first: what the initial state's transitions land in, then what the jump slots land in,
          * then everything below, level by level */

@@ -1,5 +1,5 @@
 """The prefilter of the scan kernel as a numpy model (test infrastructure): level 1 (blocked two-bit 3-gram bitmap), the
-bypass for patterns of up to three bytes, and the prefix ladder, evaluated exactly as scan_gfx950.hip does from the
+bypass for patterns of up to three bytes, and the prefix ladder, evaluated exactly as scan_*.hip does from the
 tables the library compiled (contract: struct Filter and the hash helpers in pfac_amd/csrc/pfac_context.h)."""
 import numpy as np
 

@@ -422,7 +422,7 @@ def test_cpp_example_program_prints_the_readme_answer(tmp_path):
 
 def test_input_larger_than_4_gib(workdir):
     """The vector kernel keeps positions in 32 bits; inputs of 4 GiB and more are scanned as
-    consecutive windows (scan_gfx950.hip: kMaxLaunchBytes) whose overlap is rewritten by the next
+    consecutive windows (scan_module.hip: kMaxLaunchBytes) whose overlap is rewritten by the next
     window.  Patterns planted across the window boundary, across 2^32 and at the very end must be
     reported, and the whole vector must equal those of the tiled kernel (64-bit group offsets) and of the reference-shaped
     kernel (size_t positions, reference-layout table).

@@ -185,7 +185,7 @@ def test_misaligned_pointers_stay_on_the_vector_kernel(workdir, capsys):
 @pytest.mark.parametrize("n,everywhere", [((3 << 20) + 77, False), ((48 << 20) + 5, False), ((300 << 20) + 1, False), ((1 << 30) + 4097, False),
                                           ((3 << 29) + 123, False), ((4 << 20) + 9, True), ((96 << 20) + 1, True)])
 def test_compacted_output_is_in_position_order_at_every_bin_shape(workdir, n, everywhere):
-    """PFAC_matchFromDeviceReduce orders its pairs with position bins (scan_gfx950.hip: orderPairs): the bin width follows
+    """PFAC_matchFromDeviceReduce orders its pairs with position bins (scan_order.inc: PairOrder): the bin width follows
     the input size (64 positions ... 32 Ki positions), a bin with more than 64 pairs is ranked through a bitmap in LDS.
     Inputs with crowded stretches (one position in eight matches) between sparse ones, at sizes that take every bin
     width class -- and crowded everywhere: more pairs than the handle's scratch holds on a first call, the launches leave

@@ -1,5 +1,5 @@
 """The filter kernel keeps the chunk in flight in vector registers that the compiler is told not to use
-(scan_gfx950.hip: prefetchChunk / kCompilerVgprs).  The contract is checked by the BUILD (pfac_amd/csrc/Makefile runs
+(scan_filter.hip: prefetchChunk / kCompilerVgprs).  The contract is checked by the BUILD (pfac_amd/csrc/Makefile runs
 pfac_amd/csrc/check_isa.py on the ISA it has just generated and fails without a library); these tests run the same
 functions on a fresh compile, and show that a kernel compiled for too many registers is refused.  hipcc on the CPU: no
 GPU needed."""
@@ -20,7 +20,7 @@ _spec.loader.exec_module(check_isa)
 def _compile(out, *flags):
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags,
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "pfac_amd", "csrc"),
-           os.path.join(ROOT, "pfac_amd", "csrc", "scan_gfx950.hip"), "-o", str(out)]
+           os.path.join(ROOT, "pfac_amd", "csrc", "scan_filter.hip"), "-o", str(out)]
     subprocess.run(cmd, check=True, capture_output=True, timeout=900)
     return out.read_text()
 

@@ -12,7 +12,9 @@ if [ "$rev" != WORK ]; then
   src=/tmp/pfac_variant_$name; rm -rf $src; mkdir -p $src
   git archive $rev pfac_amd/csrc include | tar -x -C $src
 fi
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -I$src/include -I$src/pfac_amd/csrc "$@" -shared -o $out/libpfac_gfx950.so $src/pfac_amd/csrc/scan_gfx950.hip 2>&1 | grep -E "error" || true
+units="$src/pfac_amd/csrc/scan_filter.hip $src/pfac_amd/csrc/scan_tiled.hip $src/pfac_amd/csrc/scan_module.hip"
+[ -f $src/pfac_amd/csrc/scan_gfx950.hip ] && units=$src/pfac_amd/csrc/scan_gfx950.hip          # revisions before the module was split into units
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -I$src/include -I$src/pfac_amd/csrc "$@" -shared -o $out/libpfac_gfx950.so $units 2>&1 | grep -E "error" || true
 ( cd $src/pfac_amd/csrc && g++ -O2 -std=c++17 -fPIC -fopenmp -D__HIP_PLATFORM_AMD__ "$@" -I/opt/rocm/include -I../../include -I. -shared \
-    -o $OLDPWD/$out/libpfac.so pfac_api.cpp pattern_compiler.cpp tables.cpp cpu_engine.cpp -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -ldl )
+    -o $OLDPWD/$out/libpfac.so $(ls pfac_api.cpp host_pipeline.cpp multi_gpu.cpp compiled_set.cpp pattern_compiler.cpp tables.cpp cpu_engine.cpp 2>/dev/null) -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -ldl )
 echo "built $name from $rev ($*)"; ls -la $out

@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--size-mib", type=int, default=1024, help="input bytes per GPU, MiB")
     ap.add_argument("--variant", default="auto", choices=["auto", "filter", "naive", "reftable"],
                     help="auto = the library default (PFACX_KERNEL_AUTO: what a drop-in PFAC.h caller gets; the filter kernel at bench sizes)")
+    ap.add_argument("--walker", default="auto", choices=["auto", "window", "stage"],
+                    help="walker of the full-result filter kernel (PFACX_setWalker): auto = the library default, what the handle's previous launch found its stream to be")
     ap.add_argument("--texture", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--perf-mode", default=None, choices=[None, "dense", "hash"])
     ap.add_argument("--platform", default="gpu", choices=["gpu", "cpu_omp"],
@@ -365,6 +367,8 @@ class Run:
                             "reftable": api.PFACX_KERNEL_REFTABLE}[args.variant]
             if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
                 self.handle.setKernelVariant(self.variant)
+            if getattr(args, "walker", "auto") != "auto" and self.gpu:
+                self.handle.setWalker({"window": api.PFACX_WALKER_WINDOW, "stage": api.PFACX_WALKER_STAGE}[args.walker])
             self.handle.readPatternFromFile(self.pattern_file)
             self.info = self.handle.info()
         else:
@@ -862,7 +866,7 @@ def rank_main(args):
                 "patterns": info.numOfPatterns, "states": info.numOfStates,
                 "table": "hashed" if run.perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
                 "walker_table": walker_table(args, run),
-                "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname,
+                "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname, "walker_requested": args.walker,
                 "build": build_info(), "platform": args.platform,
                 "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
                 "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if use_dist else None,

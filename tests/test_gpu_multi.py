@@ -1,6 +1,7 @@
 """GPU tests that need MORE THAN ONE device (skipped on a one-GPU box, so that the first multi-GPU box that runs the suite
 executes every multi-GPU line of the repo): the 2-rank RCCL bench in both scaling modes, the library's multi-GPU driver
-on devices [0, 1], and the strong-scaling mode on one device (which runs everywhere).
+on devices [0, 1]; and what runs everywhere: the strong-scaling mode on one device, two ranks SHARING one device over gloo
+(the orchestration of the N > 1 runs, minus RCCL).
 
 Reference model: PFAC/test/omp_PFAC.cpp:257-439 (one context per device, slices dealt round-robin with a
 max_patternLen + 1 overlap, the folded result of all slices equals the single run's)."""
@@ -42,6 +43,21 @@ def test_strong_scaling_mode_on_one_gpu():
     assert out["config"]["bit_exact"] is True and out["config"]["folded_reference"]["equal"] is True      # 8 MiB slices have committed digests
     assert out["config"]["folded_result"]["match_count"] == 4579 + 4590 + 4579 + 4571 + 4454 + 4655 + 4583 + 4493
     assert out["value"] > 0 and out["config"]["kernel_launched"] == "pfac_scan_tiled"                       # 8 MiB calls: the tiled kernel (AUTO)
+
+
+def test_two_ranks_on_one_device_over_gloo_weak_and_strong():
+    """The orchestration the driver's N > 1 runs go through -- bench.py starting its own rank processes, every rank scanning its
+    slice(s), rank 0 folding the gathered (count, checksum) facts against the committed reference digests -- with both ranks on
+    THIS device (--dist-backend gloo: the ranks share GPU 0), so that none of it is executed for the first time on a multi-GPU
+    node.  Weak: slices 0 and 1 of the c3 stream (8 MiB each: committed digests); strong: eight 8 MiB slices dealt round-robin."""
+    weak = _bench("--gpus", "2", "--dist-backend", "gloo", "--size-mib", "8", "--steps", "3", "--warmup", "1")
+    assert weak["n_gpus"] == 2 and weak["config"]["ranks_seen"] == [0, 1] and weak["config"]["dist_backend"] == "gloo"
+    assert weak["config"]["bit_exact"] is True and weak["scaling"] == "weak" and weak["config"]["folded_result"]["match_count"] == 4579 + 4590
+    strong = _bench("--gpus", "2", "--dist-backend", "gloo", "--scaling", "strong", "--total-mib", "64", "--size-mib", "8", "--steps", "3", "--warmup", "1")
+    assert strong["scaling"] == "strong" and strong["n_gpus"] == 2 and strong["config"]["slices_per_rank"] == 4
+    assert strong["config"]["ranks_seen"] == [0, 1]
+    assert strong["config"]["bit_exact"] is True and strong["config"]["folded_reference"]["equal"] is True
+    assert strong["config"]["folded_result"]["match_count"] == 4579 + 4590 + 4579 + 4571 + 4454 + 4655 + 4583 + 4493
 
 
 @two_gpus

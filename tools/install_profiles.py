@@ -11,7 +11,12 @@ for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json
              ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json"),
              ("bench_c3_2ranks_one_gpu_gloo.json", "bench_c3_2ranks_one_gpu_gloo.json"),
              ("bench_c5_naive.json", "bench_c5_naive_kernel.json"), ("bench_c4_strong_one_gpu.json", "bench_c4_strong_one_gpu.json"),
-             (os.path.join("traffic_c5", "summary.json"), "hbm_traffic_c5.json")):
+             ("bench_c5_under_rocprof.json", "bench_c5_under_rocprof.json"),
+             ("bench_c5_walker_window.json", "bench_c5_walker_window.json"), ("bench_c5_walker_stage.json", "bench_c5_walker_stage.json"),
+             ("bench_c3_walker_window.json", "bench_c3_walker_window.json"), ("bench_c3_walker_stage.json", "bench_c3_walker_stage.json"),
+             ("bench_c2_reftable_dense.json", "bench_c2_reftable_dense.json"), ("bench_c3_reftable_hashed.json", "bench_c3_reftable_hashed.json"),
+             ("pmc_full_c5.txt", "pmc_full_result_kernel_c5.txt"), ("pmc_full_c3.txt", "pmc_full_result_kernel_c3.txt"),
+             ("host_numa_probe.txt", "host_numa_probe.txt"), ("small_input_latency.txt", "small_input_latency.txt")):
     if os.path.exists(os.path.join(src, a)):
         cp(a, b)
 with open(os.path.join("profiles", f"{tag}_pmc_instruction_counts.txt"), "w") as out:
@@ -21,7 +26,7 @@ with open(os.path.join("profiles", f"{tag}_pmc_instruction_counts.txt"), "w") as
         f = os.path.join(src, f"pmc_reduce_{w}.txt")
         if os.path.exists(f):
             out.write(f"== {w}\n" + open(f).read() + "\n")
-for w in ("c3", "c2"):
+for w in ("c3", "c2", "c5"):
     rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
     keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "pfac_order" in r[0] or "fillBuffer" in r[0]]
     csv.writer(open(os.path.join("profiles", f"{tag}_{w}_rocprofv3_kernel_stats.csv"), "w")).writerows(keep)

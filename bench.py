@@ -58,6 +58,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md, 
 ALGO_BYTES_PER_INPUT_BYTE = 5    # 1 B input read + 4 B int32 result written
 SETTLE_STEPS = 32                # untimed launches after host-side checks, before the warmup steps
 OTHER_STEPS = 10                 # timed launches per entry of "other_configs"
+PMC_LAUNCHES = 4                 # launches of --worker pmc that the counter means are taken over (behind one synchronised launch)
 HOST_CALLS = 20                  # timed PFAC_matchFromHost / ...Reduce calls per buffer kind (median, best, p90)
 DIGESTS = os.path.join(ROOT, "tests", "golden", "full_digests.json")
 SCRATCH = os.path.join(ROOT, "gpurun_out", "bench")
@@ -201,7 +202,8 @@ def pmc_counter_mean(csv_dir, kernel_substr):
     for path in glob.glob(os.path.join(csv_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             if kernel_substr in r["Kernel_Name"]:
-                vals.append(float(r["Counter_Value"]))
+                vals.append((int(r.get("Dispatch_Id") or len(vals)), float(r["Counter_Value"])))
+    vals = [v for _, v in sorted(vals)][-PMC_LAUNCHES:]       # the launches behind the worker's first, synchronised one
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
@@ -800,7 +802,9 @@ def rank_main(args):
         f"({info.filterBitsSet} set) CUs={info.multiProcessorCount}")
 
     if args.worker == "pmc":                                   # profiled by rocprofv3: a few launches, nothing else
-        for _ in range(4):
+        run.step()                                             # as in the timed run: the first launch is over (and has voted on the
+        torch.cuda.synchronize()                               # handle's walker, PFACX_WALKER_AUTO) before the measured ones are queued
+        for _ in range(PMC_LAUNCHES):
             run.step()
         torch.cuda.synchronize()
         run.close()

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #ifndef PFAC_TILED_STATS
 #define PFAC_TILED_STATS 0                     /* measurement build: wave-wide step iterations, live lane-steps, walks, passes, dense groups */
 #endif
-    uint32_t tsIter = 0, tsLane = 0, tsWalks = 0, tsPasses = 0, tsDense = 0, tsGroups = 0;
+    uint32_t tsIter = 0, tsLane = 0, tsWalks = 0, tsPasses = 0, tsDense = 0, tsGroups = 0, tsExt = 0, tsExtLanes = 0;
 
     /* One group: g16 = its 16-byte aligned first byte; `span` bytes from there may be loaded (a multiple of 16: up to the
      * end of the 16-byte block that holds the last input byte); positions [lo, hi) of the group get a result, written to
@@ -329,6 +329,9 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                     ok &= ((diff << 8) << (56u - 8u * lenIn)) == 0;
                     const bool isLong = len > (uint32_t)pfac::kChainMax;
                     if (__ballot(ok & isLong) != 0) {
+#if PFAC_TILED_STATS
+                        tsExt++; tsExtLanes += (uint32_t)__popcll(__ballot(ok & isLong));
+#endif
                         /* a long slot of a wide bucket (pfac_context.h): header byte 7 and the chain bytes 8 .. len-1 of its
                          * extension unit against the 16 bytes from q + 8.  (row, ks and the edge byte still describe the bucket
                          * the slot came from.) */
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(a.work + pfac::kStatsWord) + 26;   /* behind the PFAC_TIMING words */
         atomicAdd(acc + 0, (unsigned long long)tsIter); atomicAdd(acc + 1, (unsigned long long)tsLane); atomicAdd(acc + 2, (unsigned long long)tsWalks);
         atomicAdd(acc + 3, (unsigned long long)tsPasses); atomicAdd(acc + 4, (unsigned long long)tsDense); atomicAdd(acc + 5, (unsigned long long)tsGroups);
+        atomicAdd(acc - 2, (unsigned long long)tsExt); atomicAdd(acc - 1, (unsigned long long)tsExtLanes);      /* the last two PFAC_TIMING words (the 8.25 KiB of counters end behind acc[5]) */
     }
 #else
     (void)tsIter; (void)tsLane; (void)tsWalks; (void)tsPasses; (void)tsDense; (void)tsGroups;
@@ -672,18 +676,18 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
     if (blocks < 1) blocks = 1;
     const size_t lds = fixed + hot * sizeof(pfac::ChainSlot);
 #if PFAC_TILED_STATS
-    (void)hipMemsetAsync(c->d_workCounters + pfac::kStatsWord + 52, 0, 6 * sizeof(unsigned long long), 0);
+    (void)hipMemsetAsync(c->d_workCounters + pfac::kStatsWord + 48, 0, 8 * sizeof(unsigned long long), 0);
 #endif
     if (big && hot == a.rootRow) hipLaunchKernelGGL(kernelBigHot, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
     else if (big) hipLaunchKernelGGL(kernelBig, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
     else hipLaunchKernelGGL(kernelSmall, dim3((unsigned)blocks), dim3(threads), lds, 0, a);
 #if PFAC_TILED_STATS
     {
-        unsigned long long t[6];
+        unsigned long long t[8];
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(t, c->d_workCounters + pfac::kStatsWord + 52, sizeof(t), hipMemcpyDeviceToHost);
-        fprintf(stderr, "PFAC_TILED_STATS owned %zu: groups %llu (dense %llu) passes %llu walks %llu wave-steps %llu live lane-steps %llu: %.2f steps per walk, %.1f live lanes per wave-step of %d\n",
-                a.owned, t[5], t[4], t[3], t[2], t[0], t[1], t[2] ? (double)t[1] / t[2] : 0.0, t[0] ? (double)t[1] / t[0] : 0.0, 64 * kTiledWalks);
+        (void)hipMemcpy(t, c->d_workCounters + pfac::kStatsWord + 48, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "PFAC_TILED_STATS owned %zu: groups %llu (dense %llu) passes %llu walks %llu wave-steps %llu live lane-steps %llu: %.2f steps per walk, %.1f live lanes per wave-step of %d; long-slot unit fetches: %llu wave-level, %llu lanes\n",
+                a.owned, t[7], t[6], t[5], t[4], t[2], t[3], t[4] ? (double)t[3] / t[4] : 0.0, t[2] ? (double)t[3] / t[2] : 0.0, 64 * kTiledWalks, t[0], t[1]);
     }
 #endif
     return hipGetLastError();

@@ -35,7 +35,7 @@
  *      not to use (v119..v127, inline assembly), so that no register copy ever waits
  *      for it.
  *   2. LIST.  The lanes' hits become one list of 16-bit codes (prefix sum of the hit
- *      counts, one divergent loop).  A chunk in which more than 90 % of the positions
+ *      counts, one divergent loop).  A chunk in which more than half of the positions
  *      hit is not listed: it goes on the launch's dense list, and the tiled kernel
  *      behind this launch walks its positions in place (its dense mode).
  *   3. LEVEL-4 TEST, one hit per lane: the first four bytes against level 4 of the

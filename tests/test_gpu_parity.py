@@ -114,8 +114,9 @@ def test_ragged_sizes(workloads, n):
 def test_long_walks_across_every_tile_and_chunk_boundary(workdir, perf, tex, mode_name):
     """Full matches, prefixes-that-are-patterns and near misses of 60-byte patterns planted so that
     they straddle a 2 KiB chunk (and 1 KiB tile, 16-byte lane) boundary at every offset 0..71:
-    exercises the 12-byte queue entries across lanes / tiles / chunks, chains longer than a slot,
-    window re-fetches, the one-window-per-step mode and the hand-over to the tail kernel."""
+    exercises the walk queue's entries (36-byte windows of the register-window walker, {buffer, offset} codes of the stage
+    walker) across lanes / tiles / chunks, chains longer than a slot header (long slots and their units), window re-fetches,
+    walks that run off their staged chunk, and the bounded walks over the ends of the input."""
     import os
     from oracle import binding as ob
     from pfac_amd import workloads as wl

@@ -85,6 +85,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_workCounters);
     if (c->h_modeHint) { (void)hipHostFree(c->h_modeHint); c->h_modeHint = c->d_modeHint = nullptr; }
     devFree(c->d_reduceScratch);
+    c->orderCleanBase = nullptr;
     c->reduceScratchBytes = 0;
     freeHostStage(c);
     for (auto &e : c->evTime) { if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e)); e = nullptr; }
@@ -643,6 +644,7 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle)
     freeHostStage(handle);
     devFree(handle->d_reduceScratch);
     handle->reduceScratchBytes = 0;
+    handle->orderCleanBase = nullptr;
     devFree(handle->d_denseList);
     handle->denseListEntries = 0;
     for (auto &child : handle->children) if (child.second) (void)PFACX_trim(child.second);

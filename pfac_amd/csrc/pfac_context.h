@@ -46,6 +46,7 @@ constexpr int kModeHintWord = 35 * 32;           /* full-result filter kernel: 1
 constexpr int kModeVotesWord = 36 * 32;
 constexpr int kTiledDenseWord = 37 * 32;         /* tiled kernel scanning a whole big call: groups it walked in dense mode, groups in all, waves that are through (three words);
                                                     the last wave out tells the host whether the stream is pattern-dense (hostHint[1]) and leaves them zero */
+constexpr int kHostPairCountWord = 4;             /* word of the handle's mapped host memory (h_modeHint) the first ordering launch (pfac_order_count) writes the number of pairs of a compacted-output call to */
 constexpr int kStatsPublishedWord = 48 * 32;     /* 64-bit: the kStatsCount statistics of the last finished filter launch, then its dense chunks */
 constexpr int kStatsWord = 64 * 32;              /* 64-bit launch statistics of the scan kernel live here, behind the part counters (PFACX_getScanStats) */
 constexpr int kStatsCount = 6;                  /* walker rounds, lane steps, walks started, level-1 hits, positions scanned, ladder candidates */
@@ -222,6 +223,12 @@ struct PFAC_context {
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;
     size_t reduceScratchBytes = 0;
+    /* the counters at the head of the scratch as the last ordered call left them: all zero (the ordering launches clean up behind themselves, scan_order.inc), so
+     * the next call with the same layout needs no memset in front of its scan; null = not known to be zero */
+    const void *orderCleanBase = nullptr;
+    size_t orderCleanBytes = 0;
+    unsigned int orderSeq = 0;                /* number of the last ordered call (pfac_order_done writes it to host memory) */
+    unsigned int orderParity = 0;             /* which of the two pairs of call counters the next ordered call uses */
     /* staging of PFAC_matchFromHost / PFAC_matchFromHostReduce on the GPU platform (pfac_api.cpp): two input and two result
      * buffers of hostStageChunk (+ overlap) positions, two copy streams, events; created on first use */
     char *d_stageIn[2] = {nullptr, nullptr};

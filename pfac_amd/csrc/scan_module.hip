@@ -92,6 +92,7 @@
 #error "scan_*.hip is written for gfx950 (CDNA4): wave64, gfx9 waitcnt semantics, 160 KiB LDS"
 #endif
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdio>
 #include <cstring>
@@ -313,11 +314,27 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     const bool ordered = !c->reduceUnordered;              /* PFAC_matchFromHost scatters the pairs: any order */
 
     /* the handle's scratch: the counters of this call (pairs, pairs per position bin), room to order the pairs through */
+#ifndef PFAC_REDUCE_TRACE
+#define PFAC_REDUCE_TRACE 0                    /* measurement build: host-side timeline of a compacted-output call on stderr */
+#endif
+#if PFAC_REDUCE_TRACE
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto trUs = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); };
+    double trPlan = 0, trScan = 0, trOrder = 0, trDone = 0;
+#endif
     PairOrder order;
     const size_t expected = n / 128 > 65536 ? n / 128 : 65536;       /* room for one match per 128 bytes before the first call has been seen */
-    st = order.plan(handle, n, expected, d_match_result, d_pos);
+    st = order.plan(handle, n, expected, d_match_result, d_pos, handle->orderParity);
     if (st != PFAC_STATUS_SUCCESS) return st;
-    if (order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    /* an ordered call cleans up behind itself (scan_order.inc) and hands the number of pairs over in mapped host memory: no memset in
+     * front of the scan when the previous call has left this very layout clean, no device-to-host copy behind the last launch */
+    const bool tidy = ordered && order.o.hostCount != nullptr && c->h_modeHint != nullptr;
+    const bool clean = tidy && handle->orderCleanBase == order.o.counts && handle->orderCleanBytes == order.counterBytes;
+    handle->orderCleanBase = nullptr;                      /* until this call has ended well */
+    if (!clean && order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+#if PFAC_REDUCE_TRACE
+    trPlan = trUs();
+#endif
     const size_t head = headPositions(a.in, n);
     const size_t mainLen = filterLength(c, head, n, n, true);
     a.reducePos = d_pos;
@@ -342,16 +359,49 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         part.reduceBase = 0;
         if (pfacmod::launchSimpleKernel(c, hashed, tex, part) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     }
-    if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+#if PFAC_REDUCE_TRACE
+    trScan = trUs();
+#endif
     unsigned int count = 0;
-    if (hipMemcpy(&count, order.o.count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    if (tidy) {
+        volatile unsigned int *hostCount = c->h_modeHint + pfac::kHostPairCountWord, *hostDone = hostCount + 1;
+        handle->orderSeq = handle->orderSeq + 1u ? handle->orderSeq + 1u : 1u;
+        order.o.seq = handle->orderSeq;
+        *hostCount = 0xFFFFFFFFu;
+        if (order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+#if PFAC_REDUCE_TRACE
+        trOrder = trUs();
+#endif
+        /* the last launch writes the call's number into host memory: polled for a while (the call is a millisecond of GPU work per GiB) */
+        const auto t0 = std::chrono::steady_clock::now();
+        bool through = false;
+        for (unsigned int spins = 0; !(through = __atomic_load_n(const_cast<unsigned int *>(hostDone), __ATOMIC_ACQUIRE) == order.o.seq); spins++) {
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (!through && hipStreamSynchronize(0) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        count = *hostCount;
+#if PFAC_REDUCE_TRACE
+        trDone = trUs();
+        fprintf(stderr, "PFAC_REDUCE_TRACE us: planned %.1f, scan queued %.1f, ordering queued %.1f, done %.1f (clean %d, polled %d)\n", trPlan, trScan, trOrder, trDone, (int)clean, (int)through);
+#endif
+    } else {
+        if (ordered && order.order(c) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+        if (hipMemcpy(&count, order.o.count, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    }
     if (count > (unsigned int)input_size) return PFAC_STATUS_INTERNAL_ERROR;
     if (ordered && count > order.o.capacity) {             /* more pairs than the scratch held: the launches left at once */
-        st = order.plan(handle, n, count, d_match_result, d_pos);
+        st = order.plan(handle, n, count, d_match_result, d_pos, handle->orderParity);
         if (st != PFAC_STATUS_SUCCESS) return st;
         if (order.clearCounters() != hipSuccess || hipMemcpyAsync(order.o.count, &count, sizeof(count), hipMemcpyHostToDevice, 0) != hipSuccess ||
             order.order(c) != hipSuccess || hipStreamSynchronize(0) != hipSuccess)      /* `count` is read by that copy */
             return PFAC_STATUS_INTERNAL_ERROR;
+    } else if (tidy) {
+        handle->orderParity ^= 1u;                         /* the counters this call has just left zero */
+        handle->orderCleanBase = order.o.counts;
+        handle->orderCleanBytes = order.counterBytes;
     }
     *h_num_matched = (int)count;
     if (count && h_match_result && hipMemcpy(h_match_result, d_match_result, count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)

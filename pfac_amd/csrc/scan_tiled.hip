@@ -173,6 +173,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #define PFAC_TILED_STATS 0                     /* measurement build: wave-wide step iterations, live lane-steps, walks, passes, dense groups */
 #endif
     uint32_t tsIter = 0, tsLane = 0, tsWalks = 0, tsPasses = 0, tsDense = 0, tsGroups = 0, tsExt = 0, tsExtLanes = 0;
+    (void)tsExt; (void)tsExtLanes;
 
     /* One group: g16 = its 16-byte aligned first byte; `span` bytes from there may be loaded (a multiple of 16: up to the
      * end of the 16-byte block that holds the last input byte); positions [lo, hi) of the group get a result, written to

@@ -95,7 +95,10 @@ constexpr uint32_t kTiledFar = 0x40000000u;            /* "the input ends nowher
  * a patch that has to wait until the zeros are in L2 is on that path (4 KiB call 8.3 -> 7.2 us); the big shape hides the wait behind
  * fifteen other waves and spends the LDS on hot rows */
 constexpr uint32_t kTiledPairs = 32;                   /* compacted output: (position, id) pairs a wave stages in LDS before it appends them with one atomic */
-constexpr uint32_t tiledWaveLds(int tiles) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + kTiledPairs * 8 + (tiles == 1 ? kTiledTile * 4 : 0); }
+constexpr int kRefWalksBig = 4;                        /* ... walks per lane (8: 128 VGPRs, C3 hashed 0.317 against 0.324 -- the rounds are bound by the number of gathers by then) */
+constexpr uint32_t kRefPend = 64 * kRefWalksBig + 256;                      /* reference-table kernel, big shape: positions of several groups that wait for a walk round (32-bit offsets from a.in) */
+constexpr int kRefTilesBig = 2;                        /* ... whose groups are 2 KiB: the walk rounds are filled from the pending list, not from one group, and the list needs the LDS */
+constexpr uint32_t tiledWaveLds(int tiles, bool refBig = false) { return (uint32_t)tiles * kTiledTile + kTiledHalo + kTiledList * 2 + kTiledPairs * 8 + (tiles == 1 ? kTiledTile * 4 : 0) + (refBig ? kRefPend * 4 : 0); }
 
 /* REF >= 0 (a TableMode): the same frame -- 16-byte loads, group + halo and the initial state's row in LDS, 3-gram early-out, whole
  * zero lines, compacted survivors, __ballot loop exit -- over the REFERENCE-layout table of the perf mode instead of the chained
@@ -107,6 +110,15 @@ template <bool TEX, int WALKS, int TILES, bool HOTALL, int REF = -1>
 __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 {
     constexpr bool kRef = REF >= 0;
+    /* the reference-layout tables cost one (dense) or two dependent (hashed) gathers per BYTE: in the big shape a position walks them only
+     * if its first four bytes are a pattern prefix (prefix4: the trie's depth-4 nodes, two probes), or a pattern of three bytes (final3) or
+     * of one or two (shortBits) matches there -- the level-4 test of the compacted-output filter kernel (pfac_context.h: struct Filter;
+     * all three are supersets: a miss proves the result is 0).  Snort-style stream: 53.2 M -> 21.3 M walks per GiB.
+     * And the walks of a sparse group do not run with the group: a step through these tables is a dependent gather (or two) per byte and a
+     * round lasts as long as its deepest walk, so a round of 80 walks costs what a round of 256 does.  The survivors' positions go on a
+     * pending list (kRefPend offsets from a.in per wave) and a round runs when 256 are waiting, its input bytes read from global memory
+     * (they have just been streamed: L2), one byte ahead of the table lookups.  C3 through the hashed pair: 0.227 -> see DESIGN 3.2b. */
+    constexpr bool kRefLevel4 = kRef && TILES > 1;
     constexpr uint32_t kGroup = (uint32_t)TILES * kTiledTile, kStage = kGroup + kTiledHalo;
     static_assert(kGroup <= 4096, "a position's code is 12 bits of offset in 16");
     static_assert(kTiledList >= 64u * (uint32_t)TILES, "dense mode parks the lanes' hit masks in the list's place");
@@ -123,12 +135,14 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     uint32_t *sGram3 = reinterpret_cast<uint32_t *>(smem);                     /* LDS address 0: level 1 addresses it by number */
     u32x4 *sRoot = reinterpret_cast<u32x4 *>(sGram3 + words3);
     u32x4 *sHot = sRoot + pfac::kCharSet;
-    unsigned char *waveBase = reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + wave * tiledWaveLds(TILES);
+    unsigned char *waveBase = reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + wave * tiledWaveLds(TILES, kRefLevel4);
     uint32_t *stage = reinterpret_cast<uint32_t *>(waveBase);
     uint16_t *list = reinterpret_cast<uint16_t *>(waveBase + kStage);
     constexpr bool kLdsResults = TILES == 1;               /* a sparse group's results are assembled in LDS and stored once, as whole lines */
     uint32_t *pairPos = reinterpret_cast<uint32_t *>(waveBase + kStage + kTiledList * 2), *pairId = pairPos + kTiledPairs;
     int *res = reinterpret_cast<int *>(waveBase + kStage + kTiledList * 2 + kTiledPairs * 8);
+    uint32_t *pend = reinterpret_cast<uint32_t *>(waveBase + kStage + kTiledList * 2 + kTiledPairs * 8);      /* kRefLevel4 (TILES > 1: no `res`) */
+    (void)pend;
     /* ScanArgs::reportDense: the block's dense groups, groups, waves that are through -- in the pair staging of the block's first wave */
     uint32_t *blockAcc = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sHot + a.hotSlots) + kStage + kTiledList * 2);
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
@@ -141,6 +155,14 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #endif
         if constexpr (kRef) {
             for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) reinterpret_cast<int *>(sRoot)[i] = a.initialRow[i];   /* ref: the initial state's row in shared memory, PFAC_kernel.cu:396-403 */
+            if constexpr (kRefLevel4) {
+                /* the hot-row space (launchTiledRef sizes it): prefix4 | final3 | the exact 2-byte bitmap, if the set has patterns that short */
+                const uint32_t p4 = (1u << pfac::kPrefix4Log2) / 128u, f3 = (1u << a.log2BitsF3) / 128u, sb = a.shortBits != nullptr ? 65536u / 128u : 0u;
+                for (uint32_t i = (uint32_t)tid; i < p4; i += blockDim.x) sHot[i] = reinterpret_cast<const u32x4 *>(a.prefix4)[i];
+                if ((1u << a.log2BitsF3) >= 128u) { for (uint32_t i = (uint32_t)tid; i < f3; i += blockDim.x) sHot[p4 + i] = reinterpret_cast<const u32x4 *>(a.final3)[i]; }
+                else for (uint32_t i = (uint32_t)tid; i < (1u << a.log2BitsF3) / 32u; i += blockDim.x) reinterpret_cast<uint32_t *>(sHot + p4)[i] = a.final3[i];
+                for (uint32_t i = (uint32_t)tid; i < sb; i += blockDim.x) sHot[p4 + (f3 ? f3 : 1u) + i] = reinterpret_cast<const u32x4 *>(a.shortBits)[i];
+            }
         } else {
             for (int i = tid; i < pfac::kCharSet; i += (int)blockDim.x) sRoot[i] = a.chainSlots[a.rootRow + (uint32_t)i];
             for (uint32_t i = (uint32_t)tid; i < a.hotSlots; i += blockDim.x) sHot[i] = a.chainSlots[i];
@@ -179,7 +201,136 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
      * end of the 16-byte block that holds the last input byte); positions [lo, hi) of the group get a result, written to
      * outGroup[offset]; `limit` = group offset of the first byte behind the input (a pattern cannot reach it);
      * posBase = position of the group's first byte in the caller's stream (compacted output) */
-    auto scanGroup = [&](const unsigned char *g16, uint64_t span, uint32_t lo, uint32_t hi, uint32_t limit, int *outGroup, uint32_t posBase) {
+    uint32_t pendCount = 0;                               /* wave-uniform */
+    const bool deferOk = kRefLevel4 && a.n < 0xFFFFFF00ull && a.denseList == nullptr;    /* the pending list holds 32-bit offsets */
+    /* compacted output: the matches of a walk set join the wave's staged pairs */
+    auto appendPairsFrom = [&](uint32_t posBase, const uint32_t (&o)[WALKS], const int (&match)[WALKS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < WALKS; k++) {
+            const bool has = match[k] != 0;
+            const uint64_t m = __ballot(has);
+            if (m) {
+                const uint32_t n = (uint32_t)__popcll(m);
+                if (staged + n > kTiledPairs) flushPairs();
+                if (n > kTiledPairs) {                         /* match-dense input: this set alone is worth an atomic */
+                    unsigned int at = 0;
+                    if (lane == 0) at = atomicAdd(a.reduceCount, n);
+                    at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + laneRankIn(m);
+                    if (has) { a.out[at] = match[k]; a.reducePos[at] = (int)(posBase + o[k]); }
+                } else {
+                    const uint32_t at = staged + laneRankIn(m);
+                    if (has) { pairPos[at] = posBase + o[k]; pairId[at] = (uint32_t)match[k]; }
+                    staged += n;
+                }
+            }
+        }
+    };
+
+
+    /* kRefLevel4: WALKS walks per lane from the offsets p[] (from a.in) through the reference-layout table, one byte per step; the bytes
+     * come from global memory, each loaded one step before it is used (beside the lookups of the step in front of it) */
+    auto runWalksGlobal = [&](const uint32_t (&p)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) __attribute__((always_inline)) {
+        if constexpr (kRefLevel4) {
+            const Lookup<kRef ? REF : 0> lookup(a);
+            const int *sInit = reinterpret_cast<const int *>(sRoot);
+            const uint32_t n32 = (uint32_t)a.n;                  /* deferOk: fits */
+            /* the input bytes off .. off+7 (any alignment; bytes at or behind the end of the input read as 0: no walk uses them).  A byte a
+             * step cost the near-miss stream (walks 24 to 60 bytes deep) more address-path time than the table's own gathers. */
+            typedef uint32_t u32_a1 __attribute__((aligned(1)));
+            auto load8 = [&](uint32_t off, uint32_t &lo, uint32_t &hi) __attribute__((always_inline)) {
+                lo = hi = 0;
+                if (off + 8u <= n32 && off + 8u > off) {
+                    lo = *reinterpret_cast<const u32_a1 *>(a.in + off);
+                    hi = *reinterpret_cast<const u32_a1 *>(a.in + off + 4u);
+                } else {
+                    for (uint32_t j = 0; j < 8u; j++)
+                        if (off + j < n32 && off + j >= off) { if (j < 4u) lo |= (uint32_t)a.in[off + j] << (8u * j); else hi |= (uint32_t)a.in[off + j] << (8u * (j - 4u)); }
+                }
+            };
+            /* all walks of a round take their i-th byte in the same iteration: the window of eight bytes moves for all of them at once, and is
+             * loaded one iteration before its first byte is needed */
+            uint32_t w0[WALKS], w1[WALKS], n0[WALKS], n1[WALKS];
+            int state[WALKS];
+#pragma unroll
+            for (int k = 0; k < WALKS; k++) {
+                match[k] = 0; state[k] = kTrap; w0[k] = w1[k] = n0[k] = n1[k] = 0;
+                if (alive[k]) load8(p[k], w0[k], w1[k]);
+                if (alive[k]) state[k] = sInit[w0[k] & 0xFFu];
+                alive[k] = alive[k] & (state[k] != kTrap);
+                match[k] = (alive[k] && state[k] <= a.numFinal) ? state[k] : 0;
+            }
+            for (uint32_t i = 1;; i++) {                         /* wave-uniform: byte p + i */
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) { alive[k] = alive[k] & (p[k] + i < n32) & (p[k] + i > p[k]); any |= alive[k]; }
+                if (__ballot(any) == 0) break;
+#if PFAC_TILED_STATS
+                tsIter++;
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) tsLane += (uint32_t)__popcll(__ballot(alive[k]));
+#endif
+                const uint32_t in8 = i & 7u;
+                if (in8 == 7u) {
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++) if (alive[k]) load8(p[k] + i + 1u, n0[k], n1[k]);
+                }
+                int next[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    next[k] = kTrap;
+                    const uint32_t ch = ((in8 < 4u ? w0[k] : w1[k]) >> (8u * (in8 & 3u))) & 0xFFu;
+                    if (alive[k]) next[k] = lookup(state[k], (int)ch);
+                }
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    alive[k] = alive[k] & (next[k] != kTrap);
+                    match[k] = (alive[k] && next[k] <= a.numFinal) ? next[k] : match[k];
+                    state[k] = next[k];
+                    if (in8 == 7u) { w0[k] = n0[k]; w1[k] = n1[k]; }
+                }
+            }
+        }
+    };
+    /* rounds of 64 x WALKS pending positions while that many are waiting (all: whatever is left) */
+    auto drainPend = [&](bool all) __attribute__((always_inline)) {
+        if constexpr (kRefLevel4) {
+            while (pendCount >= 64u * (uint32_t)WALKS || (all && pendCount != 0)) {
+                const uint32_t take = pendCount < 64u * (uint32_t)WALKS ? pendCount : 64u * (uint32_t)WALKS, first = pendCount - take;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t p[WALKS];
+                int match[WALKS];
+                bool alive[WALKS];
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) {
+                    const uint32_t e = first + (uint32_t)k * 64u + (uint32_t)lane;
+                    alive[k] = e < pendCount;
+                    p[k] = alive[k] ? pend[e] : 0u;
+                }
+#if PFAC_TILED_STATS
+#pragma unroll
+                for (int k = 0; k < WALKS; k++) tsWalks += (uint32_t)__popcll(__ballot(alive[k]));
+#endif
+                runWalksGlobal(p, alive, match);
+                if (reduce) appendPairsFrom(a.reduceBase, p, match);
+                else {
+                    bool found = false;
+#pragma unroll
+                    for (int k = 0; k < WALKS; k++) found |= match[k] != 0;
+                    if (__ballot(found) != 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* the zeros of these positions' groups are in L2 before their patches */
+#pragma unroll
+                        for (int k = 0; k < WALKS; k++)
+                            if (match[k] != 0) a.out[p[k]] = match[k];
+                    }
+                }
+                pendCount = first;
+            }
+        }
+    };
+
+    /* rel32: offset of the group's byte 0 from a.in (mod 2^32; deferred walks of the reference-table kernel) */
+    auto scanGroup = [&](const unsigned char *g16, uint64_t span, uint32_t lo, uint32_t hi, uint32_t limit, int *outGroup, uint32_t posBase, uint32_t rel32) {
         const uint32_t span32 = span > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)span;
         const bool whole = lo == 0 && (hi & (kTiledTile - 1u)) == 0;      /* whole tiles: all of the group, or -- a dense chunk -- its first ones */
         const bool bounded = limit < kGroup + a.maxWalk + 16u;           /* wave-uniform: a walk of this group can come near the end of the input */
@@ -281,6 +432,20 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             else w = (q & ~3u) < span32 ? *reinterpret_cast<const uint32_t *>(g16 + (q & ~3u)) : 0u;
             return (w >> (8u * (q & 3u))) & 0xFFu;
         };
+        /* kRefLevel4: may a pattern match at a position whose first four bytes are x?  (prefix4, final3, shortBits: pfac_context.h) */
+        auto level4 = [&](uint32_t x) __attribute__((always_inline)) -> bool {
+            const uint32_t *sP4 = reinterpret_cast<const uint32_t *>(sHot);
+            const uint32_t f3Words = (1u << a.log2BitsF3) / 32u;
+            const uint32_t *sF3 = sP4 + (1u << pfac::kPrefix4Log2) / 32u, *sShort = sF3 + (f3Words < 4u ? 4u : f3Words);
+            const uint32_t h = x * pfac::kLadMul0;
+            const uint32_t i1 = h >> (32 - pfac::kPrefix4Log2), i2 = (uint32_t)(h * pfac::kLadMulS) >> (32 - pfac::kPrefix4Log2);
+            const uint32_t shiftF3 = 32u - (uint32_t)a.log2BitsF3;
+            uint32_t pass = testBit(sP4, i1) & testBit(sP4, i2);
+            pass |= testBit(sF3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> shiftF3) & testBit(sF3, (uint32_t)__umul24(x, pfac::kFinal3Mul2) >> shiftF3);
+            if (a.shortBits != nullptr) pass |= testBit(sShort, x & 0xFFFFu);
+            return pass != 0;
+        };
+        (void)level4;
         auto runWalksRef = [&](const uint32_t (&o)[WALKS], bool (&alive)[WALKS], int (&match)[WALKS]) {
             if constexpr (kRef) {
                 const Lookup<kRef ? REF : 0> lookup(a);
@@ -289,6 +454,11 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #pragma unroll
                 for (int k = 0; k < WALKS; k++) {
                     q[k] = o[k]; match[k] = 0; state[k] = kTrap;
+                    if constexpr (kRefLevel4) {
+                        uint32_t x = 0, x1 = 0;
+                        if (alive[k]) fetch(q[k], x, x1);
+                        alive[k] = alive[k] & level4(x);
+                    }
                     if (alive[k]) state[k] = sInit[byteAt(q[k])];
                     alive[k] = alive[k] & (state[k] != kTrap);
                     match[k] = (alive[k] && state[k] <= a.numFinal) ? state[k] : 0;
@@ -409,28 +579,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             if constexpr (kRef) runWalksRef(o, alive, match);
             else runWalksChained(o, alive, match);
         };
-        /* compacted output: the matches of a walk set join the wave's staged pairs */
-        auto appendPairs = [&](const uint32_t (&o)[WALKS], const int (&match)[WALKS]) {
-#pragma unroll
-            for (int k = 0; k < WALKS; k++) {
-                const bool has = match[k] != 0;
-                const uint64_t m = __ballot(has);
-                if (m) {
-                    const uint32_t n = (uint32_t)__popcll(m);
-                    if (staged + n > kTiledPairs) flushPairs();
-                    if (n > kTiledPairs) {                         /* match-dense input: this set alone is worth an atomic */
-                        unsigned int at = 0;
-                        if (lane == 0) at = atomicAdd(a.reduceCount, n);
-                        at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + laneRankIn(m);
-                        if (has) { a.out[at] = match[k]; a.reducePos[at] = (int)(posBase + o[k]); }
-                    } else {
-                        const uint32_t at = staged + laneRankIn(m);
-                        if (has) { pairPos[at] = posBase + o[k]; pairId[at] = (uint32_t)match[k]; }
-                        staged += n;
-                    }
-                }
-            }
-        };
+        auto appendPairs = [&](const uint32_t (&o)[WALKS], const int (&match)[WALKS]) { appendPairsFrom(posBase, o, match); };
 
         uint32_t cnt = 0;
 #pragma unroll
@@ -511,6 +660,26 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (kRefLevel4) {
+                if (deferOk) {
+                    /* the level-4 test on the staged bytes; what passes waits on the pending list for a full round (at most 255 are
+                     * waiting when a pass of at most kTiledList begins: kRefPend holds them) */
+                    static_assert(64u * (uint32_t)WALKS + kTiledList <= kRefPend + 1u, "pending list");
+                    for (uint32_t base = 0; base < listedNow; base += 64u) {
+                        const uint32_t e = base + (uint32_t)lane;
+                        const bool act = e < listedNow;
+                        const uint32_t code = act ? (uint32_t)list[e] : 0u;
+                        uint32_t x = 0, x1 = 0;
+                        if (act) fetch(code, x, x1);
+                        const bool keep = act && level4(x);
+                        const uint64_t m = __ballot(keep);
+                        if (keep) pend[pendCount + laneRankIn(m)] = rel32 + code;
+                        pendCount += (uint32_t)__popcll(m);
+                    }
+                    drainPend(false);
+                    continue;
+                }
+            }
             for (uint32_t base = 0; base < listedNow; base += 64u * (uint32_t)WALKS) {
                 uint32_t o[WALKS];
                 int match[WALKS];
@@ -571,8 +740,9 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
             const uint32_t hi = ownEnd - T < kGroup ? (uint32_t)(ownEnd - T) : kGroup;
             const uint32_t limit = readEnd - T < kTiledFar ? (uint32_t)(readEnd - T) : kTiledFar;
             int *outGroup = reinterpret_cast<int *>(reinterpret_cast<uintptr_t>(a.out) + (T - head) * 4u);     /* T < head only in group 0, whose first `head` slots are never written */
-            scanGroup(base16 + T, spanAll - T, lo, hi, limit, outGroup, a.reduceBase + (uint32_t)(T - head));
+            scanGroup(base16 + T, spanAll - T, lo, hi, limit, outGroup, a.reduceBase + (uint32_t)(T - head), (uint32_t)(T - head));
         }
+        drainPend(true);
     }
     if (listed != 0) {
         /* the chunks the filter kernel in front of this launch left to this kernel (ScanArgs::denseList): denseIn is the
@@ -584,7 +754,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
         for (uint64_t it = gid; it < items; it += stride) {
             const uint64_t T = (uint64_t)a.denseList[it / kPerChunk] * kChunk + (it % kPerChunk) * kGroup;
             const uint32_t limit = a.denseReadable - T < kTiledFar ? (uint32_t)(a.denseReadable - T) : kTiledFar;
-            scanGroup(a.denseIn + T, spanAll - T, 0u, kTake, limit, a.denseOut + T, 0u);
+            scanGroup(a.denseIn + T, spanAll - T, 0u, kTake, limit, a.denseOut + T, 0u, 0u);
         }
     }
     if (reduce) flushPairs();
@@ -698,7 +868,7 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
 template <int MODE>
 hipError_t launchTiledRef(const PFAC_context *c, ScanArgs a)
 {
-    auto kernelBig = pfac_scan_tiled<false, kTiledWalks, kTiledTilesBig, false, MODE>;
+    auto kernelBig = pfac_scan_tiled<false, kRefWalksBig, kRefTilesBig, false, MODE>;
     auto kernelSmall = pfac_scan_tiled<false, PFAC_TILED_WALKS_SMALL, 1, false, MODE>;
     static ShapeCache cache;
     int dev = -1;
@@ -716,14 +886,17 @@ hipError_t launchTiledRef(const PFAC_context *c, ScanArgs a)
     }
     const size_t head = reinterpret_cast<uintptr_t>(a.in) & 15u;
     const bool big = a.owned >= kTiledBigBytes;
-    const size_t group = (big ? (size_t)kTiledTilesBig : 1) * kTiledTile;
+    const size_t group = (big ? (size_t)kRefTilesBig : 1) * kTiledTile;
     const size_t groups = a.owned ? (head + a.owned + group - 1) / group : 0;
     const unsigned threads = big ? 1024u : 256u;
     const size_t waves = threads / 64;
     const size_t cus = (size_t)(c->multiProcessorCount > 0 ? c->multiProcessorCount : 256);
-    const size_t lds = (size_t(1) << c->filter.log2Bits) / 8 + (size_t)pfac::kCharSet * sizeof(pfac::ChainSlot) + waves * tiledWaveLds(big ? kTiledTilesBig : 1);
-    if (lds > kLdsPerCu) return hipErrorInvalidValue;
-    a.hotSlots = 0;
+    /* big shape: prefix4 | final3 | shortBits in the place of the hot rows (pfac_scan_tiled: kRefLevel4), a pending list per wave */
+    const size_t f3Bytes = (size_t(1) << c->filter.log2BitsF3) / 8;
+    const size_t level4 = big ? (size_t(1) << pfac::kPrefix4Log2) / 8 + (f3Bytes < 16 ? 16 : f3Bytes) + (a.shortBits != nullptr ? 65536 / 8 : 0) : 0;
+    const size_t lds = (size_t(1) << c->filter.log2Bits) / 8 + (size_t)pfac::kCharSet * sizeof(pfac::ChainSlot) + level4 + waves * tiledWaveLds(big ? kRefTilesBig : 1, big);
+    if (lds > kLdsPerCu || (big && (a.prefix4 == nullptr || a.final3 == nullptr))) return hipErrorInvalidValue;
+    a.hotSlots = (uint32_t)(level4 / 16);
     a.denseList = nullptr;
     size_t blocks = (groups + waves - 1) / waves;
     if (blocks > (big ? cus : cus * 16)) blocks = big ? cus : cus * 16;

@@ -313,3 +313,63 @@ def test_match_from_host_pinned_keeps_up_with_pageable(workdir):
         assert n / med["pinned"] >= 0.8 * (n / med["pageable"]), med
     finally:
         h.destroy()
+
+
+def test_compacted_output_calls_leave_their_counters_clean(workdir):
+    """PFAC_matchFromDeviceReduce keeps state between calls since round 5 (scan_order.inc, scan_module.hip: reduceScan): the ordering
+    launches leave the bin counters zero and the next call skips its memset when it finds the same layout; the pairs' counter
+    exists twice and calls alternate; the count comes back through mapped host memory.  Sequences that change everything that
+    state depends on -- the input size (another bin layout), a call whose pairs do not fit the scratch (second round through the
+    four kernels behind a larger scratch), PFAC_matchFromHost in between (its pieces run the unordered path on the same scratch),
+    PFACX_trim (the scratch is gone), the tiled kernel (small inputs) -- and after each step the pairs must be exactly the non-zero
+    entries of the full result in position order.
+    ANCHOR: the full result of the same handle (pinned on the oracle / the reference digests by test_gpu_parity.py), as in
+    tests/test_gpu_round3.py::test_compacted_output_is_in_position_order_at_every_bin_shape."""
+    pats = [b"h", b"ab", b"abc", b"gfe", b"mnop", b"xyzzy", b"qq", b"nopqrstu"]
+    pf = wl.write_pattern_file(os.path.join(workdir, "tidy.pat"), pats)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(77)
+    big = (96 << 20) + 13
+    sparse = torch.randint(105, 123, (big,), dtype=torch.uint8, device="cuda:0", generator=g)           # 'i'..'z': mnop, xyzzy, qq, nopqrstu
+    crowded = torch.randint(97, 105, (40 << 20,), dtype=torch.uint8, device="cuda:0", generator=g)      # 'a'..'h': one position in eight matches
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_AUTOMATIC, api.PFACX_KERNEL_AUTO)
+    d_res = torch.empty(big, dtype=torch.int32, device="cuda:0")
+    d_pos = torch.empty(big, dtype=torch.int32, device="cuda:0")
+    d_full = torch.empty(big, dtype=torch.int32, device="cuda:0")
+
+    def check(d_in, n, what):
+        h.matchFromDevice(d_in.data_ptr(), n, d_full.data_ptr())
+        want_pos = torch.nonzero(d_full[:n]).flatten()
+        want_ids = d_full[:n][want_pos]
+        d_res.fill_(-5)
+        d_pos.fill_(-5)
+        _, count = h.matchFromDeviceReduce(d_in.data_ptr(), n, d_res.data_ptr(), d_pos.data_ptr())
+        torch.cuda.synchronize()
+        assert count == want_pos.numel(), (what, count, want_pos.numel())
+        assert torch.equal(d_pos[:count].to(torch.int64), want_pos) and torch.equal(d_res[:count], want_ids), what
+        assert int(d_pos[count:].max()) == -5 and int(d_res[count:].max()) == -5, what
+        return count
+
+    try:
+        first = check(sparse, big, "first call")
+        assert check(sparse, big, "same layout: no memset") == first
+        assert check(sparse, big, "same layout again: the other pair of counters") == first
+        check(sparse, (33 << 20) + 5, "smaller input: another bin layout")
+        assert check(sparse, big, "back to the first layout") == first
+        many = check(crowded, 40 << 20, "more pairs than the scratch holds")
+        assert many > (40 << 20) // 16
+        check(crowded, 40 << 20, "... and again, behind the larger scratch")
+        assert check(sparse, big, "sparse again") == first
+        host = np.frombuffer(sparse[:(48 << 20) + 3].cpu().numpy().tobytes(), dtype=np.uint8)
+        got = np.empty(host.size, dtype=np.int32)
+        h.matchFromHost(host.ctypes.data, host.size, got.ctypes.data)                                      # unordered pieces on the same scratch
+        h.matchFromDevice(sparse.data_ptr(), host.size, d_full.data_ptr())
+        assert np.array_equal(got, d_full[:host.size].cpu().numpy()), "PFAC_matchFromHost"
+        assert check(sparse, big, "after PFAC_matchFromHost") == first
+        h.trim()
+        assert check(sparse, big, "after PFACX_trim") == first
+        check(sparse[5:], (1 << 20) + 1, "a small, misaligned input: the tiled kernel")
+        check(sparse, 700, "700 bytes")
+        assert check(sparse, big, "and the big one once more") == first
+    finally:
+        h.destroy()

@@ -900,7 +900,7 @@ def rank_main(args):
                 walls.append(time.perf_counter() - t0r)             # the call is synchronous: the count is back
             torch.cuda.synchronize()
             tr = float(np.median(walls))                            # medians of 10 calls: one slow call (a clock dip, a host hiccup) is not the figure
-            gpu_ms = float(np.median([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel (the input's ends ride along in it) + ordering launches + the count's copy, on the launch stream
+            gpu_ms = float(np.median([ea.elapsed_ms(eb) for ea, eb in rev]))        # scan kernel (the input's ends ride along in it) + ordering launches + the completion word, on the launch stream
             # the scan kernel alone: the library brackets its launch with HIP events when asked (two more calls, not in the figures above)
             run.handle.setKernelTiming(True)
             kms = []
@@ -923,9 +923,10 @@ def rank_main(args):
                                  "algorithmic_bytes_per_call": algo,
                                  "roofline": {"bound": "hbm", "achieved": round(algo / (gpu_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(algo / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events: the ordering counters' memset, scan kernel, four ordering launches, "
-                                                      "the count's copy); kernel_ms = the scan kernel alone (PFACX_setKernelTiming; rocprofv3 kernel stats in profiles/ agree); this path is "
-                                                      "bound by the scanning waves' instruction issue, not by HBM"},
+                                              "note": "N input bytes + 8 B per match over the GPU time of the call (HIP events around the call: scan kernel, four ordering launches that clean up "
+                                                      "behind themselves, a one-thread launch that tells the polling host the call is through; the events themselves are recorded by an idle "
+                                                      "queue and include its wake-up); kernel_ms = the scan kernel alone (PFACX_setKernelTiming; rocprofv3 kernel stats in profiles/ agree); "
+                                                      "this path is bound by the scanning waves' instruction issue, not by HBM"},
                                  "note": "PFAC_matchFromDeviceReduce, synchronous (the match count returns to the host); ~1 B of HBM traffic per input byte"}
             if not same:
                 all_ok = False

@@ -331,7 +331,9 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     const bool tidy = ordered && order.o.hostCount != nullptr && c->h_modeHint != nullptr;
     const bool clean = tidy && handle->orderCleanBase == order.o.counts && handle->orderCleanBytes == order.counterBytes;
     handle->orderCleanBase = nullptr;                      /* until this call has ended well */
-    if (!clean && order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
+    /* (PFACX_setKernelTiming: the memset stays -- the event in front of the scan kernel would otherwise be recorded by an idle queue, and the
+     * kernel's time would include the queue's wake-up) */
+    if ((!clean || c->kernelTiming) && order.clearCounters() != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
 #if PFAC_REDUCE_TRACE
     trPlan = trUs();
 #endif

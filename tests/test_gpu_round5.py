@@ -140,6 +140,7 @@ def switching(workdir, longset):
 def test_stream_that_changes_its_nature_inside_one_launch(switching, walker, walker_name):
     pf, data, want = switching
     h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO | (walker << 8))
+    h.setWalker(walker)                            # AUTO too: a session under PFAC_TEST_WALKER has every new handle's walker forced
     try:
         for call in range(3):                      # AUTO: the first call runs the window walker, the next ones what the votes say
             assert_same(device_match(h, data), want, f"changing stream/{walker_name}/call {call}")
@@ -165,6 +166,7 @@ def test_auto_walker_follows_the_stream(workdir):
     near, text = cfg5.input_slice(n, 0), cfg3.input_slice(n, 0)
     want_near, want_text = _oracle(pf, near, omp=True), _oracle(pf, text, omp=True)
     h = make_handle(pf, api.PFAC_TIME_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    h.setWalker(api.PFACX_WALKER_AUTO)             # (a session under PFAC_TEST_WALKER forces every new handle's walker)
     try:
         seen = []
         for stream, want, name in ((text, want_text, "text"), (near, want_near, "near"), (near, want_near, "near"), (near, want_near, "near"),

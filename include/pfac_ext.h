@@ -158,6 +158,13 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle);
 PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size,
                                           int *h_matched_result, int numDevices, const int *devices);
 
+/* ... and its compacted-output form (PFAC_matchFromHostReduce over several GPUs): the (id, position) pairs of the whole stream in ascending
+ * position order, positions counted from the start of the stream; h_matched_result and h_pos hold `size` entries each (the workers use
+ * them as scratch), size < 2^31.  One byte per position crosses a host link and nothing is filled on the host: this, not the
+ * full-vector form, is what scales with the number of links. */
+PFAC_status_t PFACX_matchFromHostReduceMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result, int *h_pos,
+                                                int *h_num_matched, int numDevices, const int *devices);
+
 /* Counters of the most recent launch of the filter kernel on this handle (PFAC_matchFromDevice / ...Reduce of
  * 32 MiB or more; SURVEY 8d, configuration C5: walk depth, lane utilisation, early-out rate).  Waits for the default
  * stream.  All zero before the first such launch. */

@@ -89,7 +89,7 @@ EXPORTED_SYMBOLS = (
     # include/pfac_ext.h
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
-    "PFACX_matchFromHostMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
+    "PFACX_matchFromHostMultiGPU", "PFACX_matchFromHostReduceMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
     "PFACX_setKernelTiming", "PFACX_setWalker",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
@@ -144,6 +144,8 @@ def load_library() -> C.CDLL:
     lib.PFACX_saveCompiled.argtypes = [H, C.c_char_p]
     lib.PFACX_loadCompiled.argtypes = [H, C.c_char_p]
     lib.PFACX_matchFromHostMultiGPU.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    if hasattr(lib, "PFACX_matchFromHostReduceMultiGPU"):
+        lib.PFACX_matchFromHostReduceMultiGPU.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     for name in EXPORTED_SYMBOLS:
         if os.environ.get("PFAC_AB_OLD_LIBS") and not hasattr(lib, name):     # tools/ab.py: the library of an earlier revision
             continue
@@ -281,6 +283,16 @@ class PFAC:
             arr = (C.c_int * len(devices))(*devices)
             st = self._lib.PFACX_matchFromHostMultiGPU(self._h, h_input, size, h_result, len(devices), arr)
         return self._ret(st, "PFACX_matchFromHostMultiGPU", check)
+
+    def matchFromHostReduceMultiGPU(self, h_input: int, size: int, h_result: int, h_pos: int, devices=None, check: bool = True):
+        """``PFACX_matchFromHostReduceMultiGPU`` -> (status, number of pairs)."""
+        n = C.c_int(0)
+        if devices is None:
+            st = self._lib.PFACX_matchFromHostReduceMultiGPU(self._h, h_input, size, h_result, h_pos, C.byref(n), 0, None)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            st = self._lib.PFACX_matchFromHostReduceMultiGPU(self._h, h_input, size, h_result, h_pos, C.byref(n), len(devices), arr)
+        return self._ret(st, "PFACX_matchFromHostReduceMultiGPU", check), n.value
 
     def dumpTransitionTable(self, path: str, check: bool = True) -> int:
         fp = _libc.fopen(os.fsencode(path), b"w")

@@ -368,9 +368,11 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
  * position order, are copied straight behind those of the pieces before it: pieces are in stream order, so the whole list
  * is.  A pair whose position lies in the overlap belongs to the next piece, which finds it again.  Device memory: two
  * pieces (9 bytes per position) instead of 9 bytes for every position of the stream.
+ * The stream may be a slice of a longer one (PFACX_matchFromHostReduceMultiGPU): positions [0, owned) get their pairs, `readable`
+ * bytes may be read, posBase is added to every position; the caller's arrays hold `owned` entries.
  */
 constexpr size_t kHostReducePiece = size_t(16) << 20;
-PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, int *h_matched_result, int *h_pos, int *h_num_matched)
+PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, size_t readable, size_t posBase, int *h_matched_result, int *h_pos, int *h_num_matched)
 {
     if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
     const size_t overlap = (size_t)c->fa.maxPatternLen;
@@ -384,7 +386,7 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
     auto uploadPiece = [&](size_t i) -> bool {               /* into buffer i & 1, on the upload stream */
         const size_t off = i * piece;
         const size_t mine = size - off < piece ? size - off : piece;
-        const size_t scanned = size - off < mine + overlap ? size - off : mine + overlap;
+        const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
         return hipMemcpyAsync(c->d_stageIn[i & 1], h_inputString + off, scanned, hipMemcpyHostToDevice, up) == hipSuccess &&
                hipEventRecord(static_cast<hipEvent_t>(c->evUp[i & 1]), up) == hipSuccess;
     };
@@ -415,7 +417,7 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
         const int b = (int)(i & 1);
         const size_t off = i * piece;
         const size_t mine = size - off < piece ? size - off : piece;
-        const size_t scanned = size - off < mine + overlap ? size - off : mine + overlap;
+        const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
         while (uploadsQueued.load(std::memory_order_acquire) <= i && !uploadFailed.load(std::memory_order_relaxed)) std::this_thread::yield();
         ok = !uploadFailed.load(std::memory_order_relaxed) && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
         if (!ok) break;
@@ -424,12 +426,14 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
         if (st != PFAC_STATUS_SUCCESS) break;
         scansDone.store(i + 1, std::memory_order_release);     /* the scan is synchronous: its input buffer may take piece i + 2 */
         if (count == 0) continue;
-        /* total <= off (a position has at most one pair) and count <= scanned <= size - off: the caller's arrays (size entries) hold them */
-        if (hipMemcpy(h_pos + total, c->d_stagePos[b], (size_t)count * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        size_t keep = (size_t)count;                           /* positions ascend: those in the overlap are a suffix */
+        /* total <= off (a position has at most one pair); the pairs that stay (positions below `mine`) are at most `mine`, so they lie among the
+         * first size - total of the list: the caller's arrays (size entries) hold what is copied */
+        const size_t room = size - total, copied = (size_t)count < room ? (size_t)count : room;
+        if (hipMemcpy(h_pos + total, c->d_stagePos[b], copied * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        size_t keep = copied;                                  /* positions ascend: those in the overlap are a suffix */
         while (keep > 0 && (size_t)h_pos[total + keep - 1] >= mine) keep--;
         if (keep && hipMemcpy(h_matched_result + total, c->d_stageOut[b], keep * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        if (off) for (size_t k = 0; k < keep; k++) h_pos[total + k] += (int)off;
+        if (off + posBase) for (size_t k = 0; k < keep; k++) h_pos[total + k] += (int)(off + posBase);
         total += keep;
     }
     if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;

@@ -27,22 +27,14 @@
 
 using namespace pfac_internal;
 
-extern "C" {
+namespace {
 
-/*
- * pfac_ext.h: one call shards a host stream over several GPUs (SURVEY 8f rank 4; what every user of the
- * reference re-writes from PFAC/test/omp_PFAC.cpp:257-394 or SimpleMultiGPU_pthread.cpp:50-174).  One worker
- * thread per listed device: hipSetDevice, a per-device handle with this handle's pattern set and modes (kept in
- * the handle for the next call), a contiguous slice of the stream scanned together with the maxPatternLen bytes
- * behind it, only the slice's own results written (omp_PFAC.cpp:324,377).  No exchange between devices.
- */
-PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result,
-                                          int numDevices, const int *devices)
+/* The frame of both multi-GPU calls: one worker thread per listed device -- hipSetDevice, a per-device handle with this handle's pattern set and
+ * modes (kept in the handle for the next call), a contiguous slice [bound[i], bound[i + 1]) of the stream (boundaries rounded to the 1 KiB tile:
+ * pfac_amd/sharding.py plan_slices is the Python mirror) -- and `call(worker's handle, i, lo, hi)` on it, the worker's lock held. */
+template <class Call>
+PFAC_status_t onDevices(PFAC_handle_t handle, size_t size, int numDevices, const int *devices, std::vector<size_t> &bound, Call call)
 {
-    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
-    if (!h_inputString || !h_matched_result || numDevices < 0) return PFAC_STATUS_INVALID_PARAMETER;
-    if (size == 0) return PFAC_STATUS_SUCCESS;
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
     std::vector<int> devs;
@@ -61,8 +53,7 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
     /* the i-th worker's handle: bound to devs[i]; a device listed twice gets two handles (two streams of work) */
     while (c->children.size() < workers) c->children.emplace_back(-1, nullptr);
     std::vector<PFAC_status_t> status(workers, PFAC_STATUS_SUCCESS);
-    /* slice boundaries: contiguous, rounded to the 1 KiB tile (pfac_amd/sharding.py plan_slices is the Python mirror) */
-    std::vector<size_t> bound(workers + 1, 0);
+    bound.assign(workers + 1, 0);
     for (size_t i = 1; i < workers; i++) {
         size_t b = (size * i / workers) / 1024 * 1024;
         bound[i] = b > bound[i - 1] ? b : bound[i - 1];
@@ -96,7 +87,7 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
         }
         std::lock_guard<std::mutex> g(w->lock);
         w->textureMode = c->textureMode;
-        status[i] = matchHostOnGpu(w, h_inputString + bound[i], bound[i + 1] - bound[i], size - bound[i], h_matched_result + bound[i]);
+        status[i] = call(w, i, bound[i], bound[i + 1]);
     };
     int callerDevice = 0;
     (void)hipGetDevice(&callerDevice);
@@ -112,6 +103,64 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
     (void)hipSetDevice(callerDevice);
     for (PFAC_status_t st : status)
         if (st != PFAC_STATUS_SUCCESS) return st;
+    return PFAC_STATUS_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+/*
+ * pfac_ext.h: one call shards a host stream over several GPUs (SURVEY 8f rank 4; what every user of the
+ * reference re-writes from PFAC/test/omp_PFAC.cpp:257-394 or SimpleMultiGPU_pthread.cpp:50-174).  Each worker's slice is
+ * scanned together with the maxPatternLen bytes behind it, only the slice's own results written (omp_PFAC.cpp:324,377).
+ * No exchange between devices.
+ */
+PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result,
+                                          int numDevices, const int *devices)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!h_inputString || !h_matched_result || numDevices < 0) return PFAC_STATUS_INVALID_PARAMETER;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    std::vector<size_t> bound;
+    return onDevices(handle, size, numDevices, devices, bound, [&](PFAC_context *w, size_t, size_t lo, size_t hi) {
+        return matchHostOnGpu(w, h_inputString + lo, hi - lo, size - lo, h_matched_result + lo);
+    });
+}
+
+/*
+ * pfac_ext.h: the compacted-output form -- what scales with the host links (1 B per position over a link, nothing filled on the
+ * host: DESIGN.md 5).  Worker i leaves the pairs of its slice, positions counted from the start of the stream, at the slice's own
+ * offset of the caller's arrays (it has at most one pair per position); the lists are then moved together: slices are in stream
+ * order, so the whole list is in position order.
+ */
+PFAC_status_t PFACX_matchFromHostReduceMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size, int *h_matched_result, int *h_pos,
+                                                int *h_num_matched, int numDevices, const int *devices)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (!h_inputString || !h_matched_result || !h_pos || !h_num_matched || numDevices < 0 || size > 0x7FFFFFFFull) return PFAC_STATUS_INVALID_PARAMETER;
+    *h_num_matched = 0;
+    if (size == 0) return PFAC_STATUS_SUCCESS;
+    std::vector<size_t> bound;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
+    std::vector<int> counts((size_t)(numDevices ? numDevices : visible), 0);      /* one per worker */
+    const PFAC_status_t st = onDevices(handle, size, numDevices, devices, bound, [&](PFAC_context *w, size_t i, size_t lo, size_t hi) {
+        return matchHostReduceOnGpu(w, h_inputString + lo, hi - lo, size - lo, lo, h_matched_result + lo, h_pos + lo, &counts[i]);
+    });
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    size_t total = 0;
+    for (size_t i = 0; i + 1 < bound.size(); i++) {
+        const size_t n = (size_t)counts[i];
+        if (n && bound[i] != total) {
+            std::memmove(h_matched_result + total, h_matched_result + bound[i], n * sizeof(int));
+            std::memmove(h_pos + total, h_pos + bound[i], n * sizeof(int));
+        }
+        total += n;
+    }
+    *h_num_matched = (int)total;
     return PFAC_STATUS_SUCCESS;
 }
 

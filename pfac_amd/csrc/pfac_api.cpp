@@ -510,7 +510,7 @@ PFAC_status_t PFAC_matchFromHostReduce(PFAC_handle_t handle, char *h_inputString
     if (!handle->hasDevice || !handle->module) return PFAC_STATUS_LIB_NOT_EXIST;
     std::lock_guard<std::mutex> guard(handle->lock);
 
-    return matchHostReduceOnGpu(handle, h_inputString, size, h_matched_result, h_pos, h_num_matched);
+    return matchHostReduceOnGpu(handle, h_inputString, size, size, 0, h_matched_result, h_pos, h_num_matched);
 }
 
 /* ------------------------------------------------------------- extensions */

@@ -68,7 +68,7 @@ PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, 
 /* host_pipeline.cpp: the caller holds c->lock */
 PFAC_status_t matchDeviceLocked(PFAC_context *c, char *d_inputString, size_t size, int *d_matched_result);
 PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result);
-PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, int *h_matched_result, int *h_pos, int *h_num_matched);
+PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, size_t readable, size_t posBase, int *h_matched_result, int *h_pos, int *h_num_matched);
 
 } // namespace pfac_internal
 

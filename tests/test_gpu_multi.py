@@ -99,6 +99,12 @@ def test_multi_gpu_driver_on_devices_0_and_1(tmp_path):
             got = np.full(n, -3, dtype=np.int32)
             h.matchFromHostMultiGPU(data.ctypes.data, n, got.ctypes.data, devices)
             assert np.array_equal(got, want), f"devices {devices}"
+        # the compacted-output form over the same devices: the pairs of the whole stream in position order
+        want_pos = np.flatnonzero(want)
+        ids, pos = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        for devices in ([0, 1], [1, 0, 1]):
+            _, count = h.matchFromHostReduceMultiGPU(data.ctypes.data, n, ids.ctypes.data, pos.ctypes.data, devices)
+            assert count == want_pos.size and np.array_equal(pos[:count], want_pos) and np.array_equal(ids[:count], want[want_pos]), f"reduce, devices {devices}"
     finally:
         h.destroy()
         torch.cuda.set_device(0)

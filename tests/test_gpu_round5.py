@@ -375,3 +375,35 @@ def test_compacted_output_calls_leave_their_counters_clean(workdir):
         assert check(sparse, big, "and the big one once more") == first
     finally:
         h.destroy()
+
+
+def test_match_from_host_reduce_over_several_workers(workdir):
+    """PFACX_matchFromHostReduceMultiGPU: the compacted-output call sharded over worker threads / per-device handles (here every worker on
+    device 0: one, two and three slices; tests/test_gpu_multi.py runs devices [0, 1] where there are two).  Matches across every slice
+    boundary and at the very end of the stream; slices of several pieces; the pairs of the whole stream in position order == the non-zero
+    entries of the oracle's result (reference model: PFAC/test/omp_PFAC.cpp:257-439 + PFAC.cpp:1010-1128)."""
+    pats = wl.snort_patterns(3000)
+    pf = wl.write_pattern_file(os.path.join(workdir, "mgpu_reduce.pat"), pats)
+    n = (70 << 20) + 333                                              # more than one 16 Mi-position piece per worker
+    data = wl.http_stream(n, wl.http_message_pool(pats, pool_size=256, embed_fraction=0.3)).copy()
+    p = np.frombuffer(pats[7], dtype=np.uint8)
+    for cut in ((n // 2) // 1024 * 1024, (n // 3) // 1024 * 1024, (2 * n // 3) // 1024 * 1024):
+        data[cut - 2:cut - 2 + p.size] = p                            # a pattern across the boundary of two slices
+    data[n - p.size:] = p                                             # ... and one that ends with the stream
+    want = _oracle(pf, data, omp=True)
+    want_pos = np.flatnonzero(want)
+    h = api.PFAC.create()
+    h.setPerfMode(api.PFAC_SPACE_DRIVEN)
+    h.readPatternFromFile(pf)
+    try:
+        ids, pos = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        for devices in ([0], [0, 0], [0, 0, 0], None):
+            ids.fill(-7)
+            pos.fill(-7)
+            _, count = h.matchFromHostReduceMultiGPU(data.ctypes.data, n, ids.ctypes.data, pos.ctypes.data, devices)
+            assert count == want_pos.size, (devices, count, want_pos.size)
+            assert np.array_equal(pos[:count], want_pos) and np.array_equal(ids[:count], want[want_pos]), devices
+        _, single = h.matchFromHostReduce(data.ctypes.data, n, ids.ctypes.data, pos.ctypes.data)
+        assert single == want_pos.size and np.array_equal(pos[:single], want_pos)
+    finally:
+        h.destroy()

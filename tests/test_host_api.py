@@ -84,6 +84,20 @@ def test_null_handle_and_argument_checks(workloads, tmp_path):
     assert h.matchFromDevice(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.LIB_NOT_EXIST
     h.setPlatform(api.PFAC_PLATFORM_GPU)
     assert h.matchFromHost(buf.ctypes.data, 4, buf.ctypes.data, check=False) == api.STATUS.LIB_NOT_EXIST
+    # pfac_ext.h: the walker choice and the multi-GPU calls check like the rest (no device here: LIB_NOT_EXIST behind the argument checks)
+    assert lib.PFACX_setWalker(null, api.PFACX_WALKER_AUTO) == api.STATUS.INVALID_HANDLE
+    assert h.setWalker(5, check=False) == api.STATUS.INVALID_PARAMETER
+    for w in (api.PFACX_WALKER_WINDOW, api.PFACX_WALKER_STAGE, api.PFACX_WALKER_AUTO):
+        assert h.setWalker(w, check=False) == api.STATUS.SUCCESS
+    cnt = ctypes.c_int(-1)
+    assert lib.PFACX_matchFromHostReduceMultiGPU(null, 1, 1, 1, 1, ctypes.byref(cnt), 0, None) == api.STATUS.INVALID_HANDLE
+    st, count = h.matchFromHostReduceMultiGPU(0, 4, buf.ctypes.data, buf.ctypes.data, check=False)
+    assert st == api.STATUS.INVALID_PARAMETER
+    st, count = h.matchFromHostReduceMultiGPU(buf.ctypes.data, 0, buf.ctypes.data, buf.ctypes.data, check=False)
+    assert st == api.STATUS.SUCCESS and count == 0
+    st, count = h.matchFromHostReduceMultiGPU(buf.ctypes.data, 4, buf.ctypes.data, buf.ctypes.data, [0], check=False)
+    assert st == api.STATUS.LIB_NOT_EXIST
+    assert h.matchFromHostMultiGPU(buf.ctypes.data, 4, buf.ctypes.data, [0], check=False) == api.STATUS.LIB_NOT_EXIST
     assert h.destroy() == api.STATUS.SUCCESS
 
 

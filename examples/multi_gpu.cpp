@@ -60,6 +60,16 @@ int main(int argc, char **argv)
     }
     std::printf("%zu bytes, %d worker(s) on %d device(s): %zu matches, %zu differences between the sharded and the single scan\n",
                 n, workers, visible, matches, differ);
+
+    /* the compacted-output form: only the (id, position) pairs of the matches come back, in position order (one byte per position
+     * over a host link, nothing filled on the host: what scales with the number of links) */
+    std::vector<int> ids(n), pos(n);
+    int pairs = 0;
+    CHECK(PFACX_matchFromHostReduceMultiGPU(handle, input.data(), n, ids.data(), pos.data(), &pairs, workers, devices.data()));
+    size_t wrong = (size_t)pairs != matches;
+    for (int k = 0; k < pairs && !wrong; k++)
+        wrong += pos[k] < 0 || (size_t)pos[k] >= n || single[pos[k]] != ids[k] || (k && pos[k] <= pos[k - 1]);
+    std::printf("compacted output over the same workers: %d pairs, %s\n", pairs, wrong ? "DIFFERENT from the full result" : "equal to the non-zero entries of the full result");
     CHECK(PFAC_destroy(handle));
-    return differ ? 1 : 0;
+    return differ || wrong ? 1 : 0;
 }

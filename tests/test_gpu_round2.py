@@ -435,6 +435,7 @@ def test_cpp_multi_gpu_example(workdir):
     out = subprocess.run([os.path.join(ROOT, "examples", "multi_gpu"), pf, inp, "3"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 differences" in out.stdout and "3 worker(s)" in out.stdout
+    assert "equal to the non-zero entries of the full result" in out.stdout, out.stdout          # PFACX_matchFromHostReduceMultiGPU
 
 
 def test_duplicate_patterns_on_the_gpu(tmp_path):

@@ -28,7 +28,8 @@ for w in c3 c5; do
 done
 timeout 400 tools/pmc_traffic.sh c5 $O/traffic_c5 > $O/traffic_c5.log 2>&1
 for w in c3 c2 c5; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o prof -- python3 bench.py --worker rank --workload $w --no-other-configs > $O/bench_${w}_under_rocprof.json 2> $O/prof_$w.err
+  # 500 timed launches: the ~35 launches in front of them (first launch, settling, warm-up) run at rising clocks, up to 25 % slower, and are in the profiler's average too
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o prof -- python3 bench.py --worker rank --workload $w --no-other-configs --steps 500 > $O/bench_${w}_under_rocprof.json 2> $O/prof_$w.err
   timeout 400 tools/pmc_traffic.sh $w $O/traffic_$w > $O/traffic_$w.log 2>&1
 done
 grep -h '"metric"' $O/bench_*.json | python3 -c "

@@ -728,6 +728,9 @@ void pfac_scan_filter(ScanArgs a)
                     stageFree = (int)(qe - qh) <= 0 && __ballot(reads) == 0;
                 }
             }
+#ifdef PFAC_COUNT_STALLS                       /* measurement build: the level-1 statistic counts the trips that could not stage the next chunk (its buffer still read) */
+            if (chunk != kEnd && !stageFree) stHits++;
+#endif
             if (chunk == kEnd) {
                 if (qh == qv && !anyAlive()) break;      /* nothing staged, queued or walking */
             } else if (stageFree) {
@@ -869,7 +872,9 @@ void pfac_scan_filter(ScanArgs a)
             }
             PFAC_TICK(10);
             const uint32_t listed = dense ? 0u : (total < kListCap ? total : kListCap);
+#ifndef PFAC_COUNT_STALLS
             stHits += listed;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             PFAC_TICK(4);

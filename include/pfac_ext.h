@@ -84,6 +84,8 @@ typedef struct {
                                  writes; nothing is waited for): 1 = full of near misses of long patterns -> PFACX_WALKER_AUTO picks STAGE ... */
     int streamDense;           /* ... 1 = most of it pattern-dense (short patterns over text, runs of a pattern byte) -> PFACX_KERNEL_AUTO
                                  sends the next big call to the tiled kernel alone */
+    int filterLadderLast;      /* deepest level of the prefix ladder: 20, or 60 when the nodes behind the 20th byte fit its bitmap too */
+    size_t filterTailEntries;  /* entries of the tail table (PFACX_TABLE_FILTER_TAIL) */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -101,6 +103,8 @@ typedef enum {
     PFACX_TABLE_FILTER_FINAL3 = 7, /* uint32[2^filterLog2BitsFinal3 / 32]           */
     PFACX_TABLE_FILTER_GRAM1 = 9,  /* uint32[2^19 / 32]: one-bit 3-gram bitmap of the compacted-output kernel       */
     PFACX_TABLE_FILTER_PREFIX4 = 10, /* uint32[2^17 / 32]: the 4-byte pattern prefixes, two probes (same kernel)    */
+    PFACX_TABLE_FILTER_TAIL  = 11, /* uint32[3] per slot {ladder hash of a stop node, that hash rolled over the rest of the one pattern below it,
+                                      bytes of that rest | depth << 8}, a power of two of slots (none: empty): the veto on a ladder stop */
     PFACX_TABLE_CHAIN        = 8   /* uint32[4] per 16-byte unit: the device-only chained form of the hashed table that the
                                       GPU kernels walk in both perf modes.  chainSlots / 2 slot headers -- compact buckets,
                                       breadth first; then the 256 slots of the initial state; then the 2^chainJumpLog2

@@ -30,7 +30,7 @@ PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
-PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4 = 9, 10
+PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4, PFACX_TABLE_FILTER_TAIL = 9, 10, 11
 
 
 class STATUS:
@@ -67,7 +67,7 @@ class PFACX_info(C.Structure):
         ("chainJumpLog2", C.c_int), ("chainSlots", C.c_size_t),
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
         ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
-        ("streamNearMisses", C.c_int), ("streamDense", C.c_int),
+        ("streamNearMisses", C.c_int), ("streamDense", C.c_int), ("filterLadderLast", C.c_int), ("filterTailEntries", C.c_size_t),
     ]
 
 

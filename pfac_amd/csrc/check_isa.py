@@ -17,7 +17,7 @@ import re
 import sys
 
 RESERVED = {f"v{i}" for i in range(119, 128)}
-INSTANCES = 12                                          # TEX x HAS_SHORT x {compacted output, full result with the window walker, ... with the stage walker}
+INSTANCES = 16                                          # TEX x HAS_SHORT x {compacted output, full result with the window walker, ... with the stage walker, ... window walker + veto}
 
 
 class ContractError(Exception):

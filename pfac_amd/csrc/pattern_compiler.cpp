@@ -250,6 +250,7 @@ struct LadderWalk {
     const std::vector<uint32_t> &below;        /* patterns in the subtree of each state (itself included) */
     uint32_t thin;
     int extend = 0;                            /* thin nodes go on for this many more levels before they stop */
+    int last = kLadderLast;                    /* deepest level: its nodes are all stops */
     template <class Visit> void run(Visit &&visit) const
     {
         struct Item { int state; int depth; uint32_t acc; int ext; };   /* acc: bytes so far (depth < 4: the bytes; depth >= 4: rolling hash) */
@@ -267,11 +268,11 @@ struct LadderWalk {
                 continue;
             }
             /* a ladder node */
-            bool endsSoon = it.state <= F || it.depth >= kLadderLast;
+            bool endsSoon = it.state <= F || it.depth >= last;
             for (int e = fa.edgeBegin[it.state]; e < fa.edgeBegin[it.state + 1] && !endsSoon; e++) endsSoon = fa.edgeNext[e] <= F;
             const bool isThin = below[it.state] <= thin;
             const bool stop = endsSoon || (isThin && it.ext == 0);
-            visit(it.acc, it.depth, stop);
+            visit(it.acc, it.depth, stop, it.state, stop && !endsSoon);
             if (stop) continue;
             for (int e1 = fa.edgeBegin[it.state]; e1 < fa.edgeBegin[it.state + 1]; e1++) {
                 const int s1 = fa.edgeNext[e1];
@@ -347,18 +348,27 @@ void buildFilter(const Automaton &fa, Filter &f)
     const int ladCap = f.log2BitsLad;
     const size_t dens = 5;
     size_t stops = 0, goOns = 0;
-    auto count = [&](uint32_t thin, int ext) {
+    auto count = [&](uint32_t thin, int ext, int last) {
         stops = goOns = 0;
-        LadderWalk{fa, below, thin, ext}.run([&](uint32_t, int, bool stop) { (stop ? stops : goOns)++; });
+        LadderWalk{fa, below, thin, ext, last}.run([&](uint32_t, int, bool stop, int, bool) { (stop ? stops : goOns)++; });
         return dens * (2 * stops + goOns) <= (size_t(1) << ladCap);
     };
+    /* First choice: the ladder goes on behind kLadderLast wherever several patterns still share a path (thin nodes stop as before); that is
+     * few nodes for most sets -- paths are alone long before -- and what a set with a long shared prefix needs (BASELINE config 5: 24 bytes). */
     f.ladderThin = 1;
     f.ladderExtend = 1;
-    if (!count(1, f.ladderExtend)) {
+    f.ladderLast = kLadderDeepLast;
+#ifdef PFAC_NO_DEEP_LADDER
+    const bool deep = false;
+#else
+    const bool deep = count(1, f.ladderExtend, f.ladderLast);
+#endif
+    if (!deep) f.ladderLast = kLadderLast;
+    if (!deep && !count(1, f.ladderExtend, f.ladderLast)) {
         f.ladderExtend = 0;
         for (uint32_t thin = 1;; thin *= 2) {
             f.ladderThin = (int)thin;
-            if (count(thin, 0) || thin >= (1u << 30)) break;
+            if (count(thin, 0, f.ladderLast) || thin >= (1u << 30)) break;
         }
     }
     f.log2BitsLad = 13;
@@ -396,7 +406,10 @@ void buildFilter(const Automaton &fa, Filter &f)
             }
         }
     }
-    LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend}.run([&](uint32_t h, int depth, bool stop) {
+    struct ThinStop { uint32_t h; int depth; int state; };
+    std::vector<ThinStop> thinStops;
+    std::vector<uint32_t> allHashes;
+    LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast}.run([&](uint32_t h, int depth, bool stop, int state, bool thinStop) {
         if (stop) {
             setBit(f.ladder, ladderBitS1(h, f.log2BitsLad));
             setBit(f.ladder, ladderBitS2(h, f.log2BitsLad));
@@ -404,7 +417,47 @@ void buildFilter(const Automaton &fa, Filter &f)
             setBit(f.ladder, ladderBitG(h, f.log2BitsLad));
             if (depth == kLadderFirst) setBit(f.ladder, ladderBitG2(h, f.log2BitsLad));
         }
+        allHashes.push_back(h);
+        if (thinStop && below[(size_t)state] == 1) thinStops.push_back({h, depth, state});
     });
+    /* the tail table (struct Filter): the rest of the one pattern below a thin stop */
+    f.tail.clear();
+    f.log2Tail = 0;
+    f.tailEntries = 0;
+#ifndef PFAC_NO_TAIL_TABLE
+    {
+        std::sort(allHashes.begin(), allHashes.end());
+        auto shared = [&](uint32_t h) { auto r = std::equal_range(allHashes.begin(), allHashes.end(), h); return r.second - r.first > 1; };
+        struct Entry { uint32_t tag, hash, info; };
+        std::vector<Entry> entries;
+        for (const ThinStop &t : thinStops) {
+            if (shared(t.h)) continue;
+            unsigned char rest[256];
+            int r = 0, s2 = t.state;
+            while (s2 > F && r < 255 && fa.edgeBegin[s2 + 1] - fa.edgeBegin[s2] == 1) { rest[r++] = (unsigned char)fa.edgeCh[fa.edgeBegin[s2]]; s2 = fa.edgeNext[fa.edgeBegin[s2]]; }
+            if (s2 > F || fa.edgeBegin[s2 + 1] != fa.edgeBegin[s2]) continue;      /* not a single path to ONE final state without successors: leave it to the walk */
+            const int all = r & ~1;
+            if (all < kTailMinBytes || t.depth + all > 0xFFFF) continue;
+            const int bytes = all < kTailMaxBytes ? all : kTailMaxBytes, skip = all - bytes;
+            uint32_t h = t.h;
+            for (int i = skip; i < all; i += 2) h = ladderRoll(h, (uint32_t)rest[i] | ((uint32_t)rest[i + 1] << 8));
+            entries.push_back({t.h, h, (uint32_t)bytes | ((uint32_t)(t.depth + skip) << 8)});
+        }
+        if (!entries.empty()) {
+            int lg = 8;
+            while (lg < kTailLog2Max && (size_t(1) << lg) < 2 * entries.size()) lg++;
+            f.log2Tail = lg;
+            f.tail.assign((size_t(3) << lg), 0u);                 /* info 0 = no entry */
+            for (const Entry &e : entries) {
+                size_t at = (size_t)tailSlot(e.tag, lg) * 3;
+                if (f.tail[at + 2] != 0) at = (size_t)tailSlot2(e.tag, lg) * 3;
+                if (f.tail[at + 2] != 0) continue;
+                f.tail[at] = e.tag; f.tail[at + 1] = e.hash; f.tail[at + 2] = e.info;
+                f.tailEntries++;
+            }
+        }
+    }
+#endif
     /* Level 1 tests ONE bitmap per position: a pattern of one or two bytes matches whatever follows it, so all
      * 256 (or 65536) 3-grams that begin with it pass.  (The 2-byte bitmap is still tested at level 2, which
      * sorts out the positions this lets through.) */

@@ -82,6 +82,7 @@ void freeResources(PFAC_context *c)
     devFree(c->d_ladder);
     devFree(c->d_gram1);
     devFree(c->d_prefix4);
+    devFree(c->d_tail);
     devFree(c->d_workCounters);
     if (c->h_modeHint) { (void)hipHostFree(c->h_modeHint); c->h_modeHint = c->d_modeHint = nullptr; }
     devFree(c->d_reduceScratch);
@@ -187,6 +188,7 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_final3, c->filter.final3.data(), c->filter.final3.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram1, c->filter.gram1.data(), c->filter.gram1.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_prefix4, c->filter.prefix4.data(), c->filter.prefix4.size());
+    if (st == PFAC_STATUS_SUCCESS && !c->filter.tail.empty()) st = upload(c->d_tail, c->filter.tail.data(), c->filter.tail.size());
     if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
         const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
         st = upload(c->d_workCounters, zeros.data(), zeros.size());
@@ -548,6 +550,8 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         v.ladderGoOns = handle->filter.ladderGoOns;
         v.ladderThin = handle->filter.ladderThin;
         v.ladderExtend = handle->filter.ladderExtend;
+        v.filterLadderLast = handle->filter.ladderLast;
+        v.filterTailEntries = handle->filter.tailEntries;
         v.trailingBytesIgnored = handle->fa.trailingBytes;
         v.chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
         v.chainSlots = handle->h_chainSlots.size();
@@ -566,6 +570,7 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         if (handle->d_shortBits) dev += handle->filter.shortBits.size() * sizeof(uint32_t);
         if (handle->d_gram1) dev += handle->filter.gram1.size() * sizeof(uint32_t);
         if (handle->d_prefix4) dev += handle->filter.prefix4.size() * sizeof(uint32_t);
+        if (handle->d_tail) dev += handle->filter.tail.size() * sizeof(uint32_t);
         if (handle->d_workCounters) dev += pfac::kWorkCounterWords * sizeof(unsigned int);
         v.deviceTableBytes = dev;
         /* ... and what its calls have left allocated (grow-only, PFACX_trim gives it back): the two staging pieces of the host
@@ -616,6 +621,8 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.gram1.data(); *bytes = handle->filter.gram1.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_PREFIX4:
         *ptr = handle->filter.prefix4.data(); *bytes = handle->filter.prefix4.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_TAIL:
+        *ptr = handle->filter.tail.data(); *bytes = handle->filter.tail.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
         if (handle->h_chainSlots.empty()) {
             const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */

@@ -133,6 +133,17 @@ struct Filter {
     size_t bitsSetLad = 0;                    /* population of the ladder bitmap */
     size_t ladderStops = 0, ladderGoOns = 0;  /* S and G nodes inserted */
     int ladderThin = 1;                       /* nodes with at most this many patterns below them are S (raised until the bitmap is sparse enough) */
+    int ladderLast = 20;                      /* deepest level of the ladder: kLadderLast, or kLadderDeepLast when the nodes behind kLadderLast fit the bitmap too (few do: most
+                                                 paths are alone by then; BASELINE config 5's 24-byte shared prefix is what needs them) */
+    /* The tail table (round 5; the veto of the VETO kernels on a ladder stop): a stop node below which ONE pattern is left knows the rest of
+     * that pattern.  Entry {tag = the node's ladder hash, hash = the tag rolled on over `bytes` bytes of the rest of the pattern (even, at most kTailMaxBytes: the
+     * last ones up to its end or the byte before), bytes | depth of the first of them << 8} in slot tailSlot(tag) or tailSlot2(tag); a candidate that stops at such a node rolls
+     * its own hash over as many of its bytes and is walked only if the two agree -- a near miss of a long pattern costs a few multiplications
+     * instead of a walk through the table.  Only nodes whose hash no other ladder node shares have an entry (a shared hash could veto another
+     * pattern's candidate); an entry that finds both its slots taken is left out; no entry = walk, as before. */
+    std::vector<uint32_t> tail;               /* 3 words per slot, 2^log2Tail slots; empty: none */
+    int log2Tail = 0;
+    size_t tailEntries = 0;
     int ladderExtend = 0;                     /* ... after this many more levels (0: at once): the deeper test spares the walk of a candidate that
                                                  shares a pattern's prefix up to the thin node and no further */
     std::vector<uint32_t> gram3;              /* 2^log2Bits bits, key c0|c1<<8|c2<<16            */
@@ -152,6 +163,14 @@ constexpr int kGram1Log2 = 19, kPrefix4Log2 = 17;
  * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
  * bit), of h * kLadMulG (G) and, at depth 4 only, of h * kLadMulG2 (G, second bit).  scan_*.hip evaluates exactly this. */
 constexpr int kLadderFirst = 4, kLadderStep = 2, kLadderLast = 20;
+constexpr int kLadderDeepLast = 60;            /* a DEEP ladder (Filter::ladderLast) goes on in steps of two down to here: the levels behind kLadderLast are tested by a rolled loop of the
+                                                 VETO kernels only; every other kernel walks what is undecided at kLadderLast */
+constexpr uint32_t kTailMul = 0x9E3779B1u, kTailMul2 = 0x85EBCA77u;      /* the two slots of a tail entry: (tag * mul) >> (32 - log2Tail) */
+constexpr int kTailLog2Max = 12, kTailMinBytes = 6;          /* at most 4096 slots of 12 bytes (LDS); shorter rests are not worth an entry */
+constexpr int kTailMaxBytes = 32;                            /* ... and of a longer rest the LAST 32 bytes are compared (any bytes may be: the veto only has to hold for every match;
+                                                                near misses differ near the end): the kernel reads them in one go */
+inline uint32_t tailSlot(uint32_t tag, int log2Slots) { return (uint32_t)(tag * kTailMul) >> (32 - log2Slots); }
+inline uint32_t tailSlot2(uint32_t tag, int log2Slots) { return (uint32_t)(tag * kTailMul2) >> (32 - log2Slots); }
 constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
 constexpr uint32_t kLadMul0 = 0x9E3779B1u, kLadMul = 0x85EBCA77u, kLadMulS = 0xC2B2AE3Du, kLadMulG = 0x27D4EB2Fu, kLadMulG2 = 0x165667B1u;
 inline uint32_t ladderStart(uint32_t first4) { return first4 * kLadMul0; }
@@ -219,6 +238,7 @@ struct PFAC_context {
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_ladder = nullptr;
     uint32_t *d_gram1 = nullptr, *d_prefix4 = nullptr;   /* the compacted-output kernel's level 1 and depth-4 test (struct Filter) */
+    uint32_t *d_tail = nullptr;                          /* the tail table (struct Filter), or null */
     /* grow-only scratch of the compacted-output path (the arrays the pairs are ordered through), owned by the handle so that a
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;

@@ -50,10 +50,13 @@ struct ScanArgs {
     const int *initialRow;
     const uint32_t *gram3;
     const uint32_t *gram1, *prefix4;                   /* compacted-output kernel: its level 1 and depth-4 test */
+    const uint32_t *tail;                              /* the tail table (pfac::Filter), 3 words per slot, or null */
+    int log2Tail;
     const uint32_t *ladder;
     const uint32_t *final3;
     const uint32_t *shortBits;
     int log2Bits, log2BitsLad, log2BitsF3;
+    int ladderLast;                                    /* deepest level of the prefix ladder (pfac::Filter::ladderLast): behind kLadderLast only the VETO kernels look */
     int numFinal;
     int initialState;
     unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
@@ -300,10 +303,10 @@ __device__ __forceinline__ bool extensionEqual(const u32x4 &e, uint32_t y0, uint
     return (m01 < m23 ? m01 : m23) >= 8u * (len - 8u);
 }
 
-template <bool TEX, uint32_t ENTRY> struct ChainLane {
+template <bool TEX, uint32_t ENTRY, bool SPEC = false> struct ChainLane {
     using Ctx = ChainCtx<TEX>;
     static constexpr bool kDeep = ENTRY > kEntryBytes;          /* 36-byte entries: the window is nine dwords, re-fetched 32 bytes at a time */
-    static constexpr bool kSpec = kDeep && PFAC_WIDE_SPEC != 0; /* wide buckets: header and extension unit are fetched together, the unit compared out of the window */
+    static constexpr bool kSpec = kDeep && (SPEC || PFAC_WIDE_SPEC != 0); /* wide buckets: header and extension unit are fetched together, the unit compared out of the window */
     uint32_t pos = 0;
     uint32_t row = 0;                          /* first slot of the current state's bucket */
     int match = 0;

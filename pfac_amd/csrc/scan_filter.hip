@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t waveMin(uint32_t v)
 constexpr int kCompilerVgprs = PFAC_COMPILER_VGPRS;
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 64 readable input bytes follow it */
-template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets, bool STAGE>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets, bool STAGE, bool VETO = false>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(kCompilerVgprs)))
 void pfac_scan_filter(ScanArgs a)
 {
@@ -134,7 +134,12 @@ void pfac_scan_filter(ScanArgs a)
     /* full-result kernel: walks read their input from the wave's two staged chunks (StageLane), a queue entry is {buffer, offset};
      * compacted-output kernel (16 scanning waves, no LDS to spare): the input travels with the entry and lives in registers */
     constexpr bool kStageWalk = !REDUCE && STAGE;
-    using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry>>;
+    /* VETO: the register-window walker behind a deeper prefilter -- ladder levels behind the 20th byte and the tail table (pfac::Filter): what a pattern
+     * set of a few thousand patterns gets (its tables leave the LDS for it); a stop of the ladder is put to the table before it becomes a walk.  Its
+     * walker fetches the extension unit of a wide bucket's slot with the header once its wave has met long slots (what is left to walk are patterns
+     * that end within a byte of where the candidate left them: long slots all the way) */
+    constexpr bool kVeto = !REDUCE && !STAGE && VETO;
+    using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry, kVeto>>;
     constexpr int kStageWordsK = kStageWalk ? (int)(kWalkStageBytes / 4) : kStageWords;     /* words of one stage buffer */
     constexpr int kStageBufs = kStageWalk ? 2 : 1;
     constexpr int kHaloDwords = kStageWalk ? (int)(kWalkHalo / 4) : 12;                      /* dwords behind the chunk that are staged with it */
@@ -176,6 +181,7 @@ void pfac_scan_filter(ScanArgs a)
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if constexpr (kStageWalk) copy16(sHotAll, a.chainSlots, (int)a.hotSlots * 4);
+        if constexpr (kVeto) { if (a.tail != nullptr) copy16(sHotAll, a.tail, 3 << a.log2Tail); }      /* the tail table: behind everything else */
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
@@ -945,6 +951,9 @@ void pfac_scan_filter(ScanArgs a)
              * of their undecided candidates walks the next 28 batches' candidates untested, then looks again. */
             const uint32_t und0 = (uint32_t)__popcll(__ballot(und != 0));
             const bool skipLadder = !REDUCE && ladderSkip != 0;
+            const bool deepLadder = a.ladderLast > pfac::kLadderLast;       /* wave-uniform (a kernel argument) */
+            uint32_t stopHash = 0;                                          /* kVeto: the ladder hash of the level that told this candidate to stop */
+            (void)stopHash;
             if (skipLadder) { ladderSkip--; walk |= und; und = 0; }
             if (!REDUCE && __ballot(und != 0) != 0) {
                 uint32_t hl[pfac::kLadderLevels];
@@ -961,9 +970,77 @@ void pfac_scan_filter(ScanArgs a)
                     if (lv == 5 && __ballot(und != 0) == 0) break;
                     const uint32_t h = hl[lv];
                     const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
+                    if constexpr (kVeto) stopHash = (und & sHit) ? h : stopHash;
                     walk |= und & sHit;
-                    if (lv == pfac::kLadderLevels - 1) und = 0;      /* the last level has S nodes only */
+                    if (lv == pfac::kLadderLevels - 1 && !deepLadder) und = 0;      /* the last level has S nodes only */
                     else und &= ladProbe(h * pfac::kLadMulG) & ~sHit;
+                }
+                if constexpr (kVeto) {
+                    /* A deep ladder (pfac::Filter::ladderLast) goes on behind the 20 bytes wherever patterns still share a path: two more bytes of
+                     * the staged chunk per level, rolled (BASELINE config 5: the 24-byte prefix its patterns share). */
+                    if (deepLadder && __ballot(und != 0) != 0) {
+                        uint32_t h = hl[pfac::kLadderLevels - 1];
+                        const uint32_t staged = (uint32_t)kChunkBytes + 4u * (uint32_t)kHaloDwords;
+                        /* eight bytes (four levels) of the stage at a time, read before they are needed: a level is then one LDS round trip (its probes) */
+                        for (uint32_t dd = (uint32_t)pfac::kLadderLast; dd < (uint32_t)a.ladderLast && __ballot(und != 0) != 0; dd += 8u) {
+                            const bool any = und != 0u && o + dd + 12u <= staged;          /* staged? (else: undecided -> walk) */
+                            walk |= any ? 0u : und;
+                            und = any ? und : 0u;
+                            const uint32_t b = any ? o + dd : 0u;
+                            const uint32_t w0 = stage[b >> 2], w1 = stage[(b >> 2) + 1u], w2 = stage[(b >> 2) + 2u];
+                            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, b & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, b & 3u);
+                            uint32_t hk[4], s1[4], s2[4], g1[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const uint32_t piece = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0xFFFFu;
+                                h = (h ^ piece) * pfac::kLadMul;
+                                hk[k] = h;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) { s1[k] = ladProbe(hk[k]); s2[k] = ladProbe(hk[k] * pfac::kLadMulS); g1[k] = ladProbe(hk[k] * pfac::kLadMulG); }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const bool lvl = dd + 2u * (uint32_t)k < (uint32_t)a.ladderLast;        /* wave-uniform */
+                                const uint32_t sHit = s1[k] & s2[k];
+                                stopHash = (lvl && (und & sHit & 1u)) ? hk[k] : stopHash;
+                                walk |= lvl ? (und & sHit) : 0u;
+                                und = lvl ? (und & g1[k] & ~sHit) : und;
+                            }
+                        }
+                    }
+                }
+                walk |= und;                                    /* deep ladder: undecided behind the last level looked at (kernels without VETO: kLadderLast) */
+                if constexpr (kVeto) {
+                    /* The tail table (pfac::Filter): a stop node below which one pattern is left knows the hash of the rest of that pattern.  A
+                     * candidate that was told to stop there rolls its own hash over as many of its bytes and walks only if the two agree. */
+                    const bool ask = a.tail != nullptr && stopHash != 0u && (walk & 1u) != 0u;
+                    if (__ballot(ask) != 0) {
+                        const uint32_t *sTail = sHotAll;
+                        const uint32_t tshift = 32u - (uint32_t)a.log2Tail;
+                        const uint32_t s1 = ((uint32_t)(stopHash * pfac::kTailMul) >> tshift) * 3u, s2 = ((uint32_t)(stopHash * pfac::kTailMul2) >> tshift) * 3u;
+                        const uint32_t t1 = sTail[s1], h1 = sTail[s1 + 1], i1 = sTail[s1 + 2], t2 = sTail[s2], h2 = sTail[s2 + 1], i2 = sTail[s2 + 2];
+                        const bool m1 = i1 != 0u && t1 == stopHash, m2 = i2 != 0u && t2 == stopHash;
+                        const uint32_t want = m1 ? h1 : h2, info = m1 ? i1 : (m2 ? i2 : 0u);
+                        const uint32_t nb = info & 0xFFu, from = o + (info >> 8);
+                        const bool chk = ask && info != 0u && from + nb + 4u <= (uint32_t)kChunkBytes + 4u * (uint32_t)kHaloDwords;   /* the bytes must be staged */
+                        uint32_t run = stopHash;
+                        {   /* at most kTailMaxBytes bytes: nine dwords of the stage in one go, then sixteen steps of the hash in registers */
+                            static_assert(pfac::kTailMaxBytes == 32, "nine dwords");
+                            const uint32_t b = chk ? from : 0u, at4 = b >> 2, shb = b & 3u;
+                            uint32_t w[9];
+#pragma unroll
+                            for (int k = 0; k < 9; k++) w[k] = stage[at4 + (uint32_t)k];
+#pragma unroll
+                            for (int k = 0; k < 8; k++) {
+                                const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], shb);
+                                const uint32_t r1 = (run ^ (x & 0xFFFFu)) * pfac::kLadMul;
+                                run = (chk && 4u * (uint32_t)k < nb) ? r1 : run;
+                                const uint32_t r2 = (run ^ (x >> 16)) * pfac::kLadMul;
+                                run = (chk && 4u * (uint32_t)k + 2u < nb) ? r2 : run;
+                            }
+                        }
+                        if (chk && run != want) walk = 0u;
+                    }
                 }
             }
             if (REDUCE) walk |= und;                                /* undecided after the last level tested: walk */
@@ -1095,12 +1172,20 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce, bool stage)
     return bytes;
 }
 
-template <bool TEX, bool HAS_SHORT, bool REDUCE, bool STAGE>
+/* LDS of the tail table behind the buffers of a window-walker launch, or 0: none, or no room */
+size_t vetoLdsBytes(const PFAC_context *c, const ScanArgs &a)
+{
+    if (a.tail == nullptr || a.log2Tail < 2) return 0;
+    const size_t bytes = size_t(12) << a.log2Tail;
+    return filterLdsBytes(c, false, false) + bytes <= kLdsPerCu ? bytes : 0;
+}
+
+template <bool TEX, bool HAS_SHORT, bool REDUCE, bool STAGE, bool VETO = false>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a0)
 {
-    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL, STAGE>;
+    auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL, STAGE, VETO>;
     static ShapeCache cache;
-    size_t lds = filterLdsBytes(c, REDUCE, STAGE);
+    size_t lds = filterLdsBytes(c, REDUCE, STAGE) + (VETO ? vetoLdsBytes(c, a0) : 0);
     int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
     hipError_t de = hipGetDevice(&dev);
     if (de != hipSuccess) return de;
@@ -1186,16 +1271,27 @@ hipError_t launchChained(const PFAC_context *c, const ScanArgs &a, bool tex)
      * misses all over (most of its scanning waves ended it in stage mode / expecting long slots) -> StageLane, text -> the
      * register-window walker.  The word is host memory the last block of a launch writes: nothing is waited for, a launch
      * still under way simply has not voted yet */
-    bool stage = false;
+    bool stage = false, veto = false;
     if (!REDUCE) {
+        /* a pattern set with a tail table (a few thousand patterns: its tables leave the LDS for it) puts the ladder's stops to the table
+         * before they become walks: near misses hardly reach a walker then, and the register-window walker is the one for few walks */
+#ifndef PFAC_VETO
+#define PFAC_VETO 1
+#endif
+        veto = PFAC_VETO && c->walker != PFACX_WALKER_STAGE && vetoLdsBytes(c, a) != 0;
         stage = c->walker == PFACX_WALKER_STAGE ||
-                (c->walker == PFACX_WALKER_AUTO && c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0);
+                (!veto && c->walker == PFACX_WALKER_AUTO && c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0);
     }
 #ifdef PFAC_QUICK      /* development builds (register / ISA inspection): the bench instances only */
     if (REDUCE || !tex) return hipErrorNotSupported;
     if (stage) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);
+    if (veto) return c->filter.hasShort ? launchFilter<true, true, false, false, true>(c, a) : launchFilter<true, false, false, false, true>(c, a);
     return c->filter.hasShort ? launchFilter<true, true, false, false>(c, a) : launchFilter<true, false, false, false>(c, a);
 #else
+    if (!REDUCE && veto) {
+        if (tex) return c->filter.hasShort ? launchFilter<true, true, false, false, true>(c, a) : launchFilter<true, false, false, false, true>(c, a);
+        return c->filter.hasShort ? launchFilter<false, true, false, false, true>(c, a) : launchFilter<false, false, false, false, true>(c, a);
+    }
     if (!REDUCE && stage) {
         if (tex) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);
         return c->filter.hasShort ? launchFilter<false, true, false, true>(c, a) : launchFilter<false, false, false, true>(c, a);

@@ -138,11 +138,14 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.gram3 = c->d_gram3;
     a.gram1 = c->d_gram1;
     a.prefix4 = c->d_prefix4;
+    a.tail = c->filter.tail.empty() ? nullptr : c->d_tail;
+    a.log2Tail = c->filter.log2Tail;
     a.shortBits = c->d_shortBits;
     a.ladder = c->d_ladder;
     a.final3 = c->d_final3;
     a.log2Bits = c->filter.log2Bits;
     a.log2BitsLad = c->filter.log2BitsLad;
+    a.ladderLast = c->filter.ladderLast;
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.maxWalk = (uint32_t)c->fa.maxPatternLen;

@@ -7,18 +7,22 @@ from pfac_amd import api
 
 GRAM3_MUL, FINAL3_MUL, FINAL3_MUL2 = 0x8B92C5, 0x85EBCB, 0xB5297B
 LAD_MUL0, LAD_MUL, LAD_MULS, LAD_MULG, LAD_MULG2 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F, 0x165667B1
-LADDER_LAST = 20
+TAIL_MUL, TAIL_MUL2 = 0x9E3779B1, 0x85EBCA77
+LADDER_LAST = 20                   # kLadderLast: the levels every kernel tests; a DEEP ladder (info.filterLadderLast = 60) goes on behind it
 
 
-def prefilter_model(h, data):
-    """(level-1 hits, ladder candidates, positions that are walked): boolean arrays over the positions of `data`."""
+def prefilter_model(h, data, veto=True):
+    """(level-1 hits, ladder candidates, positions that are walked): boolean arrays over the positions of `data`.
+    veto: as the VETO kernels do it -- the levels behind LADDER_LAST of a deep ladder are tested too and a stop is put to the tail
+    table; without: whatever is undecided at LADDER_LAST is walked (every other kernel)."""
     info = h.info()
+    last = max(LADDER_LAST, int(getattr(info, "filterLadderLast", LADDER_LAST) or LADDER_LAST))
     g3, lad = h.table(api.PFACX_TABLE_FILTER_GRAM3), h.table(api.PFACX_TABLE_FILTER_LADDER)
     f3, sb = h.table(api.PFACX_TABLE_FILTER_FINAL3), h.table(api.PFACX_TABLE_FILTER_SHORT)
     u = np.uint64
     m32 = u(0xFFFFFFFF)
     n = data.size
-    d = np.concatenate([data, np.zeros(24, dtype=np.uint8)]).astype(np.uint64)
+    d = np.concatenate([data, np.zeros(320, dtype=np.uint8)]).astype(np.uint64)
     x = d[:n] | (d[1:n + 1] << u(8)) | (d[2:n + 2] << u(16)) | (d[3:n + 3] << u(24))
 
     def bit(bitmap, hv):
@@ -46,12 +50,42 @@ def prefilter_model(h, data):
     walk = level1 & (bypass | s)
     cand = level1 & (bypass | s | g)
     und = cand & ~walk
-    for depth in range(6, LADDER_LAST + 2, 2):
+    stop_hash = np.zeros(n, dtype=np.uint64)          # the ladder hash of the level (>= 6) at which a position was told to stop
+    stopped = np.zeros(n, dtype=bool)
+    for depth in range(6, (last if veto else LADDER_LAST) + 2, 2):
         piece = d[depth - 2:n + depth - 2] | (d[depth - 1:n + depth - 1] << u(8))
         hh = ((hh ^ piece) * u(LAD_MUL)) & m32
         s = stop(hh)
-        walk |= und & s
-        und = und & go_on(hh) & ~s if depth < LADDER_LAST else und & False
+        first = und & s
+        stop_hash[first] = hh[first]
+        stopped |= first
+        walk |= first
+        if depth < last:
+            und = und & go_on(hh) & ~s
+        else:
+            und = und & False              # the ladder's last level has stops only
+    walk |= und                            # a deep ladder looked at down to LADDER_LAST only: what is undecided there walks
+    # the tail table: a stop whose node knows the rest of its one pattern is walked only if the candidate's bytes hash like that rest
+    tail = h.table(api.PFACX_TABLE_FILTER_TAIL) if veto else np.zeros(0, dtype=np.uint32)
+    if tail.size:
+        lg = int(np.log2(tail.size // 3))
+        t = tail.reshape(-1, 3).astype(np.uint64)
+        at = np.flatnonzero(stopped)
+        hs = stop_hash[at]
+        slot = (((hs * u(TAIL_MUL)) & m32) >> u(32 - lg)).astype(np.int64)
+        slot2 = (((hs * u(TAIL_MUL2)) & m32) >> u(32 - lg)).astype(np.int64)
+        in_first = (t[slot, 2] != 0) & (t[slot, 0] == hs)
+        slot = np.where(in_first, slot, slot2)
+        tag, want, inf = t[slot, 0], t[slot, 1], t[slot, 2]
+        has = (inf != 0) & (tag == hs)
+        at, hs, want, inf = at[has], hs[has], want[has], inf[has]
+        nbytes, dep = (inf & u(0xFF)).astype(np.int64), (inf >> u(8)).astype(np.int64)
+        run = hs.copy()
+        for i in range(0, int(nbytes.max()) if nbytes.size else 0, 2):
+            live = i < nbytes
+            p = (at + dep + i)[live]
+            run[live] = ((run[live] ^ (d[p] | (d[p + 1] << u(8)))) * u(LAD_MUL)) & m32
+        walk[at[run != want]] = False      # (the kernel also needs the bytes among those it has staged: it walks a few more)
     return level1, cand, walk
 
 

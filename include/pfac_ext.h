@@ -120,7 +120,11 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
  * lives in registers (fastest on text); STAGE: walks read their input in place from the chunks a wave keeps staged in LDS and
  * take 24 bytes per step through long single-successor runs (fastest when the stream is full of near misses of long
  * patterns: BASELINE config 5, 19 % over WINDOW); AUTO (default): whatever the handle's previous full-result launch found its
- * stream to be -- the first launch on a handle runs WINDOW.  Results are identical. */
+ * stream to be -- the first launch on a handle runs WINDOW.  Results are identical.
+ * A pattern set that has a TAIL TABLE (filterTailEntries of PFACX_getInfo > 0 and room in the CU's LDS: sets of a few thousand
+ * patterns) is different: the prefilter puts a ladder stop to that table before it becomes a walk, near misses hardly reach a walker,
+ * and AUTO and WINDOW both mean the window walker behind that veto (another 13 % on BASELINE config 5); STAGE is the stage walker
+ * without it. */
 #define PFACX_WALKER_AUTO   0
 #define PFACX_WALKER_WINDOW 1
 #define PFACX_WALKER_STAGE  2

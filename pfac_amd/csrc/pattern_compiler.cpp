@@ -286,7 +286,7 @@ struct LadderWalk {
 
 } // namespace
 
-void buildFilter(const Automaton &fa, Filter &f)
+static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
 {
     f = Filter();
     f.shortBits.assign(65536 / 32, 0);
@@ -361,7 +361,7 @@ void buildFilter(const Automaton &fa, Filter &f)
 #ifdef PFAC_NO_DEEP_LADDER
     const bool deep = false;
 #else
-    const bool deep = count(1, f.ladderExtend, f.ladderLast);
+    const bool deep = allowDeep && count(1, f.ladderExtend, f.ladderLast);
 #endif
     if (!deep) f.ladderLast = kLadderLast;
     if (!deep && !count(1, f.ladderExtend, f.ladderLast)) {
@@ -425,7 +425,7 @@ void buildFilter(const Automaton &fa, Filter &f)
     f.log2Tail = 0;
     f.tailEntries = 0;
 #ifndef PFAC_NO_TAIL_TABLE
-    {
+    if (allowDeep) {
         std::sort(allHashes.begin(), allHashes.end());
         auto shared = [&](uint32_t h) { auto r = std::equal_range(allHashes.begin(), allHashes.end(), h); return r.second - r.first > 1; };
         struct Entry { uint32_t tag, hash, info; };
@@ -436,9 +436,11 @@ void buildFilter(const Automaton &fa, Filter &f)
             int r = 0, s2 = t.state;
             while (s2 > F && r < 255 && fa.edgeBegin[s2 + 1] - fa.edgeBegin[s2] == 1) { rest[r++] = (unsigned char)fa.edgeCh[fa.edgeBegin[s2]]; s2 = fa.edgeNext[fa.edgeBegin[s2]]; }
             if (s2 > F || fa.edgeBegin[s2 + 1] != fa.edgeBegin[s2]) continue;      /* not a single path to ONE final state without successors: leave it to the walk */
-            const int all = r & ~1;
+            /* an even number of bytes that END with the pattern (a near miss differs near the end; an odd rest leaves out its first byte, a
+             * long one its beginning) */
+            const int all = r;
             if (all < kTailMinBytes || t.depth + all > 0xFFFF) continue;
-            const int bytes = all < kTailMaxBytes ? all : kTailMaxBytes, skip = all - bytes;
+            const int bytes = (all < kTailMaxBytes ? all : kTailMaxBytes) & ~1, skip = all - bytes;
             uint32_t h = t.h;
             for (int i = skip; i < all; i += 2) h = ladderRoll(h, (uint32_t)rest[i] | ((uint32_t)rest[i + 1] << 8));
             entries.push_back({t.h, h, (uint32_t)bytes | ((uint32_t)(t.depth + skip) << 8)});
@@ -469,6 +471,15 @@ void buildFilter(const Automaton &fa, Filter &f)
     for (uint32_t w : f.gram3) f.bitsSet += (size_t)__builtin_popcount(w);
     for (uint32_t w : f.ladder) f.bitsSetLad += (size_t)__builtin_popcount(w);
     buildReduceFilter(fa, f);
+}
+
+void buildFilter(const Automaton &fa, Filter &f)
+{
+    buildFilterImpl(fa, f, /*allowDeep=*/true);
+    /* the deep levels and the tail table are for the VETO kernels, whose table lies in the LDS the bitmaps leave (scan_filter.hip:
+     * vetoLdsBytes); a set whose bitmaps leave none -- Snort-scale -- gets the ladder of rounds 3 and 4 exactly */
+    const size_t lds = kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 65536 / 8 : 0) + f.tail.size() * sizeof(uint32_t);
+    if ((f.ladderLast > kLadderLast || !f.tail.empty()) && (f.tail.empty() || lds > kFilterLdsBudget)) buildFilterImpl(fa, f, /*allowDeep=*/false);
 }
 
 /* gram1 and prefix4 (struct Filter): the compacted-output kernel's level 1 -- every 3-byte prefix of a pattern, and every

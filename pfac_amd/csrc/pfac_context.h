@@ -136,8 +136,8 @@ struct Filter {
     int ladderLast = 20;                      /* deepest level of the ladder: kLadderLast, or kLadderDeepLast when the nodes behind kLadderLast fit the bitmap too (few do: most
                                                  paths are alone by then; BASELINE config 5's 24-byte shared prefix is what needs them) */
     /* The tail table (round 5; the veto of the VETO kernels on a ladder stop): a stop node below which ONE pattern is left knows the rest of
-     * that pattern.  Entry {tag = the node's ladder hash, hash = the tag rolled on over `bytes` bytes of the rest of the pattern (even, at most kTailMaxBytes: the
-     * last ones up to its end or the byte before), bytes | depth of the first of them << 8} in slot tailSlot(tag) or tailSlot2(tag); a candidate that stops at such a node rolls
+     * that pattern.  Entry {tag = the node's ladder hash, hash = the tag rolled on over the LAST `bytes` bytes of the pattern (even, at most kTailMaxBytes),
+     * bytes | depth of the first of them << 8} in slot tailSlot(tag) or tailSlot2(tag); a candidate that stops at such a node rolls
      * its own hash over as many of its bytes and is walked only if the two agree -- a near miss of a long pattern costs a few multiplications
      * instead of a walk through the table.  Only nodes whose hash no other ladder node shares have an entry (a shared hash could veto another
      * pattern's candidate); an entry that finds both its slots taken is left out; no entry = walk, as before. */

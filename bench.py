@@ -871,6 +871,8 @@ def rank_main(args):
                 "table": "hashed" if run.perf_mode else "dense", "table_bytes": int(info.sizeOfTableInBytes),
                 "walker_table": walker_table(args, run),
                 "texture_mode": int(run.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname, "walker_requested": args.walker,
+                "prefilter": {"ladder_last_level": int(getattr(info, "filterLadderLast", 20) or 20), "tail_table_entries": int(getattr(info, "filterTailEntries", 0) or 0),
+                              "note": "tail_table_entries > 0: the full-result kernel runs its VETO instance (window walker behind the tail-hash veto, DESIGN 3.1)"},
                 "build": build_info(), "platform": args.platform,
                 "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
                 "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if use_dist else None,

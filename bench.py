@@ -631,7 +631,8 @@ def other_configs(args, device, buffers):
         run = Run(args, name, perf, tex, 0, 1, device, buffers)
         run.step()
         ok, method, pos, _ = run.verify(args, 0, 1)
-        ms, _ = run.timed(OTHER_STEPS, 2, 8)
+        ms, _ = run.timed(OTHER_STEPS, 2, SETTLE_STEPS)             # the check has left the GPU idle for seconds: the same settling as the headline (a kernel bound by
+                                                                       # instruction issue, like C5's, is still slow 20 launches later)
         r = roofline_block(ms, run.n_read, kernel_name(args, run))
         entry = {"workload": run.cfg.description.replace("dense table", "hashed table") if run.perf_mode else run.cfg.description,
                  "table": "hashed" if run.perf_mode else "dense", "walker_table": walker_table(args, run),

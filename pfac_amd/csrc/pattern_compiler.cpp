@@ -436,13 +436,13 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
             int r = 0, s2 = t.state;
             while (s2 > F && r < 255 && fa.edgeBegin[s2 + 1] - fa.edgeBegin[s2] == 1) { rest[r++] = (unsigned char)fa.edgeCh[fa.edgeBegin[s2]]; s2 = fa.edgeNext[fa.edgeBegin[s2]]; }
             if (s2 > F || fa.edgeBegin[s2 + 1] != fa.edgeBegin[s2]) continue;      /* not a single path to ONE final state without successors: leave it to the walk */
-            /* an even number of bytes that END with the pattern (a near miss differs near the end; an odd rest leaves out its first byte, a
-             * long one its beginning) */
+            /* a multiple of four bytes that END with the pattern (a near miss differs near the end; the rest's first bytes are left out) */
             const int all = r;
             if (all < kTailMinBytes || t.depth + all > 0xFFFF) continue;
-            const int bytes = (all < kTailMaxBytes ? all : kTailMaxBytes) & ~1, skip = all - bytes;
+            const int bytes = (all < kTailMaxBytes ? all : kTailMaxBytes) & ~3, skip = all - bytes;      /* four bytes a step (tailRoll) */
             uint32_t h = t.h;
-            for (int i = skip; i < all; i += 2) h = ladderRoll(h, (uint32_t)rest[i] | ((uint32_t)rest[i + 1] << 8));
+            for (int i = skip; i < all; i += 4)
+                h = tailRoll(h, (uint32_t)rest[i] | ((uint32_t)rest[i + 1] << 8) | ((uint32_t)rest[i + 2] << 16) | ((uint32_t)rest[i + 3] << 24));
             entries.push_back({t.h, h, (uint32_t)bytes | ((uint32_t)(t.depth + skip) << 8)});
         }
         if (!entries.empty()) {

@@ -136,7 +136,7 @@ struct Filter {
     int ladderLast = 20;                      /* deepest level of the ladder: kLadderLast, or kLadderDeepLast when the nodes behind kLadderLast fit the bitmap too (few do: most
                                                  paths are alone by then; BASELINE config 5's 24-byte shared prefix is what needs them) */
     /* The tail table (round 5; the veto of the VETO kernels on a ladder stop): a stop node below which ONE pattern is left knows the rest of
-     * that pattern.  Entry {tag = the node's ladder hash, hash = the tag rolled on over the LAST `bytes` bytes of the pattern (even, at most kTailMaxBytes),
+     * that pattern.  Entry {tag = the node's ladder hash, hash = the tag rolled on (tailRoll: four bytes a step) over the LAST `bytes` bytes of the pattern (a multiple of four, at most kTailMaxBytes),
      * bytes | depth of the first of them << 8} in slot tailSlot(tag) or tailSlot2(tag); a candidate that stops at such a node rolls
      * its own hash over as many of its bytes and is walked only if the two agree -- a near miss of a long pattern costs a few multiplications
      * instead of a walk through the table.  Only nodes whose hash no other ladder node shares have an entry (a shared hash could veto another
@@ -173,6 +173,7 @@ inline uint32_t tailSlot(uint32_t tag, int log2Slots) { return (uint32_t)(tag * 
 inline uint32_t tailSlot2(uint32_t tag, int log2Slots) { return (uint32_t)(tag * kTailMul2) >> (32 - log2Slots); }
 constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
 constexpr uint32_t kLadMul0 = 0x9E3779B1u, kLadMul = 0x85EBCA77u, kLadMulS = 0xC2B2AE3Du, kLadMulG = 0x27D4EB2Fu, kLadMulG2 = 0x165667B1u;
+inline uint32_t tailRoll(uint32_t h, uint32_t piece32) { return (h ^ piece32) * kLadMul; }       /* the tail hash: four bytes a step */
 inline uint32_t ladderStart(uint32_t first4) { return first4 * kLadMul0; }
 inline uint32_t ladderRoll(uint32_t h, uint32_t piece16) { return (h ^ piece16) * kLadMul; }
 inline uint32_t ladderBitS1(uint32_t h, int log2Bits) { return h >> (32 - log2Bits); }

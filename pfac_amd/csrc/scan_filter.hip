@@ -1033,10 +1033,8 @@ void pfac_scan_filter(ScanArgs a)
 #pragma unroll
                             for (int k = 0; k < 8; k++) {
                                 const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], shb);
-                                const uint32_t r1 = (run ^ (x & 0xFFFFu)) * pfac::kLadMul;
+                                const uint32_t r1 = (run ^ x) * pfac::kLadMul;           /* pfac::tailRoll */
                                 run = (chk && 4u * (uint32_t)k < nb) ? r1 : run;
-                                const uint32_t r2 = (run ^ (x >> 16)) * pfac::kLadMul;
-                                run = (chk && 4u * (uint32_t)k + 2u < nb) ? r2 : run;
                             }
                         }
                         if (chk && run != want) walk = 0u;

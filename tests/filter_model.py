@@ -81,10 +81,10 @@ def prefilter_model(h, data, veto=True):
         at, hs, want, inf = at[has], hs[has], want[has], inf[has]
         nbytes, dep = (inf & u(0xFF)).astype(np.int64), (inf >> u(8)).astype(np.int64)
         run = hs.copy()
-        for i in range(0, int(nbytes.max()) if nbytes.size else 0, 2):
+        for i in range(0, int(nbytes.max()) if nbytes.size else 0, 4):         # pfac::tailRoll: four bytes a step
             live = i < nbytes
             p = (at + dep + i)[live]
-            run[live] = ((run[live] ^ (d[p] | (d[p + 1] << u(8)))) * u(LAD_MUL)) & m32
+            run[live] = ((run[live] ^ (d[p] | (d[p + 1] << u(8)) | (d[p + 2] << u(16)) | (d[p + 3] << u(24)))) * u(LAD_MUL)) & m32
         walk[at[run != want]] = False      # (the kernel also needs the bytes among those it has staged: it walks a few more)
     return level1, cand, walk
 

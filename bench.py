@@ -73,11 +73,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "c6"])
     ap.add_argument("--size-mib", type=int, default=1024, help="input bytes per GPU, MiB")
     ap.add_argument("--variant", default="auto", choices=["auto", "filter", "naive", "reftable"],
                     help="auto = the library default (PFACX_KERNEL_AUTO: what a drop-in PFAC.h caller gets; the filter kernel at bench sizes)")
-    ap.add_argument("--walker", default="auto", choices=["auto", "window", "stage"],
+    ap.add_argument("--walker", default="auto", choices=["auto", "window", "stage", "veto"],
                     help="walker of the full-result filter kernel (PFACX_setWalker): auto = the library default, what the handle's previous launch found its stream to be")
     ap.add_argument("--texture", default="auto", choices=["auto", "on", "off"])
     ap.add_argument("--perf-mode", default=None, choices=[None, "dense", "hash"])
@@ -95,7 +95,7 @@ def parse_args(argv=None):
                     help="nccl (= RCCL, one GPU per rank) is the real path; gloo lets several ranks share one GPU for a dry run")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the facts all-gather even with one rank (one RCCL all_gather on "
-                         "hardware without a multi-GPU node: tests/test_gpu_round3.py)")
+                         "hardware without a multi-GPU node: tests/test_multi_gpu.py)")
     ap.add_argument("--worker", default=None, choices=[None, "cpu", "pmc", "rank"],
                     help="rank: be the single rank right here, no orchestrator and no child process (the form to put behind `rocprofv3 ... --`); "
                          "pmc: the same, a few launches only; cpu: the CPU-baseline process")
@@ -370,7 +370,7 @@ class Run:
             if args.variant != "auto":                             # auto: the handle keeps the library default, nothing is set
                 self.handle.setKernelVariant(self.variant)
             if getattr(args, "walker", "auto") != "auto" and self.gpu:
-                self.handle.setWalker({"window": api.PFACX_WALKER_WINDOW, "stage": api.PFACX_WALKER_STAGE}[args.walker])
+                self.handle.setWalker({"window": api.PFACX_WALKER_WINDOW, "stage": api.PFACX_WALKER_STAGE, "veto": api.PFACX_WALKER_VETO}[args.walker])
             self.handle.readPatternFromFile(self.pattern_file)
             self.info = self.handle.info()
         else:

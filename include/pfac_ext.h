@@ -85,7 +85,10 @@ typedef struct {
     int streamDense;           /* ... 1 = most of it pattern-dense (short patterns over text, runs of a pattern byte) -> PFACX_KERNEL_AUTO
                                  sends the next big call to the tiled kernel alone */
     int filterLadderLast;      /* deepest level of the prefix ladder: 20, or 60 when the nodes behind the 20th byte fit its bitmap too */
-    size_t filterTailEntries;  /* entries of the tail table (PFACX_TABLE_FILTER_TAIL) */
+    size_t filterTailEntries;  /* entries of the tail table in its LDS form (PFACX_TABLE_FILTER_TAIL): sets of a few thousand patterns */
+    size_t filterTailGlobalEntries; /* ... in its device-memory form (PFACX_TABLE_FILTER_TAIL_GLOBAL): sets whose bitmaps fill the LDS, or with more
+                                  thin stops than the LDS form holds (Snort-scale).  A set has one form or the other (or none) */
+    int filterLog2TailGlobal;  /* log2 of the buckets of that table */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -105,11 +108,19 @@ typedef enum {
     PFACX_TABLE_FILTER_PREFIX4 = 10, /* uint32[2^17 / 32]: the 4-byte pattern prefixes, two probes (same kernel)    */
     PFACX_TABLE_FILTER_TAIL  = 11, /* uint32[3] per slot {ladder hash of a stop node, that hash rolled over the rest of the one pattern below it,
                                       bytes of that rest | depth << 8}, a power of two of slots (none: empty): the veto on a ladder stop */
+    PFACX_TABLE_FILTER_TAIL_GLOBAL = 12, /* uint32[4] per bucket: two entries {ladder hash of a stop node, (that hash rolled over the rest of the one
+                                      pattern below it) & ~0x7FF | depth of the first compared byte << 3 | bytes / 4 - 1}; bucket of a hash h =
+                                      (h * 0x9E3779B1) >> (32 - filterLog2TailGlobal); an entry is occupied if (word1 & 0x7F8) != 0 */
     PFACX_TABLE_CHAIN        = 8   /* uint32[4] per 16-byte unit: the device-only chained form of the hashed table that the
                                       GPU kernels walk in both perf modes.  chainSlots / 2 slot headers -- compact buckets,
                                       breadth first; then the 256 slots of the initial state; then the 2^chainJumpLog2
-                                      slots of the jump table of 4-byte prefixes -- followed by as many extension units,
-                                      unit i = chain bytes 8..22 of slot i (long slots of wide buckets only).  Built on first use on a host-only handle.  */
+                                      slots of the jump table of 4-byte prefixes; then the LONG jump table, 2^chainJumpLog2
+                                      slots again (same hash, chains of up to 23 bytes) -- followed by as many extension
+                                      units, unit i = chain bytes 8..22 of slot i (long slots of wide buckets and of the long
+                                      jump table only).  With N = chainSlots / 2 and J = chainJumpLog2:
+                                        [0, N - 256 - 2 * 2^J) buckets | [.., N - 2 * 2^J) initial state | [.., N - 2^J) jump |
+                                        [.., N) long jump | [N, 2 N) extension units.
+                                      Built on first use on a host-only handle.  */
 } PFACX_table_t;
 
 PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const void **ptr,
@@ -124,10 +135,15 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
  * A pattern set that has a TAIL TABLE (filterTailEntries of PFACX_getInfo > 0 and room in the CU's LDS: sets of a few thousand
  * patterns) is different: the prefilter puts a ladder stop to that table before it becomes a walk, near misses hardly reach a walker,
  * and AUTO and WINDOW both mean the window walker behind that veto (another 13 % on BASELINE config 5); STAGE is the stage walker
- * without it. */
+ * without it.
+ * A set whose tail table lies in DEVICE memory (filterTailGlobalEntries > 0: Snort-scale sets, round 6) asks it with one gathered load per
+ * stopped candidate, which text does not repay: under AUTO such a set runs the plain window walker until a launch reports a stream full of
+ * near misses, and the veto kernel (not the stage walker) from then on, until a launch of that kernel reports text again; WINDOW is the
+ * plain window walker, VETO the veto kernel, always. */
 #define PFACX_WALKER_AUTO   0
 #define PFACX_WALKER_WINDOW 1
 #define PFACX_WALKER_STAGE  2
+#define PFACX_WALKER_VETO   3   /* the window walker behind the tail-hash veto whatever the stream looks like (a set without a tail table of either form: WINDOW) */
 PFAC_status_t PFACX_setWalker(PFAC_handle_t handle, int walker);
 
 #define PFACX_KERNEL_FILTER 0   /* LDS prefilter + compacted walkers wherever the pointers allow it */
@@ -197,6 +213,8 @@ typedef struct {
                                              fetching extension units ahead); a majority makes PFACX_WALKER_AUTO give the handle's
                                              next launch the STAGE walker                                          */
     int walker;                           /* PFACX_WALKER_WINDOW / PFACX_WALKER_STAGE: what that launch ran with */
+    int veto;                             /* ... and whether the window walker stood behind the tail-hash veto: 0 = no, 1 = tail table in LDS, 2 = in device
+                                             memory (the kernel PFACX_WALKER_VETO asks for) */
 } PFACX_scan_stats_t;
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats);

@@ -25,12 +25,12 @@ PFAC_AUTOMATIC, PFAC_TEXTURE_ON, PFAC_TEXTURE_OFF = 0, 1, 2
 PFAC_TIME_DRIVEN, PFAC_SPACE_DRIVEN = 0, 1
 
 PFACX_KERNEL_FILTER, PFACX_KERNEL_NAIVE, PFACX_KERNEL_AUTO, PFACX_KERNEL_REFTABLE = 0, 1, 2, 3
-PFACX_WALKER_AUTO, PFACX_WALKER_WINDOW, PFACX_WALKER_STAGE = 0, 1, 2
+PFACX_WALKER_AUTO, PFACX_WALKER_WINDOW, PFACX_WALKER_STAGE, PFACX_WALKER_VETO = 0, 1, 2, 3
 PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
-PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4, PFACX_TABLE_FILTER_TAIL = 9, 10, 11
+PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4, PFACX_TABLE_FILTER_TAIL, PFACX_TABLE_FILTER_TAIL_GLOBAL = 9, 10, 11, 12
 
 
 class STATUS:
@@ -68,6 +68,7 @@ class PFACX_info(C.Structure):
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
         ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
         ("streamNearMisses", C.c_int), ("streamDense", C.c_int), ("filterLadderLast", C.c_int), ("filterTailEntries", C.c_size_t),
+        ("filterTailGlobalEntries", C.c_size_t), ("filterLog2TailGlobal", C.c_int),
     ]
 
 
@@ -75,7 +76,7 @@ class PFACX_scan_stats(C.Structure):
     _fields_ = [("structSize", C.c_size_t), ("walkerRounds", C.c_ulonglong), ("laneSteps", C.c_ulonglong), ("walksStarted", C.c_ulonglong),
                 ("level1Hits", C.c_ulonglong), ("tilesPerChunk", C.c_int), ("walksPerLane", C.c_int),
                 ("ladderCandidates", C.c_ulonglong), ("denseChunks", C.c_ulonglong), ("filterKernelMs", C.c_double),
-                ("stageModeWaves", C.c_ulonglong), ("walker", C.c_int)]
+                ("stageModeWaves", C.c_ulonglong), ("walker", C.c_int), ("veto", C.c_int)]
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
@@ -192,7 +193,7 @@ class PFAC:
         obj = cls(h)
         obj.create_status = 0
         # test harness: PFAC_TEST_WALKER=window|stage runs a whole test session with one walker of the full-result kernel
-        forced = {"window": PFACX_WALKER_WINDOW, "stage": PFACX_WALKER_STAGE}.get(os.environ.get("PFAC_TEST_WALKER", "").lower())
+        forced = {"window": PFACX_WALKER_WINDOW, "stage": PFACX_WALKER_STAGE, "veto": PFACX_WALKER_VETO}.get(os.environ.get("PFAC_TEST_WALKER", "").lower())
         if forced is not None:
             obj.setWalker(forced)
         return obj

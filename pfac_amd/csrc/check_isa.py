@@ -17,7 +17,7 @@ import re
 import sys
 
 RESERVED = {f"v{i}" for i in range(119, 128)}
-INSTANCES = 16                                          # TEX x HAS_SHORT x {compacted output, full result with the window walker, ... with the stage walker, ... window walker + veto}
+INSTANCES = 20                                          # TEX x HAS_SHORT x {compacted output, full result with the window walker, ... with the stage walker, ... window walker + veto (tail table in LDS), ... (in device memory)}
 
 
 class ContractError(Exception):
@@ -100,7 +100,8 @@ def check_waits(text):
         # the compacted-output instances fetch the extension unit of a LONG slot (wide buckets, pfac_context.h) and the input
         # behind it when a header's first eight chain bytes have matched, and wait for them on the spot (`; pfac_ext_sync`
         # in the source); the full-result instances load the input of a walk that has run off its LDS stage -- patterns
-        # longer than ~100 bytes -- the same way (`; pfac_deep_sync`).  Both are rare paths behind a wave-wide test.
+        # longer than ~100 bytes -- the same way (`; pfac_deep_sync`).  Both are rare paths behind a wave-wide test.  (The VETO = 2
+        # instances wait for the buckets of the device-memory tail table nowhere but at the top of the next trip.)
         def behind_marker(i):
             for j in range(i - 1, max(0, i - 60), -1):
                 if "pfac_ext_sync" in loop[j] or "pfac_deep_sync" in loop[j]:

@@ -257,6 +257,10 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
     };
     std::unique_ptr<std::atomic<unsigned>[]> filled;
     std::vector<std::thread> fillers;
+    /* read by the fill threads for as long as they run: declared where joinAll() still sees them */
+    cpu_set_t fillCpus;
+    CPU_ZERO(&fillCpus);
+    bool bindFill = false;
     try {
         filled.reset(new std::atomic<unsigned>[numPieces]);
         for (size_t k = 0; k < numPieces; k++) filled[k].store(0, std::memory_order_relaxed);
@@ -265,8 +269,6 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
          * cross the sockets' link meet the link's own reads of the input there (2 x EPYC 9575F, GPU on node 0, pinned buffers
          * first-touched on node 1: p50 7.4 ms, p90 11.4 ms per 256 MiB call against 5.5 / 6.2 ms with the buffers on node 0 --
          * the driver's round-4 line: 29 GB/s median; tools/host_numa_probe.py).  PFAC_HOST_FILL_ANYWHERE=1 leaves them to the OS. */
-        cpu_set_t fillCpus;
-        bool bindFill = false;
         if (helpers && std::getenv("PFAC_HOST_FILL_ANYWHERE") == nullptr) {
             const int node = numaNodeOf(h_matched_result + owned / 2);
             bindFill = node >= 0 && cpusOfNumaNode(node, fillCpus);

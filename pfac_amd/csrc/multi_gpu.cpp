@@ -87,6 +87,7 @@ PFAC_status_t onDevices(PFAC_handle_t handle, size_t size, int numDevices, const
         }
         std::lock_guard<std::mutex> g(w->lock);
         w->textureMode = c->textureMode;
+        w->walker = c->walker;                                     /* PFACX_setWalker on the parent reaches the workers */
         status[i] = call(w, i, bound[i], bound[i + 1]);
     };
     int callerDevice = 0;

@@ -457,6 +457,22 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
                 f.tail[at] = e.tag; f.tail[at + 1] = e.hash; f.tail[at + 2] = e.info;
                 f.tailEntries++;
             }
+            /* the device-memory form (struct Filter: tailG): buckets of two entries, at most one entry per two buckets on average */
+            int lgG = kTailGLog2Min;
+            while (lgG < kTailGLog2Max && (size_t(1) << lgG) < 2 * entries.size()) lgG++;
+            f.log2TailG = lgG;
+            f.tailG.assign((size_t(4) << lgG), 0u);
+            for (const Entry &e : entries) {
+                const uint32_t bytes = e.info & 0xFFu, from = e.info >> 8;
+                if (from > 255u || bytes < 4u || bytes > 32u || (bytes & 3u)) continue;
+                size_t at = (size_t)tailGBucket(e.tag, lgG) * 4;
+                if (f.tailG[at + 1] & kTailGFromMask) at += 2;
+                if (f.tailG[at + 1] & kTailGFromMask) continue;
+                f.tailG[at] = e.tag;
+                f.tailG[at + 1] = (e.hash & ~kTailGInfoMask) | (from << 3) | (bytes / 4u - 1u);
+                f.tailGEntries++;
+            }
+            f.tailCandidates = entries.size();
         }
     }
 #endif
@@ -476,10 +492,25 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
 void buildFilter(const Automaton &fa, Filter &f)
 {
     buildFilterImpl(fa, f, /*allowDeep=*/true);
-    /* the deep levels and the tail table are for the VETO kernels, whose table lies in the LDS the bitmaps leave (scan_filter.hip:
-     * vetoLdsBytes); a set whose bitmaps leave none -- Snort-scale -- gets the ladder of rounds 3 and 4 exactly */
+    /* The deep levels and the tail table are for the VETO kernels.  The table of a set of a few thousand patterns lies in the LDS its
+     * bitmaps leave (scan_filter.hip: vetoLdsBytes; VETO = 1).  A set whose bitmaps leave none, or with more thin stops than that table
+     * holds -- Snort-scale --, keeps the table in device memory (VETO = 2: one gathered load per stopped candidate, round 6); round 5 gave
+     * such a set the ladder of rounds 3 and 4 and no veto at all.  A set has one form or the other. */
     const size_t lds = kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 65536 / 8 : 0) + f.tail.size() * sizeof(uint32_t);
-    if ((f.ladderLast > kLadderLast || !f.tail.empty()) && (f.tail.empty() || lds > kFilterLdsBudget)) buildFilterImpl(fa, f, /*allowDeep=*/false);
+    const bool inLds = !f.tail.empty() && lds <= kFilterLdsBudget && f.tailEntries * 16 >= f.tailCandidates * 15;      /* (a table that lost more than a sixteenth of its entries to full slots is too small) */
+#ifdef PFAC_NO_GLOBAL_TAIL
+    if ((f.ladderLast > kLadderLast || !f.tail.empty()) && !inLds) { buildFilterImpl(fa, f, /*allowDeep=*/false); return; }
+#endif
+    if (inLds) {
+        std::vector<uint32_t>().swap(f.tailG);
+        f.log2TailG = 0;
+        f.tailGEntries = 0;
+    } else {
+        std::vector<uint32_t>().swap(f.tail);
+        f.log2Tail = 0;
+        f.tailEntries = 0;
+        if (f.tailGEntries == 0) { std::vector<uint32_t>().swap(f.tailG); f.log2TailG = 0; }
+    }
 }
 
 /* gram1 and prefix4 (struct Filter): the compacted-output kernel's level 1 -- every 3-byte prefix of a pattern, and every

@@ -189,6 +189,7 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build)
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_gram1, c->filter.gram1.data(), c->filter.gram1.size());
     if (st == PFAC_STATUS_SUCCESS) st = upload(c->d_prefix4, c->filter.prefix4.data(), c->filter.prefix4.size());
     if (st == PFAC_STATUS_SUCCESS && !c->filter.tail.empty()) st = upload(c->d_tail, c->filter.tail.data(), c->filter.tail.size());
+    else if (st == PFAC_STATUS_SUCCESS && !c->filter.tailG.empty()) st = upload(c->d_tail, c->filter.tailG.data(), c->filter.tailG.size());
     if (st == PFAC_STATUS_SUCCESS) {               /* chunk counters of the scan kernel, reset before every launch */
         const std::vector<unsigned int> zeros(pfac::kWorkCounterWords, 0u);
         st = upload(c->d_workCounters, zeros.data(), zeros.size());
@@ -200,7 +201,9 @@ PFAC_status_t bindCommon(PFAC_context *c, bool build)
         if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
             c->h_modeHint = static_cast<unsigned int *>(h);
             c->d_modeHint = static_cast<unsigned int *>(d);
-            *c->h_modeHint = 0;
+            /* every word: [1] routes PFACX_KERNEL_AUTO, [4] / [5] are the pair count and the sequence number a compacted-output call polls
+             * (sequence numbers are never 0); hipHostMalloc does not promise zeros, and a block given back by freeResources may come back stale */
+            std::memset(h, 0, 64);
         } else {
             if (h) (void)hipHostFree(h);
             (void)hipGetLastError();
@@ -552,6 +555,8 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         v.ladderExtend = handle->filter.ladderExtend;
         v.filterLadderLast = handle->filter.ladderLast;
         v.filterTailEntries = handle->filter.tailEntries;
+        v.filterTailGlobalEntries = handle->filter.tailGEntries;
+        v.filterLog2TailGlobal = handle->filter.tailG.empty() ? 0 : handle->filter.log2TailG;
         v.trailingBytesIgnored = handle->fa.trailingBytes;
         v.chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
         v.chainSlots = handle->h_chainSlots.size();
@@ -570,7 +575,7 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         if (handle->d_shortBits) dev += handle->filter.shortBits.size() * sizeof(uint32_t);
         if (handle->d_gram1) dev += handle->filter.gram1.size() * sizeof(uint32_t);
         if (handle->d_prefix4) dev += handle->filter.prefix4.size() * sizeof(uint32_t);
-        if (handle->d_tail) dev += handle->filter.tail.size() * sizeof(uint32_t);
+        if (handle->d_tail) dev += (handle->filter.tail.size() + handle->filter.tailG.size()) * sizeof(uint32_t);
         if (handle->d_workCounters) dev += pfac::kWorkCounterWords * sizeof(unsigned int);
         v.deviceTableBytes = dev;
         /* ... and what its calls have left allocated (grow-only, PFACX_trim gives it back): the two staging pieces of the host
@@ -623,6 +628,8 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.prefix4.data(); *bytes = handle->filter.prefix4.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_TAIL:
         *ptr = handle->filter.tail.data(); *bytes = handle->filter.tail.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_TAIL_GLOBAL:
+        *ptr = handle->filter.tailG.data(); *bytes = handle->filter.tailG.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
         if (handle->h_chainSlots.empty()) {
             const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */
@@ -690,7 +697,8 @@ PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats
     stats->tilesPerChunk = pfac::kChunkTiles;
     stats->walksPerLane = (int)v[pfac::kStatsCount + 1];     /* of the launch the counters describe: the full-result and the compacted-output kernel differ */
     stats->stageModeWaves = v[pfac::kStatsCount + 2] & 0xFFFFFFFFull;
-    stats->walker = (v[pfac::kStatsCount + 2] >> 32) ? PFACX_WALKER_STAGE : PFACX_WALKER_WINDOW;
+    stats->walker = ((v[pfac::kStatsCount + 2] >> 32) & 1ull) ? PFACX_WALKER_STAGE : PFACX_WALKER_WINDOW;
+    stats->veto = (int)((v[pfac::kStatsCount + 2] >> 33) & 3ull);
     return PFAC_STATUS_SUCCESS;
 }
 
@@ -715,7 +723,7 @@ PFAC_status_t PFACX_setKernelTiming(PFAC_handle_t handle, int on)
 PFAC_status_t PFACX_setWalker(PFAC_handle_t handle, int walker)
 {
     if (!handle) return PFAC_STATUS_INVALID_HANDLE;
-    if (walker != PFACX_WALKER_AUTO && walker != PFACX_WALKER_WINDOW && walker != PFACX_WALKER_STAGE) return PFAC_STATUS_INVALID_PARAMETER;
+    if (walker != PFACX_WALKER_AUTO && walker != PFACX_WALKER_WINDOW && walker != PFACX_WALKER_STAGE && walker != PFACX_WALKER_VETO) return PFAC_STATUS_INVALID_PARAMETER;
     std::lock_guard<std::mutex> guard(handle->lock);
     handle->walker = walker;
     return PFAC_STATUS_SUCCESS;

@@ -144,6 +144,17 @@ struct Filter {
     std::vector<uint32_t> tail;               /* 3 words per slot, 2^log2Tail slots; empty: none */
     int log2Tail = 0;
     size_t tailEntries = 0;
+    /* ... and its form for a set whose bitmaps leave the LDS no room for it, or whose thin stops outnumber kTailLog2Max slots
+     * (Snort-scale: round 6): the same entries in DEVICE memory, consulted by the VETO = 2 kernels with one gathered 16-byte load per
+     * candidate that was told to stop (the lines a near-miss stream asks for stay in L2: it meets the same few hundred stop nodes over
+     * and over).  A bucket -- tailGBucket(tag) -- holds two 8-byte entries {tag, (hash & ~kTailGInfoMask) | depth of the first compared
+     * byte << 3 | bytes / 4 - 1}: 21 bits of the rolled hash are compared (a near miss that agrees in all of them is walked: harmless),
+     * an entry whose bucket is full is left out (no entry = walk).  `from` >= kLadderFirst, so an occupied entry has bits among
+     * kTailGFromMask; depths beyond 255 have no entry. */
+    std::vector<uint32_t> tailG;              /* 4 words per bucket, 2^log2TailG buckets; empty: none */
+    int log2TailG = 0;
+    size_t tailGEntries = 0;
+    size_t tailCandidates = 0;                /* thin stops that asked for an entry (of either form) */
     int ladderExtend = 0;                     /* ... after this many more levels (0: at once): the deeper test spares the walk of a candidate that
                                                  shares a pattern's prefix up to the thin node and no further */
     std::vector<uint32_t> gram3;              /* 2^log2Bits bits, key c0|c1<<8|c2<<16            */
@@ -169,6 +180,9 @@ constexpr uint32_t kTailMul = 0x9E3779B1u, kTailMul2 = 0x85EBCA77u;      /* the 
 constexpr int kTailLog2Max = 12, kTailMinBytes = 6;          /* at most 4096 slots of 12 bytes (LDS); shorter rests are not worth an entry */
 constexpr int kTailMaxBytes = 32;                            /* ... and of a longer rest the LAST 32 bytes are compared (any bytes may be: the veto only has to hold for every match;
                                                                 near misses differ near the end): the kernel reads them in one go */
+constexpr uint32_t kTailGInfoMask = 0x7FFu, kTailGFromMask = 0x7F8u;
+constexpr int kTailGLog2Min = 8, kTailGLog2Max = 20;
+inline uint32_t tailGBucket(uint32_t tag, int log2Buckets) { return (uint32_t)(tag * kTailMul) >> (32 - log2Buckets); }
 inline uint32_t tailSlot(uint32_t tag, int log2Slots) { return (uint32_t)(tag * kTailMul) >> (32 - log2Slots); }
 inline uint32_t tailSlot2(uint32_t tag, int log2Slots) { return (uint32_t)(tag * kTailMul2) >> (32 - log2Slots); }
 constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
@@ -232,14 +246,15 @@ struct PFAC_context {
     std::vector<pfac::ChainSlot> h_chainSlots;               /* host copy of the chained table (PFACX_saveCompiled)       */
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
     size_t numChainSlots = 0;
-    int chainJumpLog2 = 0;                    /* the chained table is numChainSlots / 2 slot headers, then as many extension units; the last 2^J
-                                                 headers are the jump table, the 256 before them the initial state's bucket (tables.cpp:
-                                                 buildChainedHashTable) */
+    int chainJumpLog2 = 0;                    /* the chained table is N = numChainSlots / 2 slot headers, then as many extension units; the last
+                                                 2^J headers are the LONG jump table, the 2^J before them the jump table, the 256 before
+                                                 those the initial state's bucket: buckets | root(256) | jump(2^J) | long jump(2^J) | N units
+                                                 (tables.cpp: buildChainedHashTable) */
     uint32_t *d_gram3 = nullptr;
     uint32_t *d_shortBits = nullptr;
     uint32_t *d_ladder = nullptr;
     uint32_t *d_gram1 = nullptr, *d_prefix4 = nullptr;   /* the compacted-output kernel's level 1 and depth-4 test (struct Filter) */
-    uint32_t *d_tail = nullptr;                          /* the tail table (struct Filter), or null */
+    uint32_t *d_tail = nullptr;                          /* the tail table (struct Filter: `tail`, or `tailG` -- a set has one of them), or null */
     /* grow-only scratch of the compacted-output path (the arrays the pairs are ordered through), owned by the handle so that a
      * call does not pay for hipMalloc/hipFree */
     void *d_reduceScratch = nullptr;

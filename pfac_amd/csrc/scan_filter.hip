@@ -123,7 +123,7 @@ __device__ __forceinline__ uint32_t waveMin(uint32_t v)
 constexpr int kCompilerVgprs = PFAC_COMPILER_VGPRS;
 
 /* a.n is a whole number of chunks (>= 1) and at least maxPatternLen + 64 readable input bytes follow it */
-template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets, bool STAGE, bool VETO = false>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, int kWalkSets, bool STAGE, int VETO = 0>
 __global__ __launch_bounds__(kBlockThreads, PFAC_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(kCompilerVgprs)))
 void pfac_scan_filter(ScanArgs a)
 {
@@ -138,8 +138,21 @@ void pfac_scan_filter(ScanArgs a)
      * set of a few thousand patterns gets (its tables leave the LDS for it); a stop of the ladder is put to the table before it becomes a walk.  Its
      * walker fetches the extension unit of a wide bucket's slot with the header once its wave has met long slots (what is left to walk are patterns
      * that end within a byte of where the candidate left them: long slots all the way) */
-    constexpr bool kVeto = !REDUCE && !STAGE && VETO;
-    using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry, kVeto>>;
+    constexpr bool kVeto = !REDUCE && !STAGE && VETO != 0;
+    /* VETO = 2 (round 6): the same kernel for a set whose tail table does not fit the LDS (Snort-scale: the bitmaps take it, and its thin stops outnumber the
+     * LDS table's slots): the table lies in device memory (pfac::Filter::tailG), a batch of the ladder with kTailAskMin or more stopped candidates asks it
+     * with ONE gathered 16-byte load per candidate and waits for the answers on the spot (`; pfac_tail_sync`: the wait also takes the walkers' slots of
+     * this trip and the prefetched chunk, which the top of the next trip would have waited for anyway; the other scanning waves of the SIMD fill the
+     * gap).  The lines a near-miss stream asks for stay in L2: it meets the same few hundred stop nodes over and over.  Text does not repay the round
+     * trip: launchChained gives such a set this kernel only while the handle's launches report near misses. */
+    constexpr bool kVetoG = kVeto && VETO == 2;
+#ifndef PFAC_TAIL_ASK_MIN
+#define PFAC_TAIL_ASK_MIN 8
+#endif
+    constexpr uint32_t kTailAskMin = PFAC_TAIL_ASK_MIN;
+    /* (VETO = 2 keeps six more registers alive across the loop's back edge -- a batch's answers from the tail table -- and leaves the unit speculation,
+     * four registers, to VETO = 1: its walker fetches a long slot's unit on the spot, like the plain window walker) */
+    using WLane = std::conditional_t<kStageWalk, StageLane<TEX>, ChainLane<TEX, kEntry, kVeto && VETO == 1>>;
     constexpr int kStageWordsK = kStageWalk ? (int)(kWalkStageBytes / 4) : kStageWords;     /* words of one stage buffer */
     constexpr int kStageBufs = kStageWalk ? 2 : 1;
     constexpr int kHaloDwords = kStageWalk ? (int)(kWalkHalo / 4) : 12;                      /* dwords behind the chunk that are staged with it */
@@ -181,7 +194,7 @@ void pfac_scan_filter(ScanArgs a)
         copy16(sFinal3, a.final3, wordsF3);
         if (HAS_SHORT) copy16(sShort, a.shortBits, 2048);
         if constexpr (kStageWalk) copy16(sHotAll, a.chainSlots, (int)a.hotSlots * 4);
-        if constexpr (kVeto) { if (a.tail != nullptr) copy16(sHotAll, a.tail, 3 << a.log2Tail); }      /* the tail table: behind everything else */
+        if constexpr (kVeto && !kVetoG) { if (a.tail != nullptr) copy16(sHotAll, a.tail, 3 << a.log2Tail); }      /* the tail table: behind everything else */
         if (tid < kControlWords) reinterpret_cast<uint32_t *>(ctl)[tid] = (tid == (int)(offsetof(Control, endSpan) / 4)) ? kEnd : 0u;      /* endSpan = none yet */
     }
     __syncthreads();
@@ -673,6 +686,63 @@ void pfac_scan_filter(ScanArgs a)
 #else
 #define PFAC_TICK(k) do { } while (0)
 #endif
+    /* the tail hash of a candidate (pfac::tailRoll): `start` rolled over the nb (a multiple of four, <= kTailMaxBytes) staged bytes from offset `from` of the chunk --
+     * nine dwords of the stage in one go, then eight steps in registers */
+    auto tailRun = [&](uint32_t start, bool chk, uint32_t from, uint32_t nb) -> uint32_t {
+        static_assert(pfac::kTailMaxBytes == 32, "nine dwords");
+        const uint32_t b = chk ? from : 0u, at4 = b >> 2, shb = b & 3u;
+        uint32_t w[9], run = start;
+#pragma unroll
+        for (int k = 0; k < 9; k++) w[k] = stage[at4 + (uint32_t)k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], shb);
+            const uint32_t r1 = (run ^ x) * pfac::kLadMul;
+            run = (chk && 4u * (uint32_t)k < nb) ? r1 : run;
+        }
+        return run;
+    };
+    /* VETO = 2: the stopped candidates of one ladder batch whose buckets of the device-memory tail table are on their way (wave-uniform flag; per lane the
+     * bucket, the candidate's offset in the staged chunk | 1 << 31, the ladder hash that stopped it) */
+    u32x4 pendE = {0, 0, 0, 0};
+    uint32_t pendCode = 0, pendHash = 0;
+    bool pendAny = false;
+    /* ... looked at at the top of the next trip: the chunk is still staged (the next one is staged further down the trip), the queue still has the room the
+     * batch was cut to.  A candidate whose bytes hash like the rest of its pattern -- or that has no entry, or whose bytes are not all staged -- walks. */
+    auto tailResolve = [&]() {
+        const bool mine = (pendCode >> 31) != 0u;
+        const uint32_t o = pendCode & 0x7FFFFFFFu;
+        const bool m1 = pendE.x == pendHash && (pendE.y & pfac::kTailGFromMask) != 0u, m2 = pendE.z == pendHash && (pendE.w & pfac::kTailGFromMask) != 0u;
+        const uint32_t want = m1 ? pendE.y : pendE.w;
+        const uint32_t nb = ((want & 7u) + 1u) * 4u, from = o + ((want >> 3) & 0xFFu);
+        const bool chk = mine && (m1 | m2) && from + nb + 4u <= (uint32_t)kChunkBytes + 4u * (uint32_t)kHaloDwords;
+        const bool vetoed = chk && ((tailRun(pendHash, chk, from, nb) ^ want) & ~pfac::kTailGInfoMask) != 0u;
+        /* a vetoed candidate is a near miss of a long pattern: this kernel's evidence of what its stream is (the walks it spares are what the other
+         * kernels count: the vote at the end of a chunk) */
+        chunkEvents += (uint32_t)__popcll(__ballot(vetoed));
+        const bool keep = mine && !vetoed;
+        const uint64_t keepMask = __ballot(keep);
+        if (keepMask != 0) {
+            if (keep) {
+                const uint32_t at = o >> 2, sh = o & 3u;
+                uint32_t e[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) e[k] = stage[at + (uint32_t)k];
+                const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
+                const u32x4 entry = {stagedBase + o, __builtin_amdgcn_alignbyte(e[1], e[0], sh), __builtin_amdgcn_alignbyte(e[2], e[1], sh), __builtin_amdgcn_alignbyte(e[3], e[2], sh)};
+                const u32x2 entryB = {__builtin_amdgcn_alignbyte(e[4], e[3], sh), __builtin_amdgcn_alignbyte(e[5], e[4], sh)};
+                const u32x4 entryC = {__builtin_amdgcn_alignbyte(e[6], e[5], sh), __builtin_amdgcn_alignbyte(e[7], e[6], sh),
+                                      __builtin_amdgcn_alignbyte(e[8], e[7], sh), __builtin_amdgcn_alignbyte(e[9], e[8], sh)};
+                queue[qi] = entry;
+                queueB[qi] = entryB;
+                queueC[qi] = entryC;
+            }
+            qv = uni(qv + (uint32_t)__popcll(keepMask));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        pendAny = false;
+        pendCode = 0u;
+    };
     /* One loop, one copy of every stage.  A trip: (1) finish the walkers' transitions issued one trip ago; (2) refill
      * idle walker lanes and issue the next transitions; (3) if the staged chunk is completely listed and tested: level
      * 1 over the next chunk (prefetched one chunk ago), then the prefetch of the one after it; (4) the next <= kListCap
@@ -688,6 +758,7 @@ void pfac_scan_filter(ScanArgs a)
          * s_waitcnt vmcnt(0), expcnt and lgkmcnt untouched */
         __builtin_amdgcn_s_waitcnt(0x0F70);
         PFAC_TICK(8);
+        if constexpr (kVetoG) { if (pendAny) tailResolve(); }
         walkConsume();
         PFAC_TICK(0);
         flushWalks = chunk == kEnd && listAt == listEnd;
@@ -1014,7 +1085,18 @@ void pfac_scan_filter(ScanArgs a)
                     /* The tail table (pfac::Filter): a stop node below which one pattern is left knows the hash of the rest of that pattern.  A
                      * candidate that was told to stop there rolls its own hash over as many of its bytes and walks only if the two agree. */
                     const bool ask = a.tail != nullptr && stopHash != 0u && (walk & 1u) != 0u;
-                    if (__ballot(ask) != 0) {
+                    if constexpr (kVetoG) {
+                        /* device memory: the bucket's two entries with ONE gathered load -- whose answer is looked at at the top of the NEXT trip, behind
+                         * the loop's one wait (tailResolve): waited for here, the wait would also be for the chunk just prefetched (the counter is
+                         * in-order: 1.47 -> 1.93 ms on the near-miss stream).  One set of answers can be under way: a second batch of the same
+                         * trip, and a batch with fewer than kTailAskMin stopped candidates (text), walk theirs as before. */
+                        if (!pendAny && (uint32_t)__popcll(__ballot(ask)) >= kTailAskMin) {
+                            pendCode = ask ? (0x80000000u | o) : 0u;          /* (the loads themselves: behind the batches of this trip, once) */
+                            pendHash = stopHash;
+                            pendAny = true;
+                            walk = ask ? 0u : walk;                 /* decided, and appended if it stands, by tailResolve */
+                        }
+                    } else if (__ballot(ask) != 0) {
                         const uint32_t *sTail = sHotAll;
                         const uint32_t tshift = 32u - (uint32_t)a.log2Tail;
                         const uint32_t s1 = ((uint32_t)(stopHash * pfac::kTailMul) >> tshift) * 3u, s2 = ((uint32_t)(stopHash * pfac::kTailMul2) >> tshift) * 3u;
@@ -1023,21 +1105,7 @@ void pfac_scan_filter(ScanArgs a)
                         const uint32_t want = m1 ? h1 : h2, info = m1 ? i1 : (m2 ? i2 : 0u);
                         const uint32_t nb = info & 0xFFu, from = o + (info >> 8);
                         const bool chk = ask && info != 0u && from + nb + 4u <= (uint32_t)kChunkBytes + 4u * (uint32_t)kHaloDwords;   /* the bytes must be staged */
-                        uint32_t run = stopHash;
-                        {   /* at most kTailMaxBytes bytes: nine dwords of the stage in one go, then sixteen steps of the hash in registers */
-                            static_assert(pfac::kTailMaxBytes == 32, "nine dwords");
-                            const uint32_t b = chk ? from : 0u, at4 = b >> 2, shb = b & 3u;
-                            uint32_t w[9];
-#pragma unroll
-                            for (int k = 0; k < 9; k++) w[k] = stage[at4 + (uint32_t)k];
-#pragma unroll
-                            for (int k = 0; k < 8; k++) {
-                                const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], shb);
-                                const uint32_t r1 = (run ^ x) * pfac::kLadMul;           /* pfac::tailRoll */
-                                run = (chk && 4u * (uint32_t)k < nb) ? r1 : run;
-                            }
-                        }
-                        if (chk && run != want) walk = 0u;
+                        if (chk && tailRun(stopHash, chk, from, nb) != want) walk = 0u;
                     }
                 }
             }
@@ -1071,6 +1139,12 @@ void pfac_scan_filter(ScanArgs a)
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
             listAt = uni(listAt + take);
+        }
+        if constexpr (kVetoG) {
+            /* the buckets of the batch that asked: ONE load site per trip, behind the loop over the batches (inside it the compiler would wait for the
+             * load of a batch before -- there is none: pendAny -- before it reuses the registers) */
+            if (pendAny && (pendCode >> 31) != 0u)
+                pendE = reinterpret_cast<const u32x4 *>(a.tail)[(uint32_t)(pendHash * pfac::kTailMul) >> (32u - (uint32_t)a.log2Tail)];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         PFAC_TICK(5);
@@ -1126,7 +1200,7 @@ void pfac_scan_filter(ScanArgs a)
             if (lane == pfac::kStatsCount + 1) published[lane] = (unsigned long long)kWalkSets;
             if (lane == pfac::kStatsCount + 2) {                  /* scanning waves that ended the launch in stage mode: published, and the next launch's starting mode */
                 const unsigned int votes = !REDUCE ? atomicExch(a.work + pfac::kModeVotesWord, 0u) : 0u;
-                published[lane] = (unsigned long long)votes | ((unsigned long long)(kStageWalk ? 1u : 0u) << 32);
+                published[lane] = (unsigned long long)votes | ((unsigned long long)(kStageWalk ? 1u : 0u) << 32) | ((unsigned long long)(kVeto ? (kVetoG ? 2u : 1u) : 0u) << 33);
                 if (!REDUCE) {
                     const unsigned int hint = votes * 2u >= gridDim.x * (unsigned int)kScanners ? 1u : 0u;
                     atomicExch(a.work + pfac::kModeHintWord, hint);
@@ -1173,17 +1247,17 @@ size_t filterLdsBytes(const PFAC_context *c, bool reduce, bool stage)
 /* LDS of the tail table behind the buffers of a window-walker launch, or 0: none, or no room */
 size_t vetoLdsBytes(const PFAC_context *c, const ScanArgs &a)
 {
-    if (a.tail == nullptr || a.log2Tail < 2) return 0;
+    if (a.tail == nullptr || a.log2Tail < 2 || c->filter.tail.empty()) return 0;      /* (a table in its device-memory form takes no LDS: VETO = 2) */
     const size_t bytes = size_t(12) << a.log2Tail;
     return filterLdsBytes(c, false, false) + bytes <= kLdsPerCu ? bytes : 0;
 }
 
-template <bool TEX, bool HAS_SHORT, bool REDUCE, bool STAGE, bool VETO = false>
+template <bool TEX, bool HAS_SHORT, bool REDUCE, bool STAGE, int VETO = 0>
 hipError_t launchFilter(const PFAC_context *c, const ScanArgs &a0)
 {
     auto kernel = pfac_scan_filter<TEX, HAS_SHORT, REDUCE, REDUCE ? PFAC_WALK_SETS : PFAC_WALK_SETS_FULL, STAGE, VETO>;
     static ShapeCache cache;
-    size_t lds = filterLdsBytes(c, REDUCE, STAGE) + (VETO ? vetoLdsBytes(c, a0) : 0);
+    size_t lds = filterLdsBytes(c, REDUCE, STAGE) + (VETO == 1 ? vetoLdsBytes(c, a0) : 0);
     int dev = -1;                                      /* the device the launch goes to: the CURRENT one (the library never switches devices) */
     hipError_t de = hipGetDevice(&dev);
     if (de != hipSuccess) return de;
@@ -1269,26 +1343,37 @@ hipError_t launchChained(const PFAC_context *c, const ScanArgs &a, bool tex)
      * misses all over (most of its scanning waves ended it in stage mode / expecting long slots) -> StageLane, text -> the
      * register-window walker.  The word is host memory the last block of a launch writes: nothing is waited for, a launch
      * still under way simply has not voted yet */
-    bool stage = false, veto = false;
+    bool stage = false;
+    int veto = 0;
     if (!REDUCE) {
         /* a pattern set with a tail table (a few thousand patterns: its tables leave the LDS for it) puts the ladder's stops to the table
          * before they become walks: near misses hardly reach a walker then, and the register-window walker is the one for few walks */
 #ifndef PFAC_VETO
 #define PFAC_VETO 1
 #endif
-        veto = PFAC_VETO && c->walker != PFACX_WALKER_STAGE && vetoLdsBytes(c, a) != 0;
-        stage = c->walker == PFACX_WALKER_STAGE ||
-                (!veto && c->walker == PFACX_WALKER_AUTO && c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0);
+        const bool nearMisses = c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0;      /* the handle's last full-result launch */
+        if (PFAC_VETO && c->walker != PFACX_WALKER_STAGE) {
+            if (vetoLdsBytes(c, a) != 0) veto = 1;
+            /* ... in device memory (Snort-scale sets): a memory round trip per batch of stopped candidates, which only a stream of near misses repays:
+             * the veto kernel takes the place of the stage walker, and goes on reporting near misses (the candidates it vetoes) while the stream stays so */
+            else if (a.tail != nullptr && !c->filter.tailG.empty() && (c->walker == PFACX_WALKER_VETO || (c->walker == PFACX_WALKER_AUTO && nearMisses))) veto = 2;
+        }
+        stage = c->walker == PFACX_WALKER_STAGE || (veto == 0 && c->walker == PFACX_WALKER_AUTO && nearMisses);
     }
 #ifdef PFAC_QUICK      /* development builds (register / ISA inspection): the bench instances only */
     if (REDUCE || !tex) return hipErrorNotSupported;
     if (stage) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);
-    if (veto) return c->filter.hasShort ? launchFilter<true, true, false, false, true>(c, a) : launchFilter<true, false, false, false, true>(c, a);
+    if (veto == 2) return c->filter.hasShort ? launchFilter<true, true, false, false, 2>(c, a) : launchFilter<true, false, false, false, 2>(c, a);
+    if (veto) return c->filter.hasShort ? launchFilter<true, true, false, false, 1>(c, a) : launchFilter<true, false, false, false, 1>(c, a);
     return c->filter.hasShort ? launchFilter<true, true, false, false>(c, a) : launchFilter<true, false, false, false>(c, a);
 #else
+    if (!REDUCE && veto == 2) {
+        if (tex) return c->filter.hasShort ? launchFilter<true, true, false, false, 2>(c, a) : launchFilter<true, false, false, false, 2>(c, a);
+        return c->filter.hasShort ? launchFilter<false, true, false, false, 2>(c, a) : launchFilter<false, false, false, false, 2>(c, a);
+    }
     if (!REDUCE && veto) {
-        if (tex) return c->filter.hasShort ? launchFilter<true, true, false, false, true>(c, a) : launchFilter<true, false, false, false, true>(c, a);
-        return c->filter.hasShort ? launchFilter<false, true, false, false, true>(c, a) : launchFilter<false, false, false, false, true>(c, a);
+        if (tex) return c->filter.hasShort ? launchFilter<true, true, false, false, 1>(c, a) : launchFilter<true, false, false, false, 1>(c, a);
+        return c->filter.hasShort ? launchFilter<false, true, false, false, 1>(c, a) : launchFilter<false, false, false, false, 1>(c, a);
     }
     if (!REDUCE && stage) {
         if (tex) return c->filter.hasShort ? launchFilter<true, true, false, true>(c, a) : launchFilter<true, false, false, true>(c, a);

@@ -138,8 +138,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.gram3 = c->d_gram3;
     a.gram1 = c->d_gram1;
     a.prefix4 = c->d_prefix4;
-    a.tail = c->filter.tail.empty() ? nullptr : c->d_tail;
-    a.log2Tail = c->filter.log2Tail;
+    a.tail = (c->filter.tail.empty() && c->filter.tailG.empty()) ? nullptr : c->d_tail;       /* a set has the table in one form: LDS slots or device-memory buckets */
+    a.log2Tail = c->filter.tail.empty() ? c->filter.log2TailG : c->filter.log2Tail;
     a.shortBits = c->d_shortBits;
     a.ladder = c->d_ladder;
     a.final3 = c->d_final3;
@@ -175,7 +175,7 @@ constexpr size_t kSmallInput = size_t(32) << 20;
  *                              prefetch of a chunk the 64 bytes behind it)
  *   [first + mainLen, ownEnd)  bounds-checked walks inside the same launch (ScanArgs::endsIn): the end of the input
  * (`first` is the first 16-byte aligned input byte: scan() and reduceScan() peel the positions in front of it) */
-size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk)
+size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t inputSize, bool vectorOk, bool reduce = false)
 {
     if (!vectorOk || c->kernelVariant == PFACX_KERNEL_NAIVE || c->kernelVariant == PFACX_KERNEL_REFTABLE) return 0;
     if (c->kernelVariant == PFACX_KERNEL_AUTO) {
@@ -183,7 +183,9 @@ size_t filterLength(const PFAC_context *c, size_t first, size_t ownEnd, size_t i
         /* the handle's last big launch found most of its stream pattern-dense (short patterns over text, runs of a pattern byte):
          * the filter kernel would list nearly every chunk for the tiled kernel after testing it; the tiled kernel takes the call
          * alone (snort-length set with 1-byte patterns: 133 -> 166 GB/s) and reports when the stream stops being dense */
-        if (c->h_modeHint != nullptr && static_cast<volatile const unsigned int *>(c->h_modeHint)[1] != 0) return 0;
+        /* (full-result calls only: a compacted-output launch neither lists dense chunks nor reports on its stream, so it could never
+         * take the hint back -- and its filter kernel has no zeros to lose to the tiled kernel's coalesced lines) */
+        if (!reduce && c->h_modeHint != nullptr && static_cast<volatile const unsigned int *>(c->h_modeHint)[1] != 0) return 0;
     }
     const size_t margin = (size_t)c->fa.maxPatternLen + 64 + kWalkHalo;   /* a window load reads up to 35 bytes beyond a walk's deepest byte; the prefetch of a chunk reads the 64 (full-result kernel: kWalkHalo) bytes behind it */
     const size_t safeEnd = inputSize > margin ? inputSize - margin : 0;
@@ -341,7 +343,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
     trPlan = trUs();
 #endif
     const size_t head = headPositions(a.in, n);
-    const size_t mainLen = filterLength(c, head, n, n, true);
+    const size_t mainLen = filterLength(c, head, n, n, true, /*reduce=*/true);
     a.reducePos = d_pos;
     a.reduceCount = order.o.count;
     if (mainLen) {

@@ -11,6 +11,8 @@ lines.
     C3  ~30 k Snort-style patterns          snort_patterns(); http_stream()
     C4  C3 patterns over N x 1 GiB slices   http_stream(seed + slice)
     C5  adversarial near-miss               adversarial_patterns(); adversarial_stream()
+    C6  the C5 stream over C3's set + C5's  snort_patterns() + the 1 000 shared-prefix patterns of C5: the worst input on
+        shared-prefix patterns              the FULL set (what PFAC_hash_draft.pdf Table 5 measures); not a BASELINE config
 """
 
 from __future__ import annotations
@@ -299,4 +301,12 @@ def make_config(name: str) -> Config:
         pool = adversarial_pool(pats)
         return Config("c5", "adversarial near-miss stream (24-byte shared prefix), dense table",
                       pats, 0, lambda n, i: adversarial_stream(n, pool, SEED_C5 + i))
-    raise ValueError(f"unknown workload {name!r} (c2, c3, c5)")
+    if name == "c6":
+        c5 = adversarial_patterns()
+        pool = adversarial_pool(c5)                        # the C5 stream itself, byte for byte
+        prefix_pats = c5[:1000]                            # C5's shared-prefix patterns (its other thousand is the C2 set)
+        seen = set(prefix_pats)
+        pats = [p for p in snort_patterns() if p not in seen] + prefix_pats
+        return Config("c6", "adversarial near-miss stream of C5 over C3's 30000 Snort-style patterns + C5's 1000 shared-prefix patterns, hashed table",
+                      pats, 1, lambda n, i: adversarial_stream(n, pool, SEED_C5 + i))
+    raise ValueError(f"unknown workload {name!r} (c2, c3, c5, c6)")

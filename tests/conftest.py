@@ -23,6 +23,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _device(request):
+    """Every test marked `gpu` runs on cuda:0 and fails -- not skips -- without one: there is no CPU fallback to test."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        assert torch.cuda.is_available(), "GPU tests need a device; there is no CPU fallback to test"
+        torch.cuda.set_device(0)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Build the product libraries, the workload generator and the oracle if they are missing."""

@@ -86,6 +86,26 @@ def prefilter_model(h, data, veto=True):
             p = (at + dep + i)[live]
             run[live] = ((run[live] ^ (d[p] | (d[p + 1] << u(8)) | (d[p + 2] << u(16)) | (d[p + 3] << u(24)))) * u(LAD_MUL)) & m32
         walk[at[run != want]] = False      # (the kernel also needs the bytes among those it has staged: it walks a few more)
+    # ... or its device-memory form (Snort-scale sets, the VETO = 2 kernels): buckets of two 8-byte entries, 21 bits of the hash compared
+    tail_g = h.table(api.PFACX_TABLE_FILTER_TAIL_GLOBAL) if veto else np.zeros(0, dtype=np.uint32)
+    if tail_g.size:
+        lg = int(np.log2(tail_g.size // 4))
+        t = tail_g.reshape(-1, 4).astype(np.uint64)
+        at = np.flatnonzero(stopped)
+        hs = stop_hash[at]
+        bucket = (((hs * u(TAIL_MUL)) & m32) >> u(32 - lg)).astype(np.int64)
+        m1 = (t[bucket, 0] == hs) & ((t[bucket, 1] & u(0x7F8)) != 0)
+        m2 = (t[bucket, 2] == hs) & ((t[bucket, 3] & u(0x7F8)) != 0)
+        word = np.where(m1, t[bucket, 1], t[bucket, 3])
+        has = m1 | m2
+        at, hs, word = at[has], hs[has], word[has]
+        nbytes, dep = (((word & u(7)) + u(1)) * u(4)).astype(np.int64), ((word >> u(3)) & u(0xFF)).astype(np.int64)
+        run = hs.copy()
+        for i in range(0, int(nbytes.max()) if nbytes.size else 0, 4):
+            live = i < nbytes
+            p = (at + dep + i)[live]
+            run[live] = ((run[live] ^ (d[p] | (d[p + 1] << u(8)) | (d[p + 2] << u(16)) | (d[p + 3] << u(24)))) * u(LAD_MUL)) & m32
+        walk[at[((run ^ word) & u(0xFFFFF800)) != 0] ] = False
     return level1, cand, walk
 
 

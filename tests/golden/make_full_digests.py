@@ -16,7 +16,7 @@ maxPatternLen + 1 bytes of its successor (omp_PFAC.cpp:324) -- variant "inner" -
 slice of the job -- variant "last", where the stream ends with the slice.  Both are recorded for every
 slice so that any world size 1..8 can be checked.
 
-    python tests/golden/make_full_digests.py [--size-mib 1024] [--only c2,c3,c5]
+    python tests/golden/make_full_digests.py [--size-mib 1024] [--only c2,c3,c5,c6]
 """
 
 import argparse
@@ -37,7 +37,8 @@ from pfac_amd import sharding                   # noqa: E402
 from pfac_amd import workloads as wl            # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "full_digests.json")
-SLICES = {"c2": 1, "c3": 8, "c5": 1}
+SLICES = {"c2": 1, "c3": 8, "c5": 1, "c6": 1}
+HASHED_ONLY = ("c3", "c6")        # Snort-scale sets: the dense table is S KiB = 0.5 GB
 
 
 def digest(result, base):
@@ -69,12 +70,12 @@ def main():
         cfg = wl.make_config(name)
         pf = wl.write_pattern_file(os.path.join(tmp, name + ".pat"), cfg.patterns)
         ref = ob.Reference(pf)
-        o = ob.Oracle(pf, dense=(name != "c3"), hashed=True)
+        o = ob.Oracle(pf, dense=(name not in HASHED_ONLY), hashed=True)
         assert ref.edges() == o.edges()
         F, init, maxlen = ref.t.num_patterns, ref.t.initial_state, ref.t.max_pattern_len
         overlap = sharding.overlap_bytes(maxlen)
         row, val = o.hash_row(), o.hash_val()
-        dense = o.dense_table() if name != "c3" else None
+        dense = o.dense_table() if name not in HASHED_ONLY else None
 
         def run(data):
             r = ob.Reference.match_hash(data, row, val, F, init, omp=True)

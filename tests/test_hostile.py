@@ -1,0 +1,155 @@
+"""Hostile pattern sets and streams: Snort's published length range with 1- and 2-byte patterns over text, an input in which every position
+matches, PFACX_KERNEL_AUTO following the density of the stream.  Results against the oracle always; rates printed, and asserted only
+under PFAC_PERF_FLOORS (gpu_helpers.perf_asserts).  Reference: PFAC/doc/PFAC_algorithm.pdf 6.1 (Snort pattern lengths 1..243)."""
+
+import concurrent.futures  # noqa: F401
+import hashlib  # noqa: F401
+import json  # noqa: F401
+import os
+import subprocess  # noqa: F401
+import sys  # noqa: F401
+import threading  # noqa: F401
+import time  # noqa: F401
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from pfac_amd import api, sharding  # noqa: E402,F401
+from pfac_amd import workloads as wl  # noqa: E402,F401
+from tests.gpu_helpers import (MODES, STAGE, VARIANTS, WALKERS, assert_same, device_match, digest_record, digests, make_handle,  # noqa: E402,F401
+                               oracle_match, perf_asserts, run_bench, timed_match)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_snort_length_distribution_with_1_and_2_byte_patterns(workdir, capsys):
+    """PFAC_algorithm.pdf 6.1: the published Snort set has lengths 1..243.  3 000 patterns with that range --
+    1- and 2-byte patterns included, which set whole rows of the exact short-pattern bitmap -- over 64 MiB of
+    text: every mode and both kernels against the oracle; GB/s of the two kernels reported."""
+    from oracle import binding as ob
+    rng = np.random.Generator(np.random.PCG64(2431))
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 /.-_=&%:", dtype=np.uint8)
+    pats = {b"q", b"Z", b"zq", b"0x", b"%%"}
+    while len(pats) < 3000:
+        u = rng.random()
+        ln = int(rng.integers(1, 3)) if u < 0.01 else int(rng.integers(3, 40)) if u < 0.8 else int(rng.integers(40, 244))
+        pats.add(alpha[rng.integers(0, alpha.size, ln)].tobytes())
+    pats = sorted(pats, key=lambda p: (rng.random(), p))
+    assert max(map(len, pats)) > 200 and min(map(len, pats)) == 1
+    pf = wl.write_pattern_file(os.path.join(workdir, "snortlen.pat"), pats)
+    n = 64 << 20
+    data = alpha[rng.integers(0, alpha.size, n)].copy()
+    for k in range(400):                                         # plant long patterns, some across 2 KiB / 8 KiB boundaries
+        p = np.frombuffer(pats[int(rng.integers(0, len(pats)))], dtype=np.uint8)
+        at = int(rng.integers(0, n - 300)) if k % 4 else (int(rng.integers(1, n >> 13)) << 13) - int(rng.integers(1, 200))
+        data[at:at + p.size] = p
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    assert np.count_nonzero(want) > n // 64                     # the 1-byte patterns make matches dense
+    rates = {}
+    for perf, tex, mode_name in MODES:
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_AUTO, "auto"),
+                               (api.PFACX_KERNEL_REFTABLE, "reftable")):
+            h = make_handle(pf, perf, tex, variant)
+            try:
+                got, rate = timed_match(h, data)
+                assert_same(got, want, f"snort lengths / {mode_name} / {vname}")
+                rates[f"{mode_name}/{vname}"] = round(rate, 1)
+            finally:
+                h.destroy()
+    with capsys.disabled():
+        print("\n[snort-length set, 64 MiB, 1-byte patterns present] input GB/s:", rates)
+    # Pattern-dense text in every table mode.  The tiled kernel is bound by instruction issue here (profiles/r04_hostile_pmc.txt: 1.9e8 VALU
+    # instructions per launch = 85 % of its time): 160-174 GB/s; through the filter kernel every chunk of this text goes on the dense list
+    # (fifteen 1-byte patterns saturate the 3-gram bitmap: 98 % of the positions pass it) and comes back to the tiled kernel: 127-138.  The
+    # default variant (AUTO) learns it from the first launch -- most chunks dense: the last block out says so in host memory -- and sends the
+    # handle's next calls to the tiled kernel alone: what is asserted on every box is that AUTO is never much slower than the better
+    # of the two; absolute floors (a slow box, a shared box: not for a correctness run) only with PFAC_PERF_FLOORS=1
+    for mode_name in ("dense-global", "dense-buffer", "hash-global", "hash-buffer"):
+        if perf_asserts():
+            best = max(rates[f"{mode_name}/naive"], rates[f"{mode_name}/filter"], rates[f"{mode_name}/reftable"])
+            assert rates[f"{mode_name}/auto"] >= 0.85 * best, rates
+            assert rates[f"{mode_name}/naive"] >= 150.0 and rates[f"{mode_name}/auto"] >= 150.0 and rates[f"{mode_name}/filter"] >= 115.0, rates
+
+
+def test_every_position_matches_256_mib(workdir, capsys):
+    """Patterns a, aa, ..., a x 8 over 256 MiB of 'a': every position reports a pattern (the longest that fits).
+    All 2^28 level-1 tests hit, every queue is full all the time, every walk patches its zero: the ordering of
+    zero stores and patches and the back-pressure paths at scale.  Must be bit-exact and must not hang."""
+    from oracle import binding as ob
+    pats = [b"a" * k for k in range(1, 9)]
+    pf = wl.write_pattern_file(os.path.join(workdir, "allmatch.pat"), pats)
+    n = 256 << 20
+    data = np.full(n, ord("a"), dtype=np.uint8)
+    data[n // 3] = ord("b")                                      # one hole: results count down towards it
+    o = ob.Oracle(pf)
+    want = o.match(data, omp=True)
+    o.close()
+    assert np.count_nonzero(want) == n - 1
+    rates = {}
+    for perf, tex, mode_name in (MODES[1], MODES[3]):
+        for variant, vname in ((api.PFACX_KERNEL_FILTER, "filter"), (api.PFACX_KERNEL_NAIVE, "naive"), (api.PFACX_KERNEL_REFTABLE, "reftable")):
+            h = make_handle(pf, perf, tex, variant)
+            try:
+                got, rate = timed_match(h, data, steps=2)
+                assert_same(got, want, f"all-match / {mode_name} / {vname}")
+                rates[f"{mode_name}/{vname}"] = round(rate, 1)
+            finally:
+                h.destroy()
+    # the default variant: the filter kernel lists every chunk as pattern-dense and the tiled kernel behind it walks them
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    try:
+        got, rate = timed_match(h, data, steps=4)
+        assert_same(got, want, "all-match / auto")
+        rates["auto"] = round(rate, 1)
+        st = h.scanStats(n)
+        assert st["denseChunks"] >= (n >> 11) - 8, st
+    finally:
+        h.destroy()
+    with capsys.disabled():
+        print("\n[every position matches, 256 MiB] input GB/s:", rates)
+    # no cliff: the filter variant (every chunk goes on the dense list) within a fifth of the tiled kernel alone, AUTO (which sends the calls
+    # behind the first one to the tiled kernel alone) never much slower than the better of the two.  Eight dependent one-byte transitions per
+    # position (every state on the way is final, so no chain folds them) are 4.2e8 VALU instructions per 64 MiB, which is all of the launch's
+    # time (profiles/r04_hostile_pmc.txt): 84-94 GB/s; the absolute floor only with PFAC_PERF_FLOORS=1
+    if perf_asserts():
+        assert rates["hash-buffer/filter"] >= 0.8 * rates["hash-buffer/naive"] and rates["dense-buffer/filter"] >= 0.8 * rates["dense-buffer/naive"], rates
+        assert rates["auto"] >= 0.85 * max(rates["hash-buffer/naive"], rates["hash-buffer/filter"], rates["hash-buffer/reftable"]), rates
+        assert min(rates["hash-buffer/naive"], rates["dense-buffer/naive"], rates["auto"]) >= 75.0, rates
+
+
+def test_auto_kernel_follows_the_density_of_the_stream(workdir):
+    """PFACX_KERNEL_AUTO: a big call whose filter launch finds most chunks pattern-dense (1-byte patterns over text) makes the
+    handle's next big call go to the tiled kernel alone -- which walks dense input in place, reports whether the stream is still
+    dense, and hands back to the filter kernel when it is not.  Results are the oracle's on both streams, whoever scans."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 /.-_=&%:", dtype=np.uint8)
+    pats = sorted({b"aaa", b"aaaa", b"aaaaaaa"} | {alpha[rng.integers(0, alpha.size, int(rng.integers(4, 30)))].tobytes() for _ in range(800)})
+    pf = wl.write_pattern_file(os.path.join(workdir, "density.pat"), pats)
+    n = 48 << 20
+    sparse = alpha[rng.integers(1, alpha.size, n)].copy()           # text without an 'a'
+    dense = np.full(n, ord("a"), dtype=np.uint8)                    # every position matches: every chunk is pattern-dense
+    dense[rng.integers(0, n, n >> 12)] = ord("b")
+    dense[:1 << 20] = sparse[:1 << 20]
+    want_dense, want_sparse = oracle_match(pf, dense, omp=True), oracle_match(pf, sparse, omp=True)
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_AUTO)
+    try:
+        assert_same(device_match(h, sparse), want_sparse, "sparse, first call")
+        filter_launches = [h.scanStats()["level1Hits"]]
+        assert h.info().streamDense == 0
+        assert_same(device_match(h, dense), want_dense, "dense through the filter kernel")
+        assert h.info().streamDense == 1 and h.scanStats()["denseChunks"] > (n >> 11) // 2
+        mark = h.scanStats()["level1Hits"]
+        assert_same(device_match(h, dense), want_dense, "dense through the tiled kernel alone")
+        assert h.scanStats()["level1Hits"] == mark and h.info().streamDense == 1      # no new filter launch; still dense
+        assert_same(device_match(h, sparse), want_sparse, "sparse through the tiled kernel alone")
+        assert h.info().streamDense == 0                                               # ... which says so
+        assert_same(device_match(h, sparse), want_sparse, "sparse, back in the filter kernel")
+        assert h.scanStats()["level1Hits"] != mark and h.scanStats()["denseChunks"] == 0
+    finally:
+        h.destroy()

@@ -8,7 +8,7 @@ for v in "$@"; do
   src=tools/bin/variants/$v; [ "$v" = tree ] && src=tools/bin/variants/_tree
   cp $src/libpfac.so $src/libpfac_gfx950.so pfac_amd/lib/
   echo "== $v"
-  timeout 900 python -m pytest tests/test_gpu_round2.py -x -q -m gpu -s -k "snort_length or every_position" 2>&1 | grep -E "GB/s|passed|failed|Error|assert" | sed 's/dense-global[^,]*, //g; s/hash-global[^,]*, //g'
+  timeout 900 python -m pytest tests/test_hostile.py -x -q -m gpu -s -k "snort_length or every_position" 2>&1 | grep -E "GB/s|passed|failed|Error|assert" | sed 's/dense-global[^,]*, //g; s/hash-global[^,]*, //g'
   for w in c3 c2 c5; do
     timeout 300 python bench.py --workload $w --variant naive --steps 5 --warmup 2 --pmc off --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys

@@ -1,5 +1,5 @@
 """tools/hostile_driver.py <allmatch|snortlen> <variant: naive|filter|auto|reftable> [launches] [MiB]   (GPU box only)
-A few PFAC_matchFromDevice launches over one of the two pattern-dense test inputs (tests/test_gpu_round2.py), for profiling:
+A few PFAC_matchFromDevice launches over one of the two pattern-dense test inputs (tests/test_hostile.py), for profiling:
 put `python3 tools/hostile_driver.py ...` directly behind `rocprofv3 ... --`."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -22,8 +22,11 @@ if __name__ == "__main__":
     l1, cand, walk = filter_model(h, data)
     hit = res != 0
     assert np.all(walk[hit]), "false negative"
-    print("%s: %d MiB, gram3 2^%d bits, ladder 2^%d bits (%d set), stops %d go-ons %d thin %d extend %d" % (name, mib, info.filterLog2Bits, info.filterLog2BitsLadder,
-          info.filterBitsSetLadder, info.ladderStops, info.ladderGoOns, info.ladderThin, info.ladderExtend))
+    print("%s: %d MiB, gram3 2^%d bits, ladder 2^%d bits (%d set), stops %d go-ons %d thin %d extend %d last %d, tail entries %d (LDS) / %d (device memory, 2^%d buckets)" % (
+          name, mib, info.filterLog2Bits, info.filterLog2BitsLadder, info.filterBitsSetLadder, info.ladderStops, info.ladderGoOns, info.ladderThin, info.ladderExtend,
+          info.filterLadderLast, info.filterTailEntries, info.filterTailGlobalEntries, info.filterLog2TailGlobal))
+    _, _, walk0 = filter_model(h, data, veto=False)
+    print("  without the veto: walks %.5f of positions, per GiB %.2f M" % (walk0.mean(), walk0.mean() * 1073.74))
     print("  level-1 hits %.4f  ladder candidates %.4f  walks %.5f  matches %.5f of positions  -> walks per match %.1f, per GiB %.2f M" % (
         l1.mean(), cand.mean(), walk.mean(), hit.mean(), walk.sum() / max(1, hit.sum()), walk.mean() * 1073.74))
     h.destroy()

@@ -1,4 +1,4 @@
-"""tools/stress_fuzz.py [first_seed] [count] -- more seeds of tests/test_gpu_parity.py::test_fuzzed_pattern_sets_over_tiny_alphabets
+"""tools/stress_fuzz.py [first_seed] [count] -- more seeds of tests/test_full_result.py::test_fuzzed_pattern_sets_over_tiny_alphabets
 (pattern sets over tiny alphabets, prefixes at every depth, 1-2 byte patterns), bigger inputs, all four table modes,
 full-result and compacted-output calls, each launch repeated: a soak run for the GPU box, not part of the suite."""
 import os, sys, tempfile

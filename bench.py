@@ -608,6 +608,56 @@ def roofline_block(kernel_ms, n_read, kname):
     }
 
 
+def size_sweep(run):
+    """Calls of the sizes an IDS submits (PFAC_algorithm.pdf Table 2 measures 2 MB ... 192 MB): the first 1, 4, 16, 64 and 256 MiB of the
+    headline stream through the handle as it stands (PFACX_KERNEL_AUTO: the tiled kernel below 32 MiB, the filter kernel from there on),
+    back-to-back calls between two HIP events; and ONE cold call of the whole stream after a second of idle GPU (clocks down: what a
+    caller's first call after a pause pays; the headline is a steady-clock figure)."""
+    from pfac_amd import hiprt
+    torch = run.torch
+    out = {}
+    for mib in (1, 4, 16, 64, 256):
+        n = mib << 20
+        if n > run.n_read:
+            break
+        calls = max(10, min(200, (2048 << 20) // n))
+        for _ in range(5):
+            run.handle.matchFromDevice(run.d_in.data_ptr(), n, run.d_out.data_ptr())
+        torch.cuda.synchronize()
+        a, b = hiprt.Event(), hiprt.Event()
+        a.record(0)
+        for _ in range(calls):
+            run.handle.matchFromDevice(run.d_in.data_ptr(), n, run.d_out.data_ptr())
+        b.record(0)
+        torch.cuda.synchronize()
+        ms = a.elapsed_ms(b) / calls
+        out[f"{mib}_MiB"] = {"ms_per_call": round(ms, 5), "calls": calls, "input_GBps": round(n / (ms / 1e3) / 1e9, 1),
+                             "frac": round(ALGO_BYTES_PER_INPUT_BYTE * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "kernel_launched": "pfac_scan_tiled" if n < (32 << 20) else "pfac_scan_filter"}
+    # the cold call: everything above has been synchronised; a second of idle, then one bracketed call of the whole stream
+    for _ in range(3):
+        run.step()
+    torch.cuda.synchronize()
+    warm_a, warm_b = hiprt.Event(), hiprt.Event()
+    warm_a.record(0)
+    run.step()
+    warm_b.record(0)
+    torch.cuda.synchronize()
+    colds = []
+    for _ in range(3):
+        time.sleep(1.0)
+        a, b = hiprt.Event(), hiprt.Event()
+        a.record(0)
+        run.step()
+        b.record(0)
+        torch.cuda.synchronize()
+        colds.append(a.elapsed_ms(b))
+    out["cold_call"] = {"bytes": int(run.n_read), "ms_after_1s_idle": [round(x, 4) for x in colds], "ms_warm": round(warm_a.elapsed_ms(warm_b), 4),
+                        "cold_over_warm": round(float(np.median(colds)) / warm_a.elapsed_ms(warm_b), 3),
+                        "note": "one call of the whole stream bracketed by HIP events after 1 s of idle GPU (three times), against the same call behind three warm ones"}
+    return out
+
+
 def other_configs(args, device, buffers):
     """The other single-GPU BASELINE configurations on the same GPU and the same buffers:
     c2 with texture mode on and off, c5 with the dense and the hashed table."""
@@ -615,6 +665,9 @@ def other_configs(args, device, buffers):
     out = {}
     todo = [("c2_texture_on", "c2", None, "on", None), ("c2_texture_off", "c2", None, "off", None),
             ("c5_dense", "c5", api.PFAC_TIME_DRIVEN, "auto", None), ("c5_hashed", "c5", api.PFAC_SPACE_DRIVEN, "auto", None),
+            # the worst input on the FULL set (PFAC_hash_draft.pdf Table 5 measures its "worst" input on the same Snort set as its regular one): C5's near-miss
+            # stream over C3's 30 000 patterns + C5's 1 000 shared-prefix patterns.  The handle finds the veto kernel by itself (PFACX_WALKER_AUTO: settling launches)
+            ("c6_near_miss_stream_over_the_snort_scale_set", "c6", api.PFAC_SPACE_DRIVEN, "auto", None),
             # BASELINE config 2 names the dense 2-D table: the filter kernel walks the chained table in both perf modes, so this is the
             # entry in which a kernel really walks int[S][256] -- the reference-shaped one (PFACX_KERNEL_REFTABLE), and the tiled kernel alone
             ("c2_dense_table_reference_shaped_kernel", "c2", api.PFAC_TIME_DRIVEN, "on", "reftable"),
@@ -647,6 +700,31 @@ def other_configs(args, device, buffers):
         run.close()
         log(f"[bench] {key}: {entry['kernel_ms_avg']} ms, frac {entry['frac']}, exact {ok} ({time.perf_counter() - t0:.1f}s)")
     return out
+
+
+def placement_facts(args, device):
+    """(PCI bus id as an integer, NUMA node of the device or -- CPU dry run -- of the CPU this rank runs on): two of the int64 facts every rank
+    contributes, so that the first run on a real 8-GPU node records which device and which socket each rank had (omp_PFAC.cpp:257-290 binds
+    one host thread per device the same way and says nothing about where)."""
+    if args.platform == "gpu" and device is not None:
+        from pfac_amd import hiprt
+        bus = hiprt.pci_bus_id(int(str(device).split(":")[-1]))
+        return hiprt.pci_code(bus), hiprt.numa_node_of_pci(bus)
+    node = -1
+    try:
+        cpu = sorted(os.sched_getaffinity(0))[0]
+        for d in os.listdir("/sys/devices/system/node"):
+            if d.startswith("node") and os.path.exists(f"/sys/devices/system/node/{d}/cpu{cpu}"):
+                node = int(d[4:])
+    except (OSError, ValueError, AttributeError, IndexError):
+        pass
+    return -1, node
+
+
+def rank_placement(allf):
+    """the gathered placement facts as the JSON line reports them"""
+    from pfac_amd import hiprt
+    return [{"rank": int(r[4]), "pci_bus_id": hiprt.pci_string(int(r[5])) or None, "numa_node": int(r[6])} for r in allf]
 
 
 def setup_rank(args):
@@ -742,7 +820,7 @@ def strong_rank_main(args):
         last, i = sset.runs[-1], sset.index[-1]
         ok2, _, _, _ = last.verify(args, i, total)
         ok = ok and ok2
-    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
+    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank, *placement_facts(args, device)],
                                      device=device if (gpu and args.dist_backend == "nccl") else None, force=args.force_dist)
     elapsed_max = float(allf[:, 3].max()) / 1e9
     total_matches, folded = sharding.combine_checksums([(int(c), int(s)) for c, s in allf[:, :2]])
@@ -767,7 +845,7 @@ def strong_rank_main(args):
                 "texture_mode": int(run0.handle.info().textureMode), "kernel": args.variant, "kernel_launched": kname, "build": build_info(),
                 "platform": args.platform, "bytes_total": facts["total_bytes"], "slices_per_rank": len(sset.runs), "matches": facts["matches"],
                 "bit_exact": facts["bit_exact"], "bit_exact_method": method, "dist_backend": args.dist_backend if use_dist else None,
-                "ranks_seen": sorted(int(r) for r in allf[:, 4]),
+                "ranks_seen": sorted(int(r) for r in allf[:, 4]), "rank_placement": rank_placement(allf),
                 "folded_result": facts["folded_result"], "folded_reference": facts["folded_reference"],
             },
             "roofline": roofline_block(per_launch, run0.n_read, kname),
@@ -836,8 +914,8 @@ def rank_main(args):
             log(f"[bench r{rank}] RESULT OF THE LAST TIMED LAUNCH DIFFERS")
             ok = False
 
-    # ---- gather per-rank facts (RCCL: 5 x int64 per rank) ----------------------------------------
-    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank],
+    # ---- gather per-rank facts (RCCL: 7 x int64 per rank: count, checksum, exact, ns, rank, PCI bus id, NUMA node) ----------------------------------------
+    allf = sharding.all_gather_facts([count, checksum & 0x7FFFFFFFFFFFFFFF, int(ok), int(elapsed * 1e9), rank, *placement_facts(args, device)],
                                      device=device if (gpu and args.dist_backend == "nccl") else None, force=args.force_dist)
     elapsed_max = float(allf[:, 3].max()) / 1e9
     total_matches, folded = sharding.combine_checksums([(int(c), int(s)) for c, s in allf[:, :2]])
@@ -876,7 +954,7 @@ def rank_main(args):
                               "note": "tail_table_entries > 0: the full-result kernel runs its VETO instance (window walker behind the tail-hash veto, DESIGN 3.1)"},
                 "build": build_info(), "platform": args.platform,
                 "bytes_per_gpu": n, "matches": total_matches, "bit_exact": all_ok, "bit_exact_method": method,
-                "ranks_seen": ranks_seen, "dist_backend": args.dist_backend if use_dist else None,
+                "ranks_seen": ranks_seen, "rank_placement": rank_placement(allf), "dist_backend": args.dist_backend if use_dist else None,
                 "folded_result": {"match_count": total_matches, "checksum": folded & 0x7FFFFFFFFFFFFFFF},
                 "folded_reference": expected,
             },
@@ -1047,6 +1125,9 @@ def rank_main(args):
                 log(f"[bench] stream probe skipped: {e}")
             if not args.no_other_configs:
                 buffers = (run.d_in, run.d_out)
+                if args.variant == "auto":
+                    out["call_size_sweep"] = size_sweep(run)
+                    log(f"[bench] call sizes: { {k: v.get('input_GBps', v.get('cold_over_warm')) for k, v in out['call_size_sweep'].items()} }")
                 out["other_configs"] = other_configs(args, device, buffers)
                 if args.workload == "c3" and args.size_mib == 1024 and args.perf_mode is None:
                     # BASELINE config 4 (8 GiB) as ONE workload on this one GPU: what `--scaling strong --gpus 1` reports, the

@@ -89,6 +89,7 @@ typedef struct {
     size_t filterTailGlobalEntries; /* ... in its device-memory form (PFACX_TABLE_FILTER_TAIL_GLOBAL): sets whose bitmaps fill the LDS, or with more
                                   thin stops than the LDS form holds (Snort-scale).  A set has one form or the other (or none) */
     int filterLog2TailGlobal;  /* log2 of the buckets of that table */
+    int filterSkipTags;        /* skip tags of the prefix ladder (PFACX_TABLE_FILTER_SKIP): depth-6 nodes with a single path down to depth 20 (at most 8) */
 } PFACX_info_t;
 
 PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info);
@@ -111,6 +112,7 @@ typedef enum {
     PFACX_TABLE_FILTER_TAIL_GLOBAL = 12, /* uint32[4] per bucket: two entries {ladder hash of a stop node, (that hash rolled over the rest of the one
                                       pattern below it) & ~0x7FF | depth of the first compared byte << 3 | bytes / 4 - 1}; bucket of a hash h =
                                       (h * 0x9E3779B1) >> (32 - filterLog2TailGlobal); an entry is occupied if (word1 & 0x7F8) != 0 */
+    PFACX_TABLE_FILTER_SKIP  = 13, /* uint32[filterSkipTags]: ladder hashes (depth 6) whose candidates are next asked at depth 20 */
     PFACX_TABLE_CHAIN        = 8   /* uint32[4] per 16-byte unit: the device-only chained form of the hashed table that the
                                       GPU kernels walk in both perf modes.  chainSlots / 2 slot headers -- compact buckets,
                                       breadth first; then the 256 slots of the initial state; then the 2^chainJumpLog2
@@ -174,11 +176,21 @@ PFAC_status_t PFACX_loadCompiled(PFAC_handle_t handle, const char *filename);
  * allocates it again.  The pattern set and its tables stay. */
 PFAC_status_t PFACX_trim(PFAC_handle_t handle);
 
+/* What the handle's FIRST PFAC_matchFromHost / PFAC_matchFromHostReduce would allocate, create and load inside the call, done ahead of it: the
+ * two staging pieces (for calls of up to maxBytes input bytes; 0 or more than a piece: whole pieces of 32 Mi positions), their copy streams and
+ * events, the ordering scratch, the kernels' code objects (one throwaway scan), the runtime's staging of pageable host memory (one throwaway
+ * upload).  Optional: without it the first call does the same, ~100 ms instead of ~7 (256 MiB).  PFACX_trim undoes it; a handle on a CPU
+ * platform has nothing to prepare (success). */
+PFAC_status_t PFACX_prepare(PFAC_handle_t handle, size_t maxBytes);
+
 /* One call shards a host stream over several GPUs of the node (reference users write this
  * themselves after PFAC/test/omp_PFAC.cpp:257-394): one worker thread and one internal handle per entry of
  * `devices` (NULL = devices 0..numDevices-1; numDevices 0 = every visible device), contiguous slices scanned
  * with a maxPatternLen read-ahead, no exchange between devices.  `handle` supplies the pattern set and modes
- * and keeps the per-device handles for the next call.  A device may be listed more than once. */
+ * and keeps the per-device handles for the next call.  A device may be listed more than once.
+ * On a handle whose platform is a CPU platform (PFAC_setPlatform, PFACX_createHostOnly) there is nothing to shard over: the call then runs
+ * `numDevices` workers (0 = one) as host threads over the CPU matchers -- same slices, same read-ahead, same folding of the results; `devices`
+ * is ignored.  That is a dry run of the driver on a machine without a GPU, not a fallback: the GPU platform never takes it. */
 PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputString, size_t size,
                                           int *h_matched_result, int numDevices, const int *devices);
 

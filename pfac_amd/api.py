@@ -30,7 +30,7 @@ PFACX_READ_STRICT, PFACX_READ_STRIP_CR = 1, 2
 (PFACX_TABLE_DENSE, PFACX_TABLE_HASH_ROWPTR, PFACX_TABLE_HASH_VALPTR, PFACX_TABLE_INITIAL_ROW,
  PFACX_TABLE_FILTER_GRAM3, PFACX_TABLE_FILTER_SHORT, PFACX_TABLE_FILTER_LADDER, PFACX_TABLE_FILTER_FINAL3,
  PFACX_TABLE_CHAIN) = range(9)
-PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4, PFACX_TABLE_FILTER_TAIL, PFACX_TABLE_FILTER_TAIL_GLOBAL = 9, 10, 11, 12
+PFACX_TABLE_FILTER_GRAM1, PFACX_TABLE_FILTER_PREFIX4, PFACX_TABLE_FILTER_TAIL, PFACX_TABLE_FILTER_TAIL_GLOBAL, PFACX_TABLE_FILTER_SKIP = 9, 10, 11, 12, 13
 
 
 class STATUS:
@@ -68,7 +68,7 @@ class PFACX_info(C.Structure):
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
         ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
         ("streamNearMisses", C.c_int), ("streamDense", C.c_int), ("filterLadderLast", C.c_int), ("filterTailEntries", C.c_size_t),
-        ("filterTailGlobalEntries", C.c_size_t), ("filterLog2TailGlobal", C.c_int),
+        ("filterTailGlobalEntries", C.c_size_t), ("filterLog2TailGlobal", C.c_int), ("filterSkipTags", C.c_int),
     ]
 
 
@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = (
     "PFACX_createHostOnly", "PFACX_getInfo", "PFACX_getTable", "PFACX_setKernelVariant",
     "PFACX_readPatternFromMemory", "PFACX_getScanStats", "PFACX_saveCompiled", "PFACX_loadCompiled",
     "PFACX_matchFromHostMultiGPU", "PFACX_matchFromHostReduceMultiGPU", "PFACX_readPatternFromFileEx", "PFACX_readPatternFromMemoryEx", "PFACX_trim",
-    "PFACX_setKernelTiming", "PFACX_setWalker",
+    "PFACX_setKernelTiming", "PFACX_setWalker", "PFACX_prepare",
 )
 MODULE_SYMBOLS = (  # include/pfac_module.h, exported by libpfac_gfx950.so
     "PFAC_kernel_timeDriven_warpper", "PFAC_kernel_spaceDriven_warpper",
@@ -138,6 +138,8 @@ def load_library() -> C.CDLL:
         lib.PFACX_setWalker.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromMemory.argtypes = [H, C.c_char_p, C.c_size_t]
     lib.PFACX_trim.argtypes = [H]
+    if hasattr(lib, "PFACX_prepare"):
+        lib.PFACX_prepare.argtypes = [H, C.c_size_t]
     lib.PFACX_setKernelTiming.argtypes = [H, C.c_int]
     lib.PFACX_readPatternFromFileEx.argtypes = [H, C.c_char_p, C.c_uint]
     lib.PFACX_readPatternFromMemoryEx.argtypes = [H, C.c_char_p, C.c_size_t, C.c_uint]
@@ -251,6 +253,10 @@ class PFAC:
     def readPatternFromMemory(self, data: bytes, check: bool = True) -> int:
         """``PFACX_readPatternFromMemory``: the pattern-file bytes without a file."""
         return self._ret(self._lib.PFACX_readPatternFromMemory(self._h, data, len(data)), "PFACX_readPatternFromMemory", check)
+
+    def prepare(self, max_bytes: int = 0, check: bool = True) -> int:
+        """``PFACX_prepare``: staging, scratch and code objects of the host paths ahead of the first call."""
+        return self._ret(self._lib.PFACX_prepare(self._h, max_bytes), "PFACX_prepare", check)
 
     def trim(self, check: bool = True) -> int:
         """``PFACX_trim``: free the handle's grow-only device temporaries."""

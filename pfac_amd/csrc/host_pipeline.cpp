@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,26 @@
 
 using pfac::Int2;
 using namespace pfac_internal;
+
+namespace {
+
+/* The threads of a host call wait for each other's progress -- the uploader for a scanned buffer, the caller for an upload to be queued and for
+ * a piece of its vector to be filled -- on a condition variable: round 5 spun on std::this_thread::yield(), which on a host whose cores are all
+ * busy (the zero fill runs up to eight threads beside the DMA engine's reads) takes the very cores the fill threads need.  Progress counters stay
+ * atomics (the fast path is one acquire load); whoever advances one calls bump(). */
+struct Progress {
+    std::mutex m;
+    std::condition_variable cv;
+    void bump() { { std::lock_guard<std::mutex> g(m); } cv.notify_all(); }
+    template <class Pred> void wait(Pred done)
+    {
+        if (done()) return;
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, done);
+    }
+};
+
+} // namespace
 
 namespace pfac_internal {
 
@@ -75,6 +96,41 @@ static PFAC_status_t ensureHostStage(PFAC_context *c, size_t need)
     if (!ok) { (void)hipGetLastError(); freeHostStage(c); return PFAC_STATUS_CUDA_ALLOC_FAILED; }
     c->hostStagePositions = need;
     return PFAC_STATUS_SUCCESS;
+}
+
+/* PFACX_prepare: everything a handle's first PFAC_matchFromHost / PFAC_matchFromHostReduce would otherwise allocate, create or load inside the
+ * call (round 5's driver line: first call 103 ms, steady 7 ms): the two staging pieces with their streams and events, the ordering scratch of a
+ * piece, the code objects of the compacted-output scan and its ordering launches (one throwaway scan of a piece filled with a byte no pattern
+ * starts with), and the runtime's own staging of pageable host memory (one throwaway upload of a pageable piece).  The caller holds c->lock. */
+PFAC_status_t prepareHostPath(PFAC_context *c, size_t maxBytes)
+{
+    if (!c->hasDevice || !c->module) return PFAC_STATUS_LIB_NOT_EXIST;
+    const size_t overlap = (size_t)c->fa.maxPatternLen;
+    const size_t want = maxBytes == 0 || maxBytes > kHostPiece ? kHostPiece : maxBytes;
+    PFAC_status_t st = ensureHostStage(c, want + overlap);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    correctTextureMode(c);
+    int filler = 0;                                            /* a byte the initial state has no transition on, if there is one: the scan then finds nothing */
+    for (int b = 0; b < pfac::kCharSet && (size_t)b < c->h_initialRow.size(); b++)
+        if (c->h_initialRow[(size_t)b] == pfac::kTrapState) { filler = b; break; }
+    hipStream_t up = static_cast<hipStream_t>(c->stageUp);
+    const size_t n = want + overlap;
+    bool ok = true;
+    try {
+        const std::vector<char> pageable(n, (char)filler);
+        ok = hipMemcpyAsync(c->d_stageIn[0], pageable.data(), n, hipMemcpyHostToDevice, up) == hipSuccess && hipStreamSynchronize(up) == hipSuccess &&
+             hipMemsetAsync(c->d_stageIn[1], filler, n, nullptr) == hipSuccess;
+    } catch (const std::bad_alloc &) { return PFAC_STATUS_ALLOC_FAILED; }
+    if (!ok) { (void)hipGetLastError(); return PFAC_STATUS_INTERNAL_ERROR; }
+    PFAC_reduce_kernel_protoType reduce = c->perfMode == PFAC_TIME_DRIVEN ? c->reduce_kernel_ptr : c->reduce_inplace_kernel_ptr;
+    for (int b = 0; b < 2 && st == PFAC_STATUS_SUCCESS; b++) {              /* both buffers, the way both host calls use them: pairs in any order / in position order */
+        int count = 0;
+        c->reduceUnordered = b == 0;
+        st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)n, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
+        c->reduceUnordered = false;
+    }
+    if (st == PFAC_STATUS_SUCCESS && hipStreamSynchronize(nullptr) != hipSuccess) st = PFAC_STATUS_INTERNAL_ERROR;
+    return st;
 }
 
 /* every result crosses the link: pieces with many matches */
@@ -212,6 +268,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
      * Piece i goes into buffer i & 1 once the scan of piece i - 2 is over. */
     std::atomic<size_t> scansDone{0}, uploadsQueued{0};
     std::atomic<bool> uploadFailed{false}, stopUploads{false};
+    Progress progress;                                         /* what the threads of this call wait for each other on */
     int device = 0;
     (void)hipGetDevice(&device);
     std::thread uploader;
@@ -222,12 +279,13 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
     } else {
         try {
             uploader = std::thread([&]() {
-                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
+                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); progress.bump(); return; }
                 for (size_t i = 0; i < numPieces; i++) {
-                    while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (i >= 2) progress.wait([&]() { return scansDone.load(std::memory_order_acquire) + 1 >= i || stopUploads.load(std::memory_order_relaxed); });
                     if (stopUploads.load(std::memory_order_relaxed)) return;
-                    if (!uploadPiece(i)) { uploadFailed.store(true); return; }
+                    if (!uploadPiece(i)) { uploadFailed.store(true); progress.bump(); return; }
                     uploadsQueued.store(i + 1, std::memory_order_release);
+                    progress.bump();
                 }
             });
         } catch (...) { ok = false; }
@@ -281,6 +339,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
                     share(k, t, helpers, lo, hi);
                     fillZeroStreaming(h_matched_result + lo, hi - lo);
                     filled[k].fetch_add(1, std::memory_order_release);
+                    progress.bump();
                 }
             });
     } catch (...) { /* no memory, or fewer threads than planned: the shares nobody started are filled by this thread, below */ }
@@ -306,7 +365,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
                 share(k, t, helpers, lo, hi);
                 fillZeroStreaming(h_matched_result + lo, hi - lo);
             }
-            while (filled[k].load(std::memory_order_acquire) < started) std::this_thread::yield();
+            progress.wait([&]() { return filled[k].load(std::memory_order_acquire) >= started; });
             filled[k].store(helpers, std::memory_order_relaxed);
         }
     };
@@ -319,7 +378,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
             const size_t off = i * piece;
             const size_t mine = owned - off < piece ? owned - off : piece;
             const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
-            while (uploadsQueued.load(std::memory_order_acquire) <= i && !uploadFailed.load(std::memory_order_relaxed)) std::this_thread::yield();
+            progress.wait([&]() { return uploadsQueued.load(std::memory_order_acquire) > i || uploadFailed.load(std::memory_order_relaxed); });
             ok = !uploadFailed.load(std::memory_order_relaxed) && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
             if (!ok) break;
             int count = 0;
@@ -328,6 +387,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
             c->reduceUnordered = false;
             if (st != PFAC_STATUS_SUCCESS) break;
             scansDone.store(i + 1, std::memory_order_release);     /* the scan is synchronous: its input buffer may take piece i + 2 */
+            progress.bump();
             if ((size_t)count > mine / 8) { densePieces.push_back(i); continue; }
             pos.resize((size_t)count);
             id.resize((size_t)count);
@@ -343,6 +403,7 @@ PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned,
         if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     } catch (const std::bad_alloc &) { st = PFAC_STATUS_ALLOC_FAILED; }
     stopUploads.store(true);
+    progress.bump();
     if (uploader.joinable()) uploader.join();
     const double tLoop = since();
     const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
@@ -394,6 +455,7 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
     };
     std::atomic<size_t> scansDone{0}, uploadsQueued{0};
     std::atomic<bool> uploadFailed{false}, stopUploads{false};
+    Progress progress;
     int device = 0;
     (void)hipGetDevice(&device);
     std::thread uploader;
@@ -404,12 +466,13 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
     } else {
         try {
             uploader = std::thread([&]() {
-                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); return; }
+                if (hipSetDevice(device) != hipSuccess) { uploadFailed.store(true); progress.bump(); return; }
                 for (size_t i = 0; i < numPieces; i++) {
-                    while (i >= 2 && scansDone.load(std::memory_order_acquire) + 1 < i && !stopUploads.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (i >= 2) progress.wait([&]() { return scansDone.load(std::memory_order_acquire) + 1 >= i || stopUploads.load(std::memory_order_relaxed); });
                     if (stopUploads.load(std::memory_order_relaxed)) return;
-                    if (!uploadPiece(i)) { uploadFailed.store(true); return; }
+                    if (!uploadPiece(i)) { uploadFailed.store(true); progress.bump(); return; }
                     uploadsQueued.store(i + 1, std::memory_order_release);
+                    progress.bump();
                 }
             });
         } catch (...) { ok = false; }
@@ -420,13 +483,14 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
         const size_t off = i * piece;
         const size_t mine = size - off < piece ? size - off : piece;
         const size_t scanned = readable - off < mine + overlap ? readable - off : mine + overlap;
-        while (uploadsQueued.load(std::memory_order_acquire) <= i && !uploadFailed.load(std::memory_order_relaxed)) std::this_thread::yield();
+        progress.wait([&]() { return uploadsQueued.load(std::memory_order_acquire) > i || uploadFailed.load(std::memory_order_relaxed); });
         ok = !uploadFailed.load(std::memory_order_relaxed) && hipStreamWaitEvent(nullptr, static_cast<hipEvent_t>(c->evUp[b]), 0) == hipSuccess;
         if (!ok) break;
         int count = 0;
         st = reduce(c, reinterpret_cast<int *>(c->d_stageIn[b]), (int)scanned, c->d_stageOut[b], c->d_stagePos[b], &count, nullptr, nullptr);
         if (st != PFAC_STATUS_SUCCESS) break;
         scansDone.store(i + 1, std::memory_order_release);     /* the scan is synchronous: its input buffer may take piece i + 2 */
+        progress.bump();
         if (count == 0) continue;
         /* total <= off (a position has at most one pair); the pairs that stay (positions below `mine`) are at most `mine`, so they lie among the
          * first size - total of the list: the caller's arrays (size entries) hold what is copied */
@@ -440,6 +504,7 @@ PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t 
     }
     if (!ok && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;
     stopUploads.store(true);
+    progress.bump();
     if (uploader.joinable()) uploader.join();
     const bool drained = hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
     if (!drained && st == PFAC_STATUS_SUCCESS) st = PFAC_STATUS_INTERNAL_ERROR;

@@ -107,6 +107,51 @@ PFAC_status_t onDevices(PFAC_handle_t handle, size_t size, int numDevices, const
     return PFAC_STATUS_SUCCESS;
 }
 
+/* A handle on a CPU platform (PFAC_setPlatform, or PFACX_createHostOnly) has no devices to shard over; the two calls then run their `numDevices`
+ * workers (0 = one) as host threads over the CPU matchers: the same slices, the same read-ahead, the same rebasing and moving-together of the
+ * pairs -- what a machine without a GPU can exercise of this file (tests/test_host_api.py runs eight workers).  Worker i gets the results of
+ * positions [bound[i], bound[i + 1]) in a vector of its own (its matcher reads, and writes results for, the maxPatternLen bytes behind its
+ * slice too: the neighbour's positions). */
+template <class Take>
+PFAC_status_t onCpuWorkers(PFAC_handle_t handle, const char *in, size_t size, int numDevices, std::vector<size_t> &bound, Take take)
+{
+    std::lock_guard<std::mutex> guard(handle->lock);
+    PFAC_context *c = handle;
+    PFAC_status_t st = prepareCpuPlatformLocked(c);
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    const size_t workers = numDevices > 0 ? (size_t)numDevices : 1;
+    const size_t overlap = (size_t)c->fa.maxPatternLen;
+    bound.assign(workers + 1, 0);
+    for (size_t i = 1; i < workers; i++) {
+        size_t b = (size * i / workers) / 1024 * 1024;
+        bound[i] = b > bound[i - 1] ? b : bound[i - 1];
+    }
+    bound[workers] = size;
+    std::vector<PFAC_status_t> status(workers, PFAC_STATUS_SUCCESS);
+    auto work = [&](size_t i) {
+        const size_t lo = bound[i], hi = bound[i + 1];
+        if (hi == lo) return;
+        const size_t scanned = size - lo < hi - lo + overlap ? size - lo : hi - lo + overlap;
+        try {
+            std::vector<int> res(scanned);
+            status[i] = matchHostOnCpuPlatformPrepared(c, in + lo, scanned, res.data());
+            if (status[i] == PFAC_STATUS_SUCCESS) take(i, lo, hi, res.data());
+        } catch (const std::bad_alloc &) { status[i] = PFAC_STATUS_ALLOC_FAILED; }
+    };
+    std::vector<std::thread> threads;
+    try {
+        for (size_t i = 1; i < workers; i++) threads.emplace_back(work, i);
+    } catch (...) {
+        for (auto &t : threads) t.join();
+        return PFAC_STATUS_ALLOC_FAILED;
+    }
+    work(0);
+    for (auto &t : threads) t.join();
+    for (PFAC_status_t s : status)
+        if (s != PFAC_STATUS_SUCCESS) return s;
+    return PFAC_STATUS_SUCCESS;
+}
+
 } // namespace
 
 extern "C" {
@@ -125,6 +170,10 @@ PFAC_status_t PFACX_matchFromHostMultiGPU(PFAC_handle_t handle, char *h_inputStr
     if (!h_inputString || !h_matched_result || numDevices < 0) return PFAC_STATUS_INVALID_PARAMETER;
     if (size == 0) return PFAC_STATUS_SUCCESS;
     std::vector<size_t> bound;
+    if (handle->platform != PFAC_PLATFORM_GPU)
+        return onCpuWorkers(handle, h_inputString, size, numDevices, bound, [&](size_t, size_t lo, size_t hi, const int *res) {
+            std::memcpy(h_matched_result + lo, res, (hi - lo) * sizeof(int));
+        });
     return onDevices(handle, size, numDevices, devices, bound, [&](PFAC_context *w, size_t, size_t lo, size_t hi) {
         return matchHostOnGpu(w, h_inputString + lo, hi - lo, size - lo, h_matched_result + lo);
     });
@@ -145,12 +194,24 @@ PFAC_status_t PFACX_matchFromHostReduceMultiGPU(PFAC_handle_t handle, char *h_in
     *h_num_matched = 0;
     if (size == 0) return PFAC_STATUS_SUCCESS;
     std::vector<size_t> bound;
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
-    std::vector<int> counts((size_t)(numDevices ? numDevices : visible), 0);      /* one per worker */
-    const PFAC_status_t st = onDevices(handle, size, numDevices, devices, bound, [&](PFAC_context *w, size_t i, size_t lo, size_t hi) {
-        return matchHostReduceOnGpu(w, h_inputString + lo, hi - lo, size - lo, lo, h_matched_result + lo, h_pos + lo, &counts[i]);
-    });
+    std::vector<int> counts;                                                     /* one per worker */
+    PFAC_status_t st;
+    if (handle->platform != PFAC_PLATFORM_GPU) {
+        counts.assign((size_t)(numDevices ? numDevices : 1), 0);
+        st = onCpuWorkers(handle, h_inputString, size, numDevices, bound, [&](size_t i, size_t lo, size_t hi, const int *res) {
+            int z = 0;                                                           /* the slice's pairs at the slice's own offset, positions counted from the start of the stream */
+            for (size_t k = 0; k < hi - lo; k++)
+                if (res[k] > 0) { h_matched_result[lo + (size_t)z] = res[k]; h_pos[lo + (size_t)z] = (int)(lo + k); z++; }
+            counts[i] = z;
+        });
+    } else {
+        int visible = 0;
+        if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) { (void)hipGetLastError(); return PFAC_STATUS_LIB_NOT_EXIST; }
+        counts.assign((size_t)(numDevices ? numDevices : visible), 0);
+        st = onDevices(handle, size, numDevices, devices, bound, [&](PFAC_context *w, size_t i, size_t lo, size_t hi) {
+            return matchHostReduceOnGpu(w, h_inputString + lo, hi - lo, size - lo, lo, h_matched_result + lo, h_pos + lo, &counts[i]);
+        });
+    }
     if (st != PFAC_STATUS_SUCCESS) return st;
     size_t total = 0;
     for (size_t i = 0; i + 1 < bound.size(); i++) {

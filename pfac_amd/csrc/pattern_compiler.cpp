@@ -409,7 +409,13 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
     struct ThinStop { uint32_t h; int depth; int state; };
     std::vector<ThinStop> thinStops;
     std::vector<uint32_t> allHashes;
+    std::vector<unsigned char> goOn((size_t)fa.numStates, 0);          /* states that are G nodes of the ladder */
+    std::vector<std::pair<uint32_t, int>> skipFrom;                     /* G nodes at depth kSkipFromDepth: (hash, state) */
     LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast}.run([&](uint32_t h, int depth, bool stop, int state, bool thinStop) {
+        if (!stop) {
+            goOn[(size_t)state] = 1;
+            if (depth == kSkipFromDepth) skipFrom.emplace_back(h, state);
+        }
         if (stop) {
             setBit(f.ladder, ladderBitS1(h, f.log2BitsLad));
             setBit(f.ladder, ladderBitS2(h, f.log2BitsLad));
@@ -420,6 +426,27 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
         allHashes.push_back(h);
         if (thinStop && below[(size_t)state] == 1) thinStops.push_back({h, depth, state});
     });
+    /* skip tags (struct Filter): depth-6 G nodes with a single path of G nodes down to kLadderLast */
+    f.skipCount = 0;
+#ifndef PFAC_NO_SKIP_TAGS
+    if (f.ladderLast >= kLadderLast) {
+        std::vector<uint32_t> sortedHashes(allHashes);
+        std::sort(sortedHashes.begin(), sortedHashes.end());
+        for (const auto &from : skipFrom) {
+            if (f.skipCount >= kSkipTagsMax) break;
+            auto r = std::equal_range(sortedHashes.begin(), sortedHashes.end(), from.first);
+            if (r.second - r.first != 1) continue;                      /* another ladder node has this hash */
+            int s = from.second;
+            bool single = true;
+            for (int d = kSkipFromDepth; d < kLadderLast && single; d++) {
+                /* one way on, nothing ends here; the ladder's own nodes on the way (every second depth) must be G nodes: no stop among them */
+                single = s > F && fa.edgeBegin[s + 1] - fa.edgeBegin[s] == 1 && (((d - kLadderFirst) % kLadderStep) != 0 || goOn[(size_t)s]);
+                if (single) s = fa.edgeNext[fa.edgeBegin[s]];
+            }
+            if (single) f.skipTags[f.skipCount++] = from.first;         /* (the node at kLadderLast is tested like any other) */
+        }
+    }
+#endif
     /* the tail table (struct Filter): the rest of the one pattern below a thin stop */
     f.tail.clear();
     f.log2Tail = 0;
@@ -497,7 +524,7 @@ void buildFilter(const Automaton &fa, Filter &f)
      * holds -- Snort-scale --, keeps the table in device memory (VETO = 2: one gathered load per stopped candidate, round 6); round 5 gave
      * such a set the ladder of rounds 3 and 4 and no veto at all.  A set has one form or the other. */
     const size_t lds = kGram3LdsBytes + ((size_t(1) << f.log2BitsLad) + (size_t(1) << f.log2BitsF3)) / 8 + (f.hasShort ? 65536 / 8 : 0) + f.tail.size() * sizeof(uint32_t);
-    const bool inLds = !f.tail.empty() && lds <= kFilterLdsBudget && f.tailEntries * 16 >= f.tailCandidates * 15;      /* (a table that lost more than a sixteenth of its entries to full slots is too small) */
+    const bool inLds = !f.tail.empty() && lds <= kFilterLdsBudget && f.tailEntries * 2 >= f.tailCandidates;      /* (a table that holds less than half of the thin stops is too small: a set of tens of thousands of patterns) */
 #ifdef PFAC_NO_GLOBAL_TAIL
     if ((f.ladderLast > kLadderLast || !f.tail.empty()) && !inLds) { buildFilterImpl(fa, f, /*allowDeep=*/false); return; }
 #endif

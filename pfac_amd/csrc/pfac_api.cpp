@@ -48,6 +48,10 @@ void freeTables(PFAC_context *c)
     devFree(c->d_hashRow);
     devFree(c->d_hashVal);
     devFree(c->d_chainSlots);
+    devFree(c->d_denseFast);
+    c->denseFastEntries = 0;
+    devFree(c->d_chainNarrow);
+    c->numChainNarrow = 0;
     std::vector<pfac::ChainSlot>().swap(c->h_chainSlots);
     c->numChainSlots = 0;
     c->chainJumpLog2 = 0;
@@ -115,7 +119,35 @@ PFAC_status_t uploadChainedHashTable(PFAC_context *c)
     if (!c->hasDevice) return PFAC_STATUS_SUCCESS;
     c->numChainSlots = c->h_chainSlots.size();
     st = upload(c->d_chainSlots, c->h_chainSlots.data(), c->h_chainSlots.size());
-    return st;
+    if (st != PFAC_STATUS_SUCCESS) return st;
+    {   /* the narrow form for the tiled kernel on text (pfac_context.h); without it that kernel walks the wide one */
+        std::vector<pfac::ChainSlot> narrow;
+        int lg = 0;
+        if (pfac::buildChainedHashTable(c->fa, narrow, lg, /*narrow=*/true) == PFAC_STATUS_SUCCESS && !narrow.empty() &&
+            upload(c->d_chainNarrow, narrow.data(), narrow.size()) == PFAC_STATUS_SUCCESS) {
+            c->numChainNarrow = narrow.size();
+            c->chainNarrowJumpLog2 = lg;
+        } else {
+            devFree(c->d_chainNarrow);
+            c->numChainNarrow = 0;
+            (void)hipGetLastError();
+        }
+    }
+    /* the dense table next to it for a small set that does not fold (PFAC_context::d_denseFast): states inside chains -- one way on, nothing ends there --
+     * are what the chained table saves steps on; a set with less than a quarter of them keeps int[S][256] too */
+    const pfac::Automaton &fa = c->fa;
+    if (fa.numStates > fa.initialState && fa.numStates <= pfac::kDenseFastMaxStates) {
+        size_t inside = 0;
+        for (int s = fa.initialState + 1; s < fa.numStates; s++) inside += fa.edgeBegin[s + 1] - fa.edgeBegin[s] == 1 ? 1u : 0u;      /* (final states are numbered below the initial state) */
+        if (inside * 4 < (size_t)fa.numStates) {
+            std::vector<int> dense;
+            if (!c->h_dense.empty()) dense = c->h_dense;
+            else if (pfac::buildDenseTable(fa, dense) != PFAC_STATUS_SUCCESS) dense.clear();
+            if (!dense.empty() && upload(c->d_denseFast, dense.data(), dense.size()) == PFAC_STATUS_SUCCESS) c->denseFastEntries = dense.size();
+            else { devFree(c->d_denseFast); c->denseFastEntries = 0; (void)hipGetLastError(); }      /* no table: AUTO keeps to the chained one */
+        }
+    }
+    return PFAC_STATUS_SUCCESS;
 }
 
 /* The reference-layout table of the perf mode on the HOST: the dense table is materialised on first use -- PFACX_getTable,
@@ -261,6 +293,18 @@ PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, 
     if (c->platform == PFAC_PLATFORM_CPU_OMP) omp = (std::getenv("OMP_NUM_THREADS") != nullptr);
     std::shared_lock<std::shared_mutex> r(c->tablesInUse);             /* a setter on another thread waits until the match is through */
     if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) return PFAC_STATUS_PATTERNS_NOT_READY;   /* ... or has just replaced the set: its tables are built on the next call */
+    return pfac::matchOnCpu(c, reinterpret_cast<const unsigned char *>(in), n, out, omp);
+}
+
+/* ... for a caller that holds c->lock and drives several threads through one handle (multi_gpu.cpp: the workers of a CPU-platform handle):
+ * the tables first, once; then any number of threads may match side by side */
+PFAC_status_t prepareCpuPlatformLocked(PFAC_context *c) { return ensureHostRefTable(c); }
+PFAC_status_t matchHostOnCpuPlatformPrepared(PFAC_context *c, const char *in, size_t n, int *out)
+{
+    bool omp = false;
+    if (c->platform == PFAC_PLATFORM_CPU_OMP) omp = (std::getenv("OMP_NUM_THREADS") != nullptr);
+    std::shared_lock<std::shared_mutex> r(c->tablesInUse);
+    if (c->perfMode == PFAC_TIME_DRIVEN && c->h_dense.empty()) return PFAC_STATUS_PATTERNS_NOT_READY;
     return pfac::matchOnCpu(c, reinterpret_cast<const unsigned char *>(in), n, out, omp);
 }
 
@@ -557,6 +601,7 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         v.filterTailEntries = handle->filter.tailEntries;
         v.filterTailGlobalEntries = handle->filter.tailGEntries;
         v.filterLog2TailGlobal = handle->filter.tailG.empty() ? 0 : handle->filter.log2TailG;
+        v.filterSkipTags = handle->filter.skipCount;
         v.trailingBytesIgnored = handle->fa.trailingBytes;
         v.chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
         v.chainSlots = handle->h_chainSlots.size();
@@ -565,7 +610,9 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
          * counters -- and the reference-layout table only while PFACX_KERNEL_REFTABLE has asked for it */
         size_t dev = 0;
         if (handle->d_chainSlots) dev += handle->numChainSlots * sizeof(pfac::ChainSlot);
+        if (handle->d_chainNarrow) dev += handle->numChainNarrow * sizeof(pfac::ChainSlot);
         if (handle->d_dense) dev += handle->h_dense.size() * sizeof(int);
+        if (handle->d_denseFast) dev += handle->denseFastEntries * sizeof(int);
         if (handle->d_hashRow) dev += handle->h_hashRow.size() * sizeof(Int2);
         if (handle->d_hashVal) dev += handle->h_hashVal.size() * sizeof(Int2);
         if (handle->d_initialRow) dev += handle->h_initialRow.size() * sizeof(int);
@@ -630,6 +677,8 @@ PFAC_status_t PFACX_getTable(PFAC_handle_t handle, PFACX_table_t which, const vo
         *ptr = handle->filter.tail.data(); *bytes = handle->filter.tail.size() * sizeof(uint32_t); break;
     case PFACX_TABLE_FILTER_TAIL_GLOBAL:
         *ptr = handle->filter.tailG.data(); *bytes = handle->filter.tailG.size() * sizeof(uint32_t); break;
+    case PFACX_TABLE_FILTER_SKIP:
+        *ptr = handle->filter.skipTags; *bytes = (size_t)handle->filter.skipCount * sizeof(uint32_t); break;
     case PFACX_TABLE_CHAIN: {
         if (handle->h_chainSlots.empty()) {
             const PFAC_status_t st = uploadChainedHashTable(handle);      /* host-only handle: builds, uploads nothing */
@@ -663,6 +712,15 @@ PFAC_status_t PFACX_trim(PFAC_handle_t handle)
     handle->denseListEntries = 0;
     for (auto &child : handle->children) if (child.second) (void)PFACX_trim(child.second);
     return PFAC_STATUS_SUCCESS;
+}
+
+PFAC_status_t PFACX_prepare(PFAC_handle_t handle, size_t maxBytes)
+{
+    if (!handle) return PFAC_STATUS_INVALID_HANDLE;
+    if (!handle->isPatternsReady) return PFAC_STATUS_PATTERNS_NOT_READY;
+    if (handle->platform != PFAC_PLATFORM_GPU) return PFAC_STATUS_SUCCESS;       /* the CPU platforms keep nothing between calls */
+    std::lock_guard<std::mutex> guard(handle->lock);
+    return prepareHostPath(handle, maxBytes);
 }
 
 PFAC_status_t PFACX_getScanStats(PFAC_handle_t handle, PFACX_scan_stats_t *stats)

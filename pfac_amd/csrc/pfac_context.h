@@ -157,6 +157,14 @@ struct Filter {
     size_t tailCandidates = 0;                /* thin stops that asked for an entry (of either form) */
     int ladderExtend = 0;                     /* ... after this many more levels (0: at once): the deeper test spares the walk of a candidate that
                                                  shares a pattern's prefix up to the thin node and no further */
+    /* Skip tags (round 6): the ladder hash of a depth-6 node from which ONE path leads down to depth kLadderLast without a pattern ending on the
+     * way and without a thin node (several patterns share at least kLadderLast bytes: BASELINE config 5's 24-byte prefix).  A candidate whose
+     * depth-6 hash is such a tag need not be asked about the levels in between: its hash at kLadderLast covers every byte up to there, so whatever
+     * does not follow the path dies at that level.  A wave skips a level nobody has to be asked about.  Exact, not a Bloom bit: a tag exists only for a hash
+     * no other ladder node shares, so a match -- whose nodes are real nodes -- can only be told to skip by its own path's tag (a stray bit could
+     * make a candidate skip the level at which its pattern ends).  The kernels take them as arguments (scalar registers): at most kSkipTagsMax. */
+    uint32_t skipTags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int skipCount = 0;
     std::vector<uint32_t> gram3;              /* 2^log2Bits bits, key c0|c1<<8|c2<<16            */
     std::vector<uint32_t> ladder;             /* 2^log2BitsLad bits                              */
     std::vector<uint32_t> final3;             /* 2^log2BitsF3 bits, 3-byte patterns              */
@@ -169,6 +177,8 @@ struct Filter {
     std::vector<uint32_t> prefix4;            /* 2^kPrefix4Log2 bits */
 };
 constexpr int kGram1Log2 = 19, kPrefix4Log2 = 17;
+constexpr int kSkipTagsMax = 8, kSkipFromDepth = 6;
+constexpr int kDenseFastMaxStates = 8192;      /* 8 MiB of int[S][256]: stays in L2 */
 
 /* the ladder's hash: h(4) = (first four bytes, little endian) * kLadMul0; h(d) = (h(d-2) ^ (bytes d-2, d-1 as a 16-bit
  * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
@@ -243,9 +253,20 @@ struct PFAC_context {
     pfac::Int2 *d_hashRow = nullptr;
     pfac::Int2 *d_hashVal = nullptr;
     int *d_initialRow = nullptr;
+    /* A small pattern set whose states hardly fold into chains (most states final or branching: the patterns a, aa, ..., a x 8 of the all-match test) gains
+     * nothing from the chained table -- a step consumes one byte either way, and the chained step is three times the instructions of one gathered dword of
+     * int[S][256].  Such a set also keeps the DENSE table on the device (S KiB, at most kDenseFastMaxStates states), in both perf modes, and
+     * PFACX_KERNEL_AUTO sends the big calls of a pattern-dense stream to the tiled frame over it (scan_module.hip: scan) */
+    int *d_denseFast = nullptr;
+    size_t denseFastEntries = 0;
     std::vector<pfac::ChainSlot> h_chainSlots;               /* host copy of the chained table (PFACX_saveCompiled)       */
     pfac::ChainSlot *d_chainSlots = nullptr;  /* device-only chained form of hashRow/hashVal (tables.cpp)          */
     size_t numChainSlots = 0;
+    /* the NARROW chained table (tables.cpp: no wide buckets, no long jump table, no units): what the tiled kernel walks while the handle's stream
+     * is not full of near misses; device only (built from the trie with the set, dropped with it) */
+    pfac::ChainSlot *d_chainNarrow = nullptr;
+    size_t numChainNarrow = 0;
+    int chainNarrowJumpLog2 = 0;
     int chainJumpLog2 = 0;                    /* the chained table is N = numChainSlots / 2 slot headers, then as many extension units; the last
                                                  2^J headers are the LONG jump table, the 2^J before them the jump table, the 256 before
                                                  those the initial state's bucket: buckets | root(256) | jump(2^J) | long jump(2^J) | N units

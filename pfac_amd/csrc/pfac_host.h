@@ -20,7 +20,7 @@ PFAC_status_t buildDenseTable(const Automaton &fa, std::vector<int> &dense);
 PFAC_status_t buildHashTable(const Automaton &fa, std::vector<Int2> &rowPtr,
                              std::vector<Int2> &valPtr);
 
-PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2);
+PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2, bool narrow = false);
 
 /* cpu_engine.cpp: PFAC_PLATFORM_CPU / PFAC_PLATFORM_CPU_OMP */
 PFAC_status_t matchOnCpu(const PFAC_context *ctx, const unsigned char *in, size_t n, int *out,
@@ -65,7 +65,10 @@ PFAC_status_t bindTable(PFAC_context *c);
 PFAC_status_t bindCommon(PFAC_context *c, bool build = true);
 void correctTextureMode(PFAC_context *c);
 PFAC_status_t matchHostOnCpuPlatform(PFAC_context *c, const char *in, size_t n, int *out);
+PFAC_status_t prepareCpuPlatformLocked(PFAC_context *c);                                        /* the caller holds c->lock */
+PFAC_status_t matchHostOnCpuPlatformPrepared(PFAC_context *c, const char *in, size_t n, int *out);   /* ... has called the above; any number of threads */
 /* host_pipeline.cpp: the caller holds c->lock */
+PFAC_status_t prepareHostPath(PFAC_context *c, size_t maxBytes);
 PFAC_status_t matchDeviceLocked(PFAC_context *c, char *d_inputString, size_t size, int *d_matched_result);
 PFAC_status_t matchHostOnGpu(PFAC_context *c, char *h_inputString, size_t owned, size_t readable, int *h_matched_result);
 PFAC_status_t matchHostReduceOnGpu(PFAC_context *c, char *h_inputString, size_t size, size_t readable, size_t posBase, int *h_matched_result, int *h_pos, int *h_num_matched);

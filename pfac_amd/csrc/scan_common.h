@@ -57,6 +57,8 @@ struct ScanArgs {
     const uint32_t *shortBits;
     int log2Bits, log2BitsLad, log2BitsF3;
     int ladderLast;                                    /* deepest level of the prefix ladder (pfac::Filter::ladderLast): behind kLadderLast only the VETO kernels look */
+    int skipCount;                                     /* skip tags (pfac::Filter): depth-6 ladder hashes whose candidates are next asked at kLadderLast */
+    uint32_t skipTags[pfac::kSkipTagsMax];
     int numFinal;
     int initialState;
     unsigned int *work;                                /* pfac::kWorkCounterWords zeroed counters: next chunk of each input part */
@@ -802,6 +804,8 @@ hipError_t launchFilterKernel(const PFAC_context *c, const ScanArgs &a, bool tex
 /* scan_tiled.hip: the tiled kernel over the chained table; and "whatever is not the filter kernel's" (PFACX_KERNEL_REFTABLE: over the reference-layout table of the perf mode) */
 hipError_t launchTiledKernel(const PFAC_context *c, const ScanArgs &a, bool tex);
 hipError_t launchSimpleKernel(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part);
+/* ... the tiled frame over part.dense = int[S][256] whatever the perf mode and the kernel variant (PFAC_context::d_denseFast) */
+hipError_t launchDenseTableKernel(const PFAC_context *c, bool tex, const ScanArgs &part);
 }
 
 #endif /* PFAC_SCAN_COMMON_H_ */

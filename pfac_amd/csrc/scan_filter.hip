@@ -49,6 +49,11 @@ constexpr uint32_t kListCap = PFAC_LIST_CAP;  /* 16-bit hit codes per wave; more
                                                 * full ones (C5 1.559 / 1.545 / 1.532 ms with 16 / 32 / 48; 64 = 48; C3 unchanged) */
 #endif
 constexpr uint32_t kAppendMin = PFAC_APPEND_MIN;
+#ifndef PFAC_MERGE_MIN
+#define PFAC_MERGE_MIN 48                      /* tested candidates left in the list while the chunk has more hits: fewer than this wait for the next list round */
+#endif
+constexpr uint32_t kMergeMin = PFAC_MERGE_MIN;
+static_assert(kMergeMin <= 64 && kMergeMin < kListCap, "left-over candidates are moved to the list's head one per lane");
 #ifndef PFAC_PATCH_STAGED
 #define PFAC_PATCH_STAGED 0                    /* full-result kernel: 1 = finished matches are staged per wave in LDS and stored kReduceCap at a time */
 #endif
@@ -402,6 +407,15 @@ void pfac_scan_filter(ScanArgs a)
     };
     constexpr uint32_t kRefillBatch = (uint32_t)PFAC_REFILL_BATCH < kQCap / 2 ? (uint32_t)PFAC_REFILL_BATCH : kQCap / 2;   /* the ladder stops feeding a queue with less than 16 free entries */
     bool flushWalks = false;                        /* nothing left to filter: queued walks start however few they are */
+#ifndef PFAC_WALK_GATE
+#define PFAC_WALK_GATE 48                      /* 0: a walker round in every trip (rounds 2 - 5) */
+#endif
+#ifndef PFAC_WALK_GATE_TRIPS
+#define PFAC_WALK_GATE_TRIPS 4
+#endif
+    constexpr bool kWalkGated = !REDUCE && !kStageWalk && kWalkSets == 1 && PFAC_WALK_GATE > 0;
+    constexpr uint32_t kWalkGate = PFAC_WALK_GATE, kWalkGateTrips = PFAC_WALK_GATE_TRIPS;
+    uint32_t walkIdleTrips = 0;
     /* hand verified queue entries to idle walker lanes */
     auto walkRefill = [&]() {
 #pragma unroll
@@ -759,14 +773,28 @@ void pfac_scan_filter(ScanArgs a)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         PFAC_TICK(8);
         if constexpr (kVetoG) { if (pendAny) tailResolve(); }
-        walkConsume();
-        PFAC_TICK(0);
         flushWalks = chunk == kEnd && listAt == listEnd;
-        /* ---- 2. hand idle walker lanes new positions, start the next transition of
-         *         every live walk */
-        walkRefill();
-        PFAC_TICK(1);
-        walkIssue();
+        /* The walkers of the window-walker kernels do not run in every trip (round 6).  A round -- consume, refill, issue -- costs the wave the
+         * same ~250 instructions for five live walks as for sixty-four, and behind the prefilter a chunk leaves six to eight walks (text: 3.3 M
+         * walks per GiB, 22 lane steps per chunk: rounds were a third full; the near-miss streams behind the veto the same), on streams whose
+         * launches are bound by instruction issue.  A round runs when live + queued walks would fill kWalkGate lanes, when the queue is half
+         * full, at the end of the wave's input -- and after kWalkGateTrips trips without one, so that no walk waits long.  The slots loaded by
+         * the last round stay in their registers meanwhile (the top-of-trip wait has seen them arrive). */
+        bool walkRound = true;                                  /* wave-uniform */
+        if constexpr (kWalkGated) {
+            const uint32_t live = (uint32_t)__popcll(__ballot(alive[0])), queued = qv - qh;
+            walkRound = flushWalks || live + queued >= kWalkGate || queued >= kQCap / 2 || walkIdleTrips >= kWalkGateTrips;
+            walkIdleTrips = walkRound ? 0u : walkIdleTrips + 1u;
+        }
+        if (walkRound) {
+            walkConsume();
+            PFAC_TICK(0);
+            /* ---- 2. hand idle walker lanes new positions, start the next transition of
+             *         every live walk */
+            walkRefill();
+            PFAC_TICK(1);
+            walkIssue();
+        }
         PFAC_TICK(2);
         if (listAt == listEnd && __ballot(hits != 0) == 0) {
             /* kStageWalk: the next chunk goes into the buffer of the chunk before the one just filtered -- once no walk reads that
@@ -925,11 +953,22 @@ void pfac_scan_filter(ScanArgs a)
         }
         /* ---- 4. the lanes' hits -> one list of 16-bit codes (lane << 5 | bit), slot = prefix sum of the hit
          *         counts; hits beyond the list's capacity stay in `hits` for the next trip */
-        if (listAt == listEnd && __ballot(hits != 0) != 0) {
+        /* (full-result kernel: also when fewer than kMergeMin tested candidates are left over while the chunk still has hits to list -- the next hits are
+         * listed behind them and one batch of the ladder takes them together.  A batch costs the wave the same ~600 instructions for 20 candidates as
+         * for 64, and a chunk with more level-1 hits than the list holds -- a Snort-scale set over alphanumeric text: 170 -- used to pay for two or
+         * three of them: BASELINE config 5's stream over the 31 000-pattern set, 2.3 batches per chunk -> 1.) */
+        if ((listAt == listEnd || (!REDUCE && listEnd - listAt < kMergeMin)) && __ballot(hits != 0) != 0) {
+            const uint32_t carry = listEnd - listAt;                /* tested candidates that stay in front of the new hits (wave-uniform) */
+            if (carry != 0 && listAt != 0) {                        /* ... at the list's head: carry < kMergeMin <= 64, one code per lane */
+                const uint32_t code = (uint32_t)lane < carry ? listCode(listAt) : 0u;
+                if ((uint32_t)lane < carry) list[lane] = (uint16_t)code;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             const uint32_t cnt = (uint32_t)__builtin_popcount(hits);
             const uint32_t incl = waveInclusiveScan(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t idx = incl - cnt;
+            uint32_t idx = carry + incl - cnt;
             PFAC_TICK(9);
             const bool dense = !REDUCE && freshChunk && total > kDenseHits && a.denseList != nullptr;      /* wave-uniform */
             if (dense) {
@@ -948,7 +987,7 @@ void pfac_scan_filter(ScanArgs a)
                 hits &= hits - 1;
             }
             PFAC_TICK(10);
-            const uint32_t listed = dense ? 0u : (total < kListCap ? total : kListCap);
+            const uint32_t listed = dense ? 0u : (total < kListCap - carry ? total : kListCap - carry);
 #ifndef PFAC_COUNT_STALLS
             stHits += listed;
 #endif
@@ -960,10 +999,10 @@ void pfac_scan_filter(ScanArgs a)
              * in place (a wave's LDS accesses execute in order: every lane has read its code before any lane writes, and
              * the k-th round writes below the codes it has read); bit 15 = "walk, whatever follows" (an S node at depth
              * 4, or a pattern of up to three bytes matches here). */
-            uint32_t kept = 0;
+            uint32_t kept = carry;
             for (uint32_t base = 0; base < listed; base += 64u) {
                 const bool act = base + (uint32_t)lane < listed;
-                const uint32_t code = act ? listCode(base) : 0u;
+                const uint32_t code = act ? listCode(carry + base) : 0u;
                 const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
                 const uint32_t at = o >> 2, sh = o & 3u;
                 const uint32_t x = __builtin_amdgcn_alignbyte(stage[at + 1], stage[at], sh);
@@ -990,7 +1029,7 @@ void pfac_scan_filter(ScanArgs a)
             }
             listAt = 0;
             listEnd = kept;
-            stCand += kept;
+            stCand += kept - carry;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             PFAC_TICK(11);
@@ -1005,6 +1044,7 @@ void pfac_scan_filter(ScanArgs a)
             const uint32_t room = kQCap - (qv - qh);
             const uint32_t take = room < want ? room : want;
             if (left == 0 || (take != want && take < kAppendMin)) break;
+            if (!REDUCE && left < kMergeMin && __ballot(hits != 0) != 0) break;      /* more of this chunk's hits are about to join them (step 4 of the next trip) */
             const bool act = (uint32_t)lane < take;
             const uint32_t code = act ? listCode(listAt) : 0u;
             const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);
@@ -1034,17 +1074,33 @@ void pfac_scan_filter(ScanArgs a)
                     const uint32_t xw = lv <= 2 ? x1 : lv <= 4 ? x2 : lv <= 6 ? x3 : x4;
                     hl[lv] = (hl[lv - 1] ^ ((lv & 1) ? (xw & 0xFFFFu) : (xw >> 16))) * pfac::kLadMul;
                 }
+                /* Skip tags (pfac::Filter): a candidate whose depth-6 hash is the tag of a single path down to kLadderLast is next asked at that level
+                 * (its hash there covers every byte on the way).  When the batch has tags -- a kernel argument: pattern sets with a long shared prefix,
+                 * BASELINE config 5 -- and nobody else is undecided behind depth 6, the wave goes from level 6 straight to the last one: six levels of
+                 * three probes each were two thirds of a batch's instructions on the near-miss stream. */
+                uint32_t skipping = 0;                                          /* 0 / 1 */
+                bool straightToLast = false;                                    /* wave-uniform */
+                if (a.skipCount != 0) {
+                    for (int k = 0; k < a.skipCount; k++) skipping |= hl[1] == a.skipTags[k] ? 1u : 0u;
+                    skipping &= und;
+                }
 #pragma unroll
                 for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
                     /* one early exit, in the middle: a check per level makes every level wait for the LDS reads of the one before
                      * it, and on text a batch almost always has a candidate that follows some long keyword to the last levels */
                     if (lv == 5 && __ballot(und != 0) == 0) break;
+                    /* (looked at behind levels 6, 8 and 10: the few candidates of OTHER patterns in a batch -- a Snort-scale set over the same stream -- are
+                     * decided by then, as a rule) */
+                    if (lv >= 2 && lv <= 4 && a.skipCount != 0 && !straightToLast) straightToLast = __ballot((und & ~skipping) != 0) == 0;
+                    if (lv >= 2 && lv < pfac::kLadderLevels - 1 && straightToLast) continue;
+                    /* who is asked at this level: the undecided, but for those on a tagged path between its first and its last level */
+                    const uint32_t act = (lv >= 2 && lv < pfac::kLadderLevels - 1) ? (und & ~skipping) : und;
                     const uint32_t h = hl[lv];
                     const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
-                    if constexpr (kVeto) stopHash = (und & sHit) ? h : stopHash;
-                    walk |= und & sHit;
+                    if constexpr (kVeto) stopHash = (act & sHit) ? h : stopHash;
+                    walk |= act & sHit;
                     if (lv == pfac::kLadderLevels - 1 && !deepLadder) und = 0;      /* the last level has S nodes only */
-                    else und &= ladProbe(h * pfac::kLadMulG) & ~sHit;
+                    else und &= ~act | (ladProbe(h * pfac::kLadMulG) & ~sHit);
                 }
                 if constexpr (kVeto) {
                     /* A deep ladder (pfac::Filter::ladderLast) goes on behind the 20 bytes wherever patterns still share a path: two more bytes of

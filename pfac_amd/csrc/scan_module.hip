@@ -146,6 +146,8 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.log2Bits = c->filter.log2Bits;
     a.log2BitsLad = c->filter.log2BitsLad;
     a.ladderLast = c->filter.ladderLast;
+    a.skipCount = c->filter.skipCount;
+    for (int k = 0; k < pfac::kSkipTagsMax; k++) a.skipTags[k] = c->filter.skipTags[k];
     a.log2BitsF3 = c->filter.log2BitsF3;
     a.numFinal = c->fa.numPatterns;
     a.maxWalk = (uint32_t)c->fa.maxPatternLen;
@@ -161,6 +163,23 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
         if ((chained > dense ? chained : dense) > 0xFFFFFFFFull) return PFAC_STATUS_CUDA_ALLOC_FAILED;
     }
     return PFAC_STATUS_SUCCESS;
+}
+
+/* the tiled kernel's table: the narrow chained table (no long slots: tables.cpp) unless the handle's last full-result filter launch found its stream
+ * full of near misses (the word the walker choice reads), or PFACX_WALKER_STAGE / _VETO says the caller expects them */
+void tiledTable(const PFAC_context *c, ScanArgs &a)
+{
+    if (c->d_chainNarrow == nullptr || c->numChainNarrow == 0) return;
+    const bool nearMisses = (c->h_modeHint != nullptr && *static_cast<volatile const unsigned int *>(c->h_modeHint) != 0) ||
+                            c->walker == PFACX_WALKER_STAGE || c->walker == PFACX_WALKER_VETO;
+    if (nearMisses) return;
+    a.chainSlots = reinterpret_cast<const u32x4 *>(c->d_chainNarrow);
+    a.jumpShift = 32u - (uint32_t)c->chainNarrowJumpLog2;
+    a.jumpBase = (uint32_t)(c->numChainNarrow - (size_t(1) << c->chainNarrowJumpLog2));
+    a.jumpLongBase = a.jumpBase;                       /* (no long jump table: nothing in the narrow table is long) */
+    a.rootRow = a.jumpBase - (uint32_t)pfac::kCharSet;
+    a.extDelta = 0;
+    a.chainBytes = clampExtent(c->numChainNarrow * sizeof(pfac::ChainSlot));
 }
 
 /* below this many positions a call takes the tiled kernel alone: ~8 us + what the positions cost instead of the filter
@@ -265,6 +284,7 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
                 rest.denseReadable = input_size - first;
                 rest.owned = 0;
                 rest.n = input_size - first;
+                tiledTable(c, rest);
                 e = pfacmod::launchTiledKernel(c, rest, tex);
             }
 #endif
@@ -278,13 +298,24 @@ PFAC_status_t scan(PFAC_handle_t handle, char *d_input_string, size_t input_size
             rest.n = input_size - first + back;
             headDone = true;
             rest.reportDense = (c->kernelVariant == PFACX_KERNEL_AUTO && vectorOk && ownEnd - first >= kSmallInput) ? 1u : 0u;   /* a big call sent here for its density: say if it still is */
-            e = pfacmod::launchSimpleKernel(c, hashed, tex, rest);
+            /* ... and if the set is one that does not fold into chains (a few all-final states: PFAC_context::d_denseFast), through the dense table:
+             * a step is one byte either way there, and one gathered dword costs a third of the chained step's instructions (input in which every
+             * position matches, 256 MiB: 94 -> 123 GB/s) */
+            if (rest.reportDense != 0 && c->d_denseFast != nullptr) {
+                rest.dense = c->d_denseFast;
+                rest.denseBytes = clampExtent(c->denseFastEntries * sizeof(int));
+                e = pfacmod::launchDenseTableKernel(c, tex, rest);
+            } else {
+                if (c->kernelVariant != PFACX_KERNEL_REFTABLE) tiledTable(c, rest);
+                e = pfacmod::launchSimpleKernel(c, hashed, tex, rest);
+            }
         }
     }
     if (e == hipSuccess && !headDone) {                 /* the whole input is in front of the first aligned byte */
         ScanArgs part = a;
         part.owned = head;
         part.n = input_size;
+        if (c->kernelVariant != PFACX_KERNEL_REFTABLE) tiledTable(c, part);
         e = pfacmod::launchSimpleKernel(c, hashed, tex, part);
     }
     return e == hipSuccess ? PFAC_STATUS_SUCCESS : PFAC_STATUS_INTERNAL_ERROR;
@@ -364,6 +395,7 @@ PFAC_status_t reduceScan(PFAC_handle_t handle, int *d_input_string, int input_si
         ScanArgs part = a;
         part.owned = n;
         part.reduceBase = 0;
+        if (c->kernelVariant != PFACX_KERNEL_REFTABLE) tiledTable(c, part);
         if (pfacmod::launchSimpleKernel(c, hashed, tex, part) != hipSuccess) return PFAC_STATUS_INTERNAL_ERROR;
     }
 #if PFAC_REDUCE_TRACE

@@ -940,4 +940,5 @@ hipError_t launchSimple(const PFAC_context *c, bool hashed, bool tex, const Scan
 namespace pfacmod {
 hipError_t launchTiledKernel(const PFAC_context *c, const ScanArgs &a, bool tex) { return tex ? launchTiled<true>(c, a) : launchTiled<false>(c, a); }
 hipError_t launchSimpleKernel(const PFAC_context *c, bool hashed, bool tex, const ScanArgs &part) { return launchSimple(c, hashed, tex, part); }
+hipError_t launchDenseTableKernel(const PFAC_context *c, bool tex, const ScanArgs &part) { return tex ? launchTiledRef<DENSE_BUFFER>(c, part) : launchTiledRef<DENSE_GLOBAL>(c, part); }
 }

@@ -169,8 +169,10 @@ struct ChainBuilder {
     bool failed = false;
     size_t wideBuckets = 0, longSlots = 0;
 
-    ChainBuilder(const Automaton &a, std::vector<ChainSlot> &out)
-        : fa(a), slots(out), bucketOff((size_t)a.numStates, -1), bucketKS((size_t)a.numStates, 0u) {}
+    bool wideBuckets_ = PFAC_WIDE_BUCKETS != 0;    /* false: every chain <= kChainMax (the table of rounds 2-4; the NARROW table of round 6) */
+
+    ChainBuilder(const Automaton &a, std::vector<ChainSlot> &out, bool wideOn)
+        : fa(a), slots(out), bucketOff((size_t)a.numStates, -1), bucketKS((size_t)a.numStates, 0u), wideBuckets_(wideOn && PFAC_WIDE_BUCKETS != 0) {}
 
     static ChainSlot emptySlot()
     {
@@ -225,7 +227,7 @@ struct ChainBuilder {
         }
         if (k < 0) { failed = true; return; }      /* cannot happen: k = 128, S = 256 is the identity */
         bool wide = false;
-        if (PFAC_WIDE_BUCKETS)
+        if (wideBuckets_)
             for (int i = b; i < e && !wide; i++) wide = naturalChain(fa.edgeNext[i], kChainMax + 1) > kChainMax;
         bucketOff[state] = (int)slots.size();
         bucketKS[state] = ((uint32_t)wide << 16) | ((uint32_t)k << 8) | (uint32_t)(S - 1);
@@ -296,7 +298,11 @@ struct ChainBuilder {
 
 } // namespace
 
-PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2)
+/* narrow = true (round 6): the same table without wide buckets, long jump table and extension units -- N' = buckets + 256 + 2^J headers and nothing
+ * else.  The tiled kernel walks it on streams that are not full of near misses (calls below 32 MiB, pattern-dense chunks): a long slot's unit is
+ * fetched on the spot there, the whole wave waiting, and on text nearly every step of a wave's 256 walks had one or two lanes at such a slot
+ * (C3 through the tiled kernel alone: 704-757 GB/s before the wide buckets, 652-680 with them). */
+PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> &slots, int &jumpLog2, bool narrow)
 {
     const int F = fa.numPatterns, init = fa.initialState;
     /* 4-byte prefixes: {key, state at depth 4} */
@@ -306,6 +312,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         slots.clear();
         if (fa.numStates <= init) {                                /* no patterns: root row + smallest jump table, all empty */
             jumpLog2 = kJumpLog2Min;
+            if (narrow) { slots.assign((size_t)kCharSet + (size_t(1) << jumpLog2), ChainBuilder::emptySlot()); return PFAC_STATUS_SUCCESS; }
             slots.assign((size_t)kCharSet + (size_t(2) << jumpLog2), ChainBuilder::emptySlot());
             slots.resize(2 * slots.size(), ChainBuilder::zeroUnit());
             return PFAC_STATUS_SUCCESS;
@@ -331,7 +338,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
 #define PFAC_JUMP_SPARSITY 8                   /* jump slots per 4-byte pattern prefix (a prefix that finds its slot taken walks from the initial state) */
 #endif
         while (jumpLog2 < kJumpLog2Max && (size_t(1) << jumpLog2) < (size_t)PFAC_JUMP_SPARSITY * prefixes.size()) jumpLog2++;
-        ChainBuilder b(fa, slots);
+        ChainBuilder b(fa, slots, !narrow);
         std::vector<ChainSlot> root((size_t)kCharSet, ChainBuilder::emptySlot()), jump(size_t(1) << jumpLog2, ChainBuilder::emptySlot());
         /* the LONG jump table: the same prefixes in the same places, but a slot folds up to kChainMaxWide bytes (chain bytes 8.. in
          * its extension unit): the start of a walker that expects long single-successor runs (scan_common.h: StageLane) */
@@ -344,6 +351,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
             if (!(dst.meta & kSlotEmpty)) continue;            /* taken: this prefix walks from the initial state */
             const unsigned char rest[3] = {(unsigned char)(p.key >> 8), (unsigned char)(p.key >> 16), (unsigned char)(p.key >> 24)};
             dst = b.makeSlot((int)(p.key & 0xFFu), p.state, kChainMax, rest, 3).hdr;
+            if (narrow) continue;
             const BuiltSlot wide = b.makeSlot((int)(p.key & 0xFFu), p.state, PFAC_WIDE_BUCKETS ? kChainMaxWide : kChainMax, rest, 3);
             jumpLong[jumpHash(p.key, jumpLog2)] = wide.hdr;
             std::memcpy(&jumpLongUnits[jumpHash(p.key, jumpLog2)], wide.ext, sizeof(wide.ext));
@@ -352,6 +360,7 @@ PFAC_status_t buildChainedHashTable(const Automaton &fa, std::vector<ChainSlot> 
         if (b.failed) return PFAC_STATUS_INTERNAL_ERROR;
         slots.insert(slots.end(), root.begin(), root.end());
         slots.insert(slots.end(), jump.begin(), jump.end());
+        if (narrow) return PFAC_STATUS_SUCCESS;
         /* the extension units, slot for slot: unit i belongs to slot i (root row and the short jump table never have one) */
         b.units.resize(slots.size(), ChainBuilder::zeroUnit());
         slots.insert(slots.end(), jumpLong.begin(), jumpLong.end());

@@ -57,5 +57,40 @@ class Event:
             pass
 
 
+def pci_bus_id(device: int) -> str:
+    """"0000:05:00.0" of a HIP device (hipDeviceGetPCIBusId), or "" if the runtime does not say."""
+    rt = _rt()
+    buf = C.create_string_buffer(64)
+    try:
+        rt.hipDeviceGetPCIBusId.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        if rt.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return ""
+    except AttributeError:
+        return ""
+    return buf.value.decode(errors="replace").lower()
+
+
+def pci_code(bus_id: str) -> int:
+    """domain:bus:device.function as one integer (domain << 24 | bus << 16 | device << 8 | function): what a rank puts among its gathered int64 facts; -1 = unknown"""
+    try:
+        dom, bus, rest = bus_id.split(":")
+        dev, fn = rest.split(".")
+        return (int(dom, 16) << 24) | (int(bus, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16)
+    except ValueError:
+        return -1
+
+
+def pci_string(code: int) -> str:
+    return "" if code < 0 else "%04x:%02x:%02x.%x" % (code >> 24, (code >> 16) & 0xFF, (code >> 8) & 0xFF, code & 0xFF)
+
+
+def numa_node_of_pci(bus_id: str) -> int:
+    """NUMA node of a PCI device from sysfs (-1: unknown, or a single-node machine that says so)"""
+    try:
+        return int(open(f"/sys/bus/pci/devices/{bus_id}/numa_node").read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
 def device_synchronize():
     _ok(_rt().hipDeviceSynchronize(), "hipDeviceSynchronize")

@@ -52,16 +52,21 @@ def prefilter_model(h, data, veto=True):
     und = cand & ~walk
     stop_hash = np.zeros(n, dtype=np.uint64)          # the ladder hash of the level (>= 6) at which a position was told to stop
     stopped = np.zeros(n, dtype=bool)
+    skip_tags = h.table(api.PFACX_TABLE_FILTER_SKIP).astype(np.uint64)
+    skipping = np.zeros(n, dtype=bool)                 # on a tagged path: not asked about the levels between 6 and LADDER_LAST
     for depth in range(6, (last if veto else LADDER_LAST) + 2, 2):
         piece = d[depth - 2:n + depth - 2] | (d[depth - 1:n + depth - 1] << u(8))
         hh = ((hh ^ piece) * u(LAD_MUL)) & m32
+        if depth == 6 and skip_tags.size:
+            skipping = und & np.isin(hh, skip_tags)
+        asked = und & ~skipping if 6 < depth < LADDER_LAST else und
         s = stop(hh)
-        first = und & s
+        first = asked & s
         stop_hash[first] = hh[first]
         stopped |= first
         walk |= first
         if depth < last:
-            und = und & go_on(hh) & ~s
+            und = (und & ~asked) | (asked & go_on(hh) & ~s)
         else:
             und = und & False              # the ladder's last level has stops only
     walk |= und                            # a deep ladder looked at down to LADDER_LAST only: what is undecided there walks

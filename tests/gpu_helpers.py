@@ -3,6 +3,8 @@ test_kernel_variants.py, test_full_size_digests.py, test_multi_gpu.py): handles 
 device buffers, the committed reference digests, event-timed launches.  Test infrastructure only."""
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest

@@ -673,3 +673,41 @@ def test_chained_table_walk_equals_oracle(workloads, oracle_results, name, perf)
         assert np.count_nonzero(want) >= len(lost)
         _, fell_back2 = walk_all(stream, want)
         assert fell_back2 >= len(lost)
+
+
+@pytest.mark.parametrize("workers", [1, 3, 8])
+def test_multi_worker_calls_on_a_cpu_platform_handle(workloads, oracle_results, workers):
+    """PFACX_matchFromHostMultiGPU / PFACX_matchFromHostReduceMultiGPU on a host-only handle: the `numDevices` workers run as host threads over
+    the CPU matchers -- the slices (boundaries on 1 KiB tiles), the maxPatternLen read-ahead behind each, the rebasing of every worker's
+    positions and the moving-together of the lists are the GPU workers' (multi_gpu.cpp), so eight workers can be exercised without a GPU
+    (omp_PFAC.cpp:257-394 is the reference's user-side version).  Matches planted across every slice boundary; full vector and pairs == oracle."""
+    from oracle import binding as ob
+    w = workloads["c2"]
+    data = w.data.copy()
+    n = int(data.size)
+    pats = [p for p in open(w.pattern_file, "rb").read().split(b"\n") if len(p) >= 12]
+    for i in range(1, workers):
+        b = (n * i // workers) // 1024 * 1024
+        p = np.frombuffer(pats[i % len(pats)], dtype=np.uint8)
+        data[b - p.size // 2:b - p.size // 2 + p.size] = p                  # begins in worker i - 1's slice, ends in worker i's
+    o = ob.Oracle(w.pattern_file)
+    want = o.match(data)
+    o.close()
+    for i in range(1, workers):
+        b = (n * i // workers) // 1024 * 1024
+        p = pats[i % len(pats)]
+        assert want[b - len(p) // 2] != 0
+    for perf in (api.PFAC_TIME_DRIVEN, api.PFAC_SPACE_DRIVEN):
+        h = api.PFAC.createHostOnly()
+        try:
+            h.setPerfMode(perf)
+            h.readPatternFromFile(w.pattern_file)
+            got = np.full(n, -9, dtype=np.int32)
+            h.matchFromHostMultiGPU(data.ctypes.data, n, got.ctypes.data, devices=list(range(workers)))
+            assert np.array_equal(got, want), (perf, workers, int(np.flatnonzero(got != want)[0]))
+            ids, pos = np.full(n, -9, dtype=np.int32), np.full(n, -9, dtype=np.int32)
+            _, count = h.matchFromHostReduceMultiGPU(data.ctypes.data, n, ids.ctypes.data, pos.ctypes.data, devices=list(range(workers)))
+            nz = np.flatnonzero(want)
+            assert count == nz.size and np.array_equal(pos[:count], nz) and np.array_equal(ids[:count], want[nz]), (perf, workers, count, nz.size)
+        finally:
+            h.destroy()

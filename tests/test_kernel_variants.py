@@ -226,7 +226,10 @@ def _plant_stream(pats, prefix, tails, p300, p700, n, seed, density):
 @pytest.mark.parametrize("perf,tex,mode_name", MODES)
 @pytest.mark.parametrize("variant,variant_name", [(api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_WINDOW << 8), "filter-window"),
                                                   (api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_STAGE << 8), "filter-stage"),
-                                                  (api.PFACX_KERNEL_NAIVE, "tiled"), (api.PFACX_KERNEL_REFTABLE, "reftable")])
+                                                  (api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_VETO << 8), "filter-veto"),
+                                                  (api.PFACX_KERNEL_NAIVE, "tiled"),                                        # the narrow table: no slot is long
+                                                  (api.PFACX_KERNEL_NAIVE | (api.PFACX_WALKER_STAGE << 8), "tiled-wide"),  # a caller that expects near misses: the wide table, units on demand
+                                                  (api.PFACX_KERNEL_REFTABLE, "reftable")])
 def test_long_slots_in_every_kernel(workdir, longset, perf, tex, mode_name, variant, variant_name):
     pf, pats, prefix, tails, p300, p700 = longset
     n = 2048 * 150 + 333
@@ -400,7 +403,7 @@ def test_veto_kernel_with_the_tail_table_in_device_memory(bigset, perf, tex, mod
         try:
             assert_same(device_match(plain, data), want, f"window walker, same set / {mode_name}")
             st0 = plain.scanStats(data.size)
-            assert st0["veto"] == 0 and st["walksStarted"] * 2 < st0["walksStarted"], (st["walksStarted"], st0["walksStarted"])      # the veto spares most walks of the near-miss part
+            assert st0["veto"] == 0 and st["walksStarted"] * 3 < st0["walksStarted"] * 2, (st["walksStarted"], st0["walksStarted"])      # the veto spares the walks of the near misses (a fifth of the records are complete patterns, text walks as before)
         finally:
             plain.destroy()
         h.setWalker(api.PFACX_WALKER_AUTO)

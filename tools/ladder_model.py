@@ -22,9 +22,9 @@ if __name__ == "__main__":
     l1, cand, walk = filter_model(h, data)
     hit = res != 0
     assert np.all(walk[hit]), "false negative"
-    print("%s: %d MiB, gram3 2^%d bits, ladder 2^%d bits (%d set), stops %d go-ons %d thin %d extend %d last %d, tail entries %d (LDS) / %d (device memory, 2^%d buckets)" % (
+    print("%s: %d MiB, gram3 2^%d bits, ladder 2^%d bits (%d set), stops %d go-ons %d thin %d extend %d last %d, tail entries %d (LDS) / %d (device memory, 2^%d buckets), skip tags %d" % (
           name, mib, info.filterLog2Bits, info.filterLog2BitsLadder, info.filterBitsSetLadder, info.ladderStops, info.ladderGoOns, info.ladderThin, info.ladderExtend,
-          info.filterLadderLast, info.filterTailEntries, info.filterTailGlobalEntries, info.filterLog2TailGlobal))
+          info.filterLadderLast, info.filterTailEntries, info.filterTailGlobalEntries, info.filterLog2TailGlobal, info.filterSkipTags))
     _, _, walk0 = filter_model(h, data, veto=False)
     print("  without the veto: walks %.5f of positions, per GiB %.2f M" % (walk0.mean(), walk0.mean() * 1073.74))
     print("  level-1 hits %.4f  ladder candidates %.4f  walks %.5f  matches %.5f of positions  -> walks per match %.1f, per GiB %.2f M" % (

@@ -89,6 +89,7 @@ typedef struct {
     size_t filterTailGlobalEntries; /* ... in its device-memory form (PFACX_TABLE_FILTER_TAIL_GLOBAL): sets whose bitmaps fill the LDS, or with more
                                   thin stops than the LDS form holds (Snort-scale).  A set has one form or the other (or none) */
     int filterLog2TailGlobal;  /* log2 of the buckets of that table */
+    unsigned int filterLadderSalt; /* XORed into the depth-4 hash of the prefix ladder (chosen per pattern set: pfac_context.h) */
     int filterSkipTags;        /* skip tags of the prefix ladder (PFACX_TABLE_FILTER_SKIP): depth-6 nodes with a single path down to depth 20 (at most 8) */
 } PFACX_info_t;
 

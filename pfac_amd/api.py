@@ -68,7 +68,7 @@ class PFACX_info(C.Structure):
         ("ladderStops", C.c_size_t), ("ladderGoOns", C.c_size_t), ("ladderThin", C.c_int), ("ladderExtend", C.c_int),
         ("trailingBytesIgnored", C.c_size_t), ("deviceTableBytes", C.c_size_t), ("deviceScratchBytes", C.c_size_t),
         ("streamNearMisses", C.c_int), ("streamDense", C.c_int), ("filterLadderLast", C.c_int), ("filterTailEntries", C.c_size_t),
-        ("filterTailGlobalEntries", C.c_size_t), ("filterLog2TailGlobal", C.c_int), ("filterSkipTags", C.c_int),
+        ("filterTailGlobalEntries", C.c_size_t), ("filterLog2TailGlobal", C.c_int), ("filterLadderSalt", C.c_uint), ("filterSkipTags", C.c_int),
     ]
 
 

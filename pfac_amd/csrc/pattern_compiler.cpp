@@ -251,6 +251,7 @@ struct LadderWalk {
     uint32_t thin;
     int extend = 0;                            /* thin nodes go on for this many more levels before they stop */
     int last = kLadderLast;                    /* deepest level: its nodes are all stops */
+    uint32_t salt = 0;                         /* pfac::Filter::ladderSalt */
     template <class Visit> void run(Visit &&visit) const
     {
         struct Item { int state; int depth; uint32_t acc; int ext; };   /* acc: bytes so far (depth < 4: the bytes; depth >= 4: rolling hash) */
@@ -263,7 +264,7 @@ struct LadderWalk {
             if (it.depth < kLadderFirst) {                     /* below the first level: every path, finals on the way included */
                 for (int e = fa.edgeBegin[it.state]; e < fa.edgeBegin[it.state + 1]; e++) {
                     const uint32_t acc = it.acc | ((uint32_t)fa.edgeCh[e] << (8 * it.depth));
-                    stack.push_back({fa.edgeNext[e], it.depth + 1, it.depth + 1 == kLadderFirst ? ladderStart(acc) : acc, it.ext});
+                    stack.push_back({fa.edgeNext[e], it.depth + 1, it.depth + 1 == kLadderFirst ? ladderStart(acc, salt) : acc, it.ext});
                 }
                 continue;
             }
@@ -406,12 +407,42 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
             }
         }
     }
+    /* The salt of the ladder's hashes (struct Filter).  All bits of a node share a dword now, and a GO-ON node whose two stop bits happen to be set by its
+     * dword's other tenants stops every candidate that follows it -- early, at a hash no tail entry knows: a walk.  For most nodes that is one path in
+     * thousands; for the node every pattern of a set with a shared prefix passes (BASELINE config 5: one path, 1 000 patterns) it is the whole stream
+     * (measured on the model before the salt: depth 6 of that path was such a node, 2.5 M walks per GiB became 21.7 M).  The compiler knows every node:
+     * it tries kSaltTries salts and keeps the one under which the false stops have the fewest patterns below them (0 for config 5's set). */
+    f.ladderSalt = 0;
+    {
+        const uint32_t kSaltTries = 12;
+        uint64_t bestCost = ~uint64_t(0);
+        for (uint32_t t = 0; t < kSaltTries && bestCost != 0; t++) {
+            const uint32_t salt = t * 0x9E3779B9u;
+            std::vector<uint32_t> bits((size_t(1) << f.log2BitsLad) / 32, 0);
+            std::vector<std::pair<uint32_t, uint32_t>> goOns;           /* (hash, patterns below) */
+            LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast, salt}.run([&](uint32_t h, int depth, bool stop, int state, bool) {
+                if (stop) {
+                    setBit(bits, ladderBitS1(h, f.log2BitsLad));
+                    setBit(bits, ladderBitS2(h, f.log2BitsLad));
+                } else {
+                    setBit(bits, ladderBitG(h, f.log2BitsLad));
+                    if (depth == kLadderFirst) setBit(bits, ladderBitG2(h, f.log2BitsLad));
+                    goOns.emplace_back(h, below[(size_t)state]);
+                }
+            });
+            auto has = [&](uint32_t b) { return (bits[b >> 5] >> (b & 31)) & 1u; };
+            uint64_t cost = 0;
+            for (const auto &g : goOns)
+                if (has(ladderBitS1(g.first, f.log2BitsLad)) && has(ladderBitS2(g.first, f.log2BitsLad))) cost += g.second;
+            if (cost < bestCost) { bestCost = cost; f.ladderSalt = salt; }
+        }
+    }
     struct ThinStop { uint32_t h; int depth; int state; };
     std::vector<ThinStop> thinStops;
     std::vector<uint32_t> allHashes;
     std::vector<unsigned char> goOn((size_t)fa.numStates, 0);          /* states that are G nodes of the ladder */
     std::vector<std::pair<uint32_t, int>> skipFrom;                     /* G nodes at depth kSkipFromDepth: (hash, state) */
-    LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast}.run([&](uint32_t h, int depth, bool stop, int state, bool thinStop) {
+    LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast, f.ladderSalt}.run([&](uint32_t h, int depth, bool stop, int state, bool thinStop) {
         if (!stop) {
             goOn[(size_t)state] = 1;
             if (depth == kSkipFromDepth) skipFrom.emplace_back(h, state);
@@ -559,7 +590,7 @@ void buildReduceFilter(const Automaton &fa, Filter &f)
                 setGram1(key3);
                 const int s3 = fa.edgeNext[e3];
                 for (int e4 = fa.edgeBegin[s3]; e4 < fa.edgeBegin[s3 + 1]; e4++) {
-                    const uint32_t h = ladderStart(key3 | ((uint32_t)fa.edgeCh[e4] << 24));
+                    const uint32_t h = ladderStart(key3 | ((uint32_t)fa.edgeCh[e4] << 24));       /* (prefix4 is not salted) */
                     const uint32_t b1 = prefix4Bit1(h), b2 = prefix4Bit2(h);
                     f.prefix4[b1 >> 5] |= 1u << (b1 & 31);
                     f.prefix4[b2 >> 5] |= 1u << (b2 & 31);

@@ -602,6 +602,7 @@ PFAC_status_t PFACX_getInfo(PFAC_handle_t handle, PFACX_info_t *info)
         v.filterTailGlobalEntries = handle->filter.tailGEntries;
         v.filterLog2TailGlobal = handle->filter.tailG.empty() ? 0 : handle->filter.log2TailG;
         v.filterSkipTags = handle->filter.skipCount;
+        v.filterLadderSalt = handle->filter.ladderSalt;
         v.trailingBytesIgnored = handle->fa.trailingBytes;
         v.chainJumpLog2 = handle->h_chainSlots.empty() ? 0 : handle->chainJumpLog2;
         v.chainSlots = handle->h_chainSlots.size();

@@ -133,6 +133,8 @@ struct Filter {
     size_t bitsSetLad = 0;                    /* population of the ladder bitmap */
     size_t ladderStops = 0, ladderGoOns = 0;  /* S and G nodes inserted */
     int ladderThin = 1;                       /* nodes with at most this many patterns below them are S (raised until the bitmap is sparse enough) */
+    uint32_t ladderSalt = 0;                  /* XORed into the depth-4 hash of the ladder (and so into every hash rolled from it): picked by the pattern compiler so that no
+                                                 GO-ON node with many patterns below it has its two STOP bits set by its dword's other tenants (pattern_compiler.cpp) */
     int ladderLast = 20;                      /* deepest level of the ladder: kLadderLast, or kLadderDeepLast when the nodes behind kLadderLast fit the bitmap too (few do: most
                                                  paths are alone by then; BASELINE config 5's 24-byte shared prefix is what needs them) */
     /* The tail table (round 5; the veto of the VETO kernels on a ladder stop): a stop node below which ONE pattern is left knows the rest of
@@ -198,29 +200,45 @@ inline uint32_t tailSlot2(uint32_t tag, int log2Slots) { return (uint32_t)(tag *
 constexpr int kLadderLevels = (kLadderLast - kLadderFirst) / kLadderStep + 1;
 constexpr uint32_t kLadMul0 = 0x9E3779B1u, kLadMul = 0x85EBCA77u, kLadMulS = 0xC2B2AE3Du, kLadMulG = 0x27D4EB2Fu, kLadMulG2 = 0x165667B1u;
 inline uint32_t tailRoll(uint32_t h, uint32_t piece32) { return (h ^ piece32) * kLadMul; }       /* the tail hash: four bytes a step */
-inline uint32_t ladderStart(uint32_t first4) { return first4 * kLadMul0; }
+inline uint32_t ladderStart(uint32_t first4, uint32_t salt = 0) { return (first4 * kLadMul0) ^ salt; }      /* salt: pfac::Filter::ladderSalt (prefix4: none) */
 inline uint32_t ladderRoll(uint32_t h, uint32_t piece16) { return (h ^ piece16) * kLadMul; }
+/* Round 6: the ladder bitmap is BLOCKED like level 1 -- all bits of a node lie in ONE dword, so a level costs the kernel one LDS read and no
+ * multiplication (rounds 3 - 5: three reads at three hashed places, two 32-bit multiplications): the dword from bits 18.. of h (its byte address
+ * is one SDWA AND of h's high half, like level 1's), the bits from four 5-bit fields of h: S = bits [3..7] and [8..12], G = [13..17], the second
+ * G bit of depth 4 = [0..4].  (kLadMulS / kLadMulG / kLadMulG2 are still what prefix4 and the layout fingerprint use.) */
+#ifndef PFAC_LADDER_BLOCKED
+#define PFAC_LADDER_BLOCKED 1                  /* 0: measurement builds of both libraries -- the layout of rounds 3 - 5 (tests/filter_model.py models the blocked one) */
+#endif
+inline uint32_t ladderWord(uint32_t h, int log2Bits) { return (h >> 18) & ((1u << (log2Bits - 5)) - 1u); }
+#if PFAC_LADDER_BLOCKED
+inline uint32_t ladderBitS1(uint32_t h, int log2Bits) { return ladderWord(h, log2Bits) * 32u + ((h >> 3) & 31u); }
+inline uint32_t ladderBitS2(uint32_t h, int log2Bits) { return ladderWord(h, log2Bits) * 32u + ((h >> 8) & 31u); }
+inline uint32_t ladderBitG(uint32_t h, int log2Bits) { return ladderWord(h, log2Bits) * 32u + ((h >> 13) & 31u); }
+inline uint32_t ladderBitG2(uint32_t h, int log2Bits) { return ladderWord(h, log2Bits) * 32u + (h & 31u); }
+#else
 inline uint32_t ladderBitS1(uint32_t h, int log2Bits) { return h >> (32 - log2Bits); }
 inline uint32_t ladderBitS2(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulS) >> (32 - log2Bits); }
 inline uint32_t ladderBitG(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulG) >> (32 - log2Bits); }
 inline uint32_t ladderBitG2(uint32_t h, int log2Bits) { return (uint32_t)(h * kLadMulG2) >> (32 - log2Bits); }
+#endif
 
-constexpr uint32_t kGram3Mul = 0x8B92C5u;     /* 24-bit odd multiplier of the 3-gram hash, picked by scanning 160
-                                                 candidates for the lowest false-positive rate on the text, binary
-                                                 and near-miss streams */
+constexpr uint32_t kGram3Mul = 0x9A17AFu;     /* 24-bit odd multiplier of the 3-gram hash of gram3, picked by scanning 200 candidates for the lowest false-positive
+                                                 rate on the text stream (round 6, for the dword index below: 4.6 % of the Snort-style stream pass level 1 where round 5's
+                                                 0x8B92C5 with the product's TOP bits let 4.95 % through; the near-miss stream over the 31 000-pattern set: 6.2 % instead of 8.3 %) */
+constexpr uint32_t kGram1Mul = 0x8B92C5u;     /* ... of gram1 (the compacted-output kernel's one-bit level 1): round 4's choice stands there (4.8 % against 5.3 % with the above) */
 /* Level 1 is a BLOCKED two-bit Bloom filter: a 3-gram owns two bits of ONE dword, so a position costs the kernel one
  * LDS read (a one-bit filter of twice the size lets slightly fewer positions through, 4.8 % instead of 5.1 % of the
- * Snort-style stream, and leaves the prefix ladder half the LDS).  The dword comes from the top bits of the 24 x 24 ->
- * 32 bit product, the first bit from the low five bits of the first byte, the second from those of the second byte --
- * the kernel gets the dword address with a shift and an AND and the bits with the implicit mod-32 of a shift by the
+ * Snort-style stream, and leaves the prefix ladder half the LDS).  The dword comes from bits 18.. of the 24 x 24 ->
+ * 32 bit product -- the kernels get its BYTE address with ONE instruction, an AND of the product's high half with
+ * (words - 1) << 2 (SDWA; the top bits, round 5, needed a shift and an AND: one instruction of nine per position) --, the first
+ * bit from the low five bits of the first byte, the second from those of the second byte: the implicit mod-32 of a shift by the
  * gram itself and by the gram >> 8 (scan_*.hip). */
-inline uint32_t gram3Word(uint32_t key24, int log2Bits) { return (uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> (37 - log2Bits); }
+inline uint32_t gram3Word(uint32_t key24, int log2Bits) { return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> 18) & ((1u << (log2Bits - 5)) - 1u); }
 inline uint32_t gram3Bit1(uint32_t key24) { return key24 & 31u; }
 inline uint32_t gram3Bit2(uint32_t key24) { return (key24 >> 8) & 31u; }
-/* gram1: the dword from bits 18..31 of the 24 x 24 -> 32 bit product (the kernel gets its byte address with ONE instruction,
- * an AND of the product's high half with 0xFFFC: SDWA), the bit from the low five bits of the gram's first byte (the
- * implicit mod-32 of a shift by the gram itself) */
-inline uint32_t gram1Word(uint32_t key24) { return ((uint32_t)((key24 & 0xFFFFFFu) * kGram3Mul) >> 18) & ((1u << (kGram1Log2 - 5)) - 1u); }
+/* gram1: the dword from bits 18..31 of the 24 x 24 -> 32 bit product (the same one-instruction address), the bit from the low
+ * five bits of the gram's first byte (the implicit mod-32 of a shift by the gram itself) */
+inline uint32_t gram1Word(uint32_t key24) { return ((uint32_t)((key24 & 0xFFFFFFu) * kGram1Mul) >> 18) & ((1u << (kGram1Log2 - 5)) - 1u); }
 inline uint32_t gram1Bit(uint32_t key24) { return key24 & 31u; }
 /* prefix4: keyed by the ladder's hash of the first four bytes, h = ladderStart(first4): bits h >> (32 - kPrefix4Log2) and
  * (h * kLadMulS) >> (32 - kPrefix4Log2) */

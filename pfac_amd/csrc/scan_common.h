@@ -57,6 +57,7 @@ struct ScanArgs {
     const uint32_t *shortBits;
     int log2Bits, log2BitsLad, log2BitsF3;
     int ladderLast;                                    /* deepest level of the prefix ladder (pfac::Filter::ladderLast): behind kLadderLast only the VETO kernels look */
+    uint32_t ladderSalt;                               /* pfac::Filter::ladderSalt */
     int skipCount;                                     /* skip tags (pfac::Filter): depth-6 ladder hashes whose candidates are next asked at kLadderLast */
     uint32_t skipTags[pfac::kSkipTagsMax];
     int numFinal;

@@ -233,12 +233,32 @@ void pfac_scan_filter(ScanArgs a)
     uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sLadder, sFinal3, sShort,
-                  35u - (uint32_t)a.log2Bits /* product -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2BitsLad, 32u - (uint32_t)a.log2BitsF3};
-    /* one probe of the prefix ladder: bit `v >> shiftLad` of the bitmap, in bit 0 of the result (the bits above it are garbage) */
+                  ((1u << ((uint32_t)a.log2Bits - 5u)) - 1u) << 2 /* product's high half -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2BitsLad, 32u - (uint32_t)a.log2BitsF3};
+    /* The prefix ladder's bitmap is blocked (pfac_context.h: ladderWord): ALL bits of a node hash h lie in one dword -- bits 18.. of h pick it, its byte
+     * address is one SDWA AND of h's high half with (dwords - 1) << 2 --, and 5-bit fields of h number the bits: S = [3..7] and [8..12], G = [13..17], the
+     * second G bit of depth 4 = [0..4].  A level is ONE LDS read and no multiplication (rounds 3 - 5: three reads at three hashed places and two 32-bit
+     * multiplications -- a third of a level's instructions).  The results carry the bit in bit 0; the bits above it are garbage. */
+#if PFAC_LADDER_BLOCKED
+    uint32_t vLadMask;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vLadMask) : "s"(((1u << ((uint32_t)a.log2BitsLad - 5u)) - 1u) << 2));
+    auto ladWord = [&](uint32_t h) -> uint32_t {
+        uint32_t addr;
+        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(h), "v"(vLadMask));
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(addr + kLadderLdsOffset);
+    };
+    auto ladStop = [](uint32_t w, uint32_t h) -> uint32_t { return (w >> ((h >> 3) & 31u)) & (w >> ((h >> 8) & 31u)); };
+    auto ladGoOn = [](uint32_t w, uint32_t h) -> uint32_t { return w >> ((h >> 13) & 31u); };
+    auto ladGoOn2 = [](uint32_t w, uint32_t h) -> uint32_t { return w >> (h & 31u); };
+#else       /* measurement builds (-DPFAC_LADDER_BLOCKED=0, host library too): the bitmap of rounds 3 - 5, a probe per bit at a place of its own */
     auto ladProbe = [&](uint32_t v) -> uint32_t {
         const uint32_t idx = v >> lds.shiftLad;
         return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(((idx >> 3) & ~3u) + kLadderLdsOffset) >> (idx & 31u);
     };
+    auto ladWord = [](uint32_t h) -> uint32_t { return h; };
+    auto ladStop = [&](uint32_t, uint32_t h) -> uint32_t { return ladProbe(h) & ladProbe(h * pfac::kLadMulS); };
+    auto ladGoOn = [&](uint32_t, uint32_t h) -> uint32_t { return ladProbe(h * pfac::kLadMulG); };
+    auto ladGoOn2 = [&](uint32_t, uint32_t h) -> uint32_t { return ladProbe(h * pfac::kLadMulG2); };
+#endif
     WCtx wctx(a);
     if constexpr (kStageWalk) {
         wctx.hotAddr = (uint32_t)(reinterpret_cast<unsigned char *>(sHotAll) - smem);
@@ -408,10 +428,10 @@ void pfac_scan_filter(ScanArgs a)
     constexpr uint32_t kRefillBatch = (uint32_t)PFAC_REFILL_BATCH < kQCap / 2 ? (uint32_t)PFAC_REFILL_BATCH : kQCap / 2;   /* the ladder stops feeding a queue with less than 16 free entries */
     bool flushWalks = false;                        /* nothing left to filter: queued walks start however few they are */
 #ifndef PFAC_WALK_GATE
-#define PFAC_WALK_GATE 48                      /* 0: a walker round in every trip (rounds 2 - 5) */
+#define PFAC_WALK_GATE 64                      /* 0: a walker round in every trip (rounds 2 - 5) */
 #endif
 #ifndef PFAC_WALK_GATE_TRIPS
-#define PFAC_WALK_GATE_TRIPS 4
+#define PFAC_WALK_GATE_TRIPS 6
 #endif
     constexpr bool kWalkGated = !REDUCE && !kStageWalk && kWalkSets == 1 && PFAC_WALK_GATE > 0;
     constexpr uint32_t kWalkGate = PFAC_WALK_GATE, kWalkGateTrips = PFAC_WALK_GATE_TRIPS;
@@ -665,8 +685,8 @@ void pfac_scan_filter(ScanArgs a)
      * issues at ~0.6 of the rate of the same instruction on vector registers (tools/valu_probe2.hip: v_lshrrev
      * 1.10 vs 1.78 ns, v_mul_u32_u24 1.76 vs 2.03 ns per wave and SIMD), and these two run 2048 times per chunk */
     uint32_t vShift3, vGram3Mul;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(REDUCE ? 0xFFFCu : lds.shift3));      /* compacted-output kernel: the address mask of gram1 */
-    asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(pfac::kGram3Mul));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vShift3) : "s"(REDUCE ? 0xFFFCu : lds.shift3));      /* the address mask of the level-1 bitmap: (dwords - 1) << 2 (gram1: 64 KiB) */
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vGram3Mul) : "s"(REDUCE ? pfac::kGram1Mul : pfac::kGram3Mul));
     uint32_t listAt = 0, listEnd = 0, stagedBase = 0;
     bool freshChunk = false;                    /* level 1 of the staged chunk has just run: `hits` holds all of its hits */
     uint32_t *sDense = sDenseAll + wave * kDenseStage;     /* pattern-dense chunks of this wave, not yet on the launch's list */
@@ -912,15 +932,11 @@ void pfac_scan_filter(ScanArgs a)
                              * the 48-bit product -- one v_mul_hi_u32_u24 and an AND -- would save an instruction, but the first byte of
                              * the gram hardly reaches it: level-1 hits went from 5 % to 18 % of the text stream.) */
                             const uint32_t product = (uint32_t)__umul24(x, vGram3Mul);   /* __umul24 returns int: shifts must be logical */
-                            if (REDUCE) {
-                                /* gram1: byte address of the dword = bits 18..31 of the product, times four = the product's high half
-                                 * AND 0xFFFC -- one SDWA instruction (a shift and an AND otherwise) */
-                                uint32_t addr;
-                                asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(product), "v"(vShift3));
-                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(addr + kGram1LdsOffset);
-                            } else {
-                                word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> vShift3) & ~3u);
-                            }
+                            /* byte address of the dword = bits 18.. of the product, times four = the product's high half AND (dwords - 1) << 2 --
+                             * one SDWA instruction (a shift and an AND otherwise: round 5's full-result kernels) */
+                            uint32_t addr;
+                            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(addr) : "v"(product), "v"(vShift3));
+                            word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(addr + (REDUCE ? kGram1LdsOffset : 0u));
                             xs[q] = x;
                         }
                         /* the second bit of a 3-gram is numbered by the low five bits of its SECOND byte: the first byte of the
@@ -1006,7 +1022,7 @@ void pfac_scan_filter(ScanArgs a)
                 const uint32_t o = ((code & 0x10u) << 6) | ((code >> 1) & 0x3F0u) | (code & 0xFu);       /* byte offset inside the chunk: tile, lane, position */
                 const uint32_t at = o >> 2, sh = o & 3u;
                 const uint32_t x = __builtin_amdgcn_alignbyte(stage[at + 1], stage[at], sh);
-                const uint32_t h = x * pfac::kLadMul0;
+                const uint32_t h = REDUCE ? x * pfac::kLadMul0 : (x * pfac::kLadMul0) ^ a.ladderSalt;      /* pfac::ladderStart; prefix4 is not salted */
                 uint32_t sHit, gHit;
                 if (REDUCE) {                                      /* every 4-byte pattern prefix walks: prefix4, two probes (LDS address 0) */
                     auto probe4 = [&](uint32_t v) -> uint32_t {
@@ -1016,8 +1032,9 @@ void pfac_scan_filter(ScanArgs a)
                     sHit = probe4(h) & probe4(h * pfac::kLadMulS) & 1u;
                     gHit = 0;
                 } else {
-                    sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS) & 1u;
-                    gHit = ladProbe(h * pfac::kLadMulG) & ladProbe(h * pfac::kLadMulG2) & 1u;
+                    const uint32_t w = ladWord(h);
+                    sHit = ladStop(w, h) & 1u;
+                    gHit = ladGoOn(w, h) & ladGoOn2(w, h) & 1u;               /* depth 4: G nodes set two bits */
                 }
                 uint32_t decided = sHit | (testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul) >> lds.shiftF3) &
                                            testBit(sFinal3, (uint32_t)__umul24(x, pfac::kFinal3Mul2) >> lds.shiftF3));
@@ -1068,7 +1085,7 @@ void pfac_scan_filter(ScanArgs a)
             if (skipLadder) { ladderSkip--; walk |= und; und = 0; }
             if (!REDUCE && __ballot(und != 0) != 0) {
                 uint32_t hl[pfac::kLadderLevels];
-                hl[0] = x0 * pfac::kLadMul0;
+                hl[0] = (x0 * pfac::kLadMul0) ^ a.ladderSalt;           /* pfac::ladderStart */
 #pragma unroll
                 for (int lv = 1; lv < pfac::kLadderLevels; lv++) {
                     const uint32_t xw = lv <= 2 ? x1 : lv <= 4 ? x2 : lv <= 6 ? x3 : x4;
@@ -1096,11 +1113,12 @@ void pfac_scan_filter(ScanArgs a)
                     /* who is asked at this level: the undecided, but for those on a tagged path between its first and its last level */
                     const uint32_t act = (lv >= 2 && lv < pfac::kLadderLevels - 1) ? (und & ~skipping) : und;
                     const uint32_t h = hl[lv];
-                    const uint32_t sHit = ladProbe(h) & ladProbe(h * pfac::kLadMulS);      /* bit 0; und is 0 or 1 */
+                    const uint32_t w = ladWord(h);
+                    const uint32_t sHit = ladStop(w, h);                            /* bit 0; und is 0 or 1 */
                     if constexpr (kVeto) stopHash = (act & sHit) ? h : stopHash;
                     walk |= act & sHit;
                     if (lv == pfac::kLadderLevels - 1 && !deepLadder) und = 0;      /* the last level has S nodes only */
-                    else und &= ~act | (ladProbe(h * pfac::kLadMulG) & ~sHit);
+                    else und &= ~act | (ladGoOn(w, h) & ~sHit);
                 }
                 if constexpr (kVeto) {
                     /* A deep ladder (pfac::Filter::ladderLast) goes on behind the 20 bytes wherever patterns still share a path: two more bytes of
@@ -1116,7 +1134,7 @@ void pfac_scan_filter(ScanArgs a)
                             const uint32_t b = any ? o + dd : 0u;
                             const uint32_t w0 = stage[b >> 2], w1 = stage[(b >> 2) + 1u], w2 = stage[(b >> 2) + 2u];
                             const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, b & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, b & 3u);
-                            uint32_t hk[4], s1[4], s2[4], g1[4];
+                            uint32_t hk[4], wk[4];
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 const uint32_t piece = ((k < 2 ? lo : hi) >> (16 * (k & 1))) & 0xFFFFu;
@@ -1124,14 +1142,14 @@ void pfac_scan_filter(ScanArgs a)
                                 hk[k] = h;
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; k++) { s1[k] = ladProbe(hk[k]); s2[k] = ladProbe(hk[k] * pfac::kLadMulS); g1[k] = ladProbe(hk[k] * pfac::kLadMulG); }
+                            for (int k = 0; k < 4; k++) wk[k] = ladWord(hk[k]);
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 const bool lvl = dd + 2u * (uint32_t)k < (uint32_t)a.ladderLast;        /* wave-uniform */
-                                const uint32_t sHit = s1[k] & s2[k];
+                                const uint32_t sHit = ladStop(wk[k], hk[k]);
                                 stopHash = (lvl && (und & sHit & 1u)) ? hk[k] : stopHash;
                                 walk |= lvl ? (und & sHit) : 0u;
-                                und = lvl ? (und & g1[k] & ~sHit) : und;
+                                und = lvl ? (und & ladGoOn(wk[k], hk[k]) & ~sHit) : und;
                             }
                         }
                     }

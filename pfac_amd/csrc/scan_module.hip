@@ -146,6 +146,7 @@ PFAC_status_t fillArgs(const PFAC_context *c, bool hashed, const char *d_input_s
     a.log2Bits = c->filter.log2Bits;
     a.log2BitsLad = c->filter.log2BitsLad;
     a.ladderLast = c->filter.ladderLast;
+    a.ladderSalt = c->filter.ladderSalt;
     a.skipCount = c->filter.skipCount;
     for (int k = 0; k < pfac::kSkipTagsMax; k++) a.skipTags[k] = c->filter.skipTags[k];
     a.log2BitsF3 = c->filter.log2BitsF3;

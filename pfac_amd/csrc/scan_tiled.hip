@@ -173,7 +173,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
     (void)sInit;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(a.chainSlots), 0, (int)a.chainBytes, 0x00020000);
-    const uint32_t shift3 = 35u - (uint32_t)a.log2Bits;
+    const uint32_t mask3 = ((1u << ((uint32_t)a.log2Bits - 5u)) - 1u) << 2;      /* pfac::gram3Word as a byte address: (product >> 16) & mask3 */
     const uint32_t hot = a.hotSlots;
     const bool reduce = a.reducePos != nullptr;
     /* compacted output: matches are staged per wave and appended kTiledPairs at a time -- one device counter answers ~90 atomics per
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(1024) void pfac_scan_tiled(ScanArgs a)
                     const uint32_t nx = j < 3 ? dw[(j + 1) & 3] : nxtLane;
                     const uint32_t x = i == 0 ? dw[j] : i == 1 ? dw[j] >> 8 : __builtin_amdgcn_alignbyte(nx, dw[j], i);
                     const uint32_t product = (uint32_t)__umul24(x, pfac::kGram3Mul);
-                    word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> shift3) & ~3u);
+                    word[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((product >> 16) & mask3);
                     xs[q] = x;
                 }
                 xs[8] = b0 + 8 < 16 ? dw[(b0 + 8) >> 2] : nxtLane;

@@ -5,7 +5,7 @@ import numpy as np
 
 from pfac_amd import api
 
-GRAM3_MUL, FINAL3_MUL, FINAL3_MUL2 = 0x8B92C5, 0x85EBCB, 0xB5297B
+GRAM3_MUL, GRAM1_MUL, FINAL3_MUL, FINAL3_MUL2 = 0x9A17AF, 0x8B92C5, 0x85EBCB, 0xB5297B
 LAD_MUL0, LAD_MUL, LAD_MULS, LAD_MULG, LAD_MULG2 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F, 0x165667B1
 TAIL_MUL, TAIL_MUL2 = 0x9E3779B1, 0x85EBCA77
 LADDER_LAST = 20                   # kLadderLast: the levels every kernel tests; a DEEP ladder (info.filterLadderLast = 60) goes on behind it
@@ -30,7 +30,7 @@ def prefilter_model(h, data, veto=True):
 
     # level 1: two bits of one dword (patterns of 1-2 bytes are folded into the bitmap)
     prod = ((x & u(0xFFFFFF)) * u(GRAM3_MUL)) & m32
-    word = g3[(prod >> u(37 - info.filterLog2Bits)).astype(np.int64)]
+    word = g3[((prod >> u(18)) & u((1 << (info.filterLog2Bits - 5)) - 1)).astype(np.int64)]
     level1 = (((word >> (x & u(31)).astype(np.uint32)) & (word >> ((x >> u(8)) & u(31)).astype(np.uint32))) & 1).astype(bool)
     k3 = x & u(0xFFFFFF)
     sf = u(32 - info.filterLog2BitsFinal3)
@@ -39,14 +39,21 @@ def prefilter_model(h, data, veto=True):
         bypass |= bit(sb, x & u(0xFFFF))
     sh = u(32 - info.filterLog2BitsLadder)
 
+    def lad_word(hh):                      # pfac::ladderWord: all bits of a node lie in one dword (blocked, round 6)
+        return lad[((hh >> u(18)) & u((1 << (info.filterLog2BitsLadder - 5)) - 1)).astype(np.int64)]
+
+    def field(word, hh, lo):
+        return ((word >> ((hh >> u(lo)) & u(31)).astype(np.uint32)) & 1).astype(bool)
+
     def stop(hh):
-        return bit(lad, hh >> sh) & bit(lad, ((hh * u(LAD_MULS)) & m32) >> sh)
+        w = lad_word(hh)
+        return field(w, hh, 3) & field(w, hh, 8)
 
     def go_on(hh):
-        return bit(lad, ((hh * u(LAD_MULG)) & m32) >> sh)
+        return field(lad_word(hh), hh, 13)
 
-    hh = (x * u(LAD_MUL0)) & m32
-    s, g = stop(hh), go_on(hh) & bit(lad, ((hh * u(LAD_MULG2)) & m32) >> sh)       # depth 4: G nodes set two bits
+    hh = ((x * u(LAD_MUL0)) & m32) ^ u(int(getattr(info, "filterLadderSalt", 0)))
+    s, g = stop(hh), go_on(hh) & field(lad_word(hh), hh, 0)       # depth 4: G nodes set two bits
     walk = level1 & (bypass | s)
     cand = level1 & (bypass | s | g)
     und = cand & ~walk
@@ -129,7 +136,7 @@ def reduce_filter_model(h, data):
     def bit(bitmap, hv):
         return ((bitmap[(hv >> u(5)).astype(np.int64)] >> (hv & u(31)).astype(np.uint32)) & 1).astype(bool)
 
-    prod = ((x & u(0xFFFFFF)) * u(GRAM3_MUL)) & m32
+    prod = ((x & u(0xFFFFFF)) * u(GRAM1_MUL)) & m32
     word = g1[((prod >> u(18)) & u(0x3FFF)).astype(np.int64)]          # the kernel: (product's high half) & 0xFFFC as the byte address
     level1 = ((word >> (x & u(31)).astype(np.uint32)) & 1).astype(bool)
     k3 = x & u(0xFFFFFF)

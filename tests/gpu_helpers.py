@@ -111,3 +111,11 @@ def run_bench(*flags, timeout=900):
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+def o_prefix(pf, data):
+    from oracle import binding as ob
+    o = ob.Oracle(pf, dense=False, hashed=True)
+    try:
+        return o.match(data, hashed=True, omp=True)
+    finally:
+        o.close()

@@ -20,7 +20,7 @@ torch = pytest.importorskip("torch")
 from pfac_amd import api, sharding  # noqa: E402,F401
 from pfac_amd import workloads as wl  # noqa: E402,F401
 from tests.gpu_helpers import (MODES, STAGE, VARIANTS, WALKERS, assert_same, device_match, digest_record, digests, make_handle,  # noqa: E402,F401
-                               oracle_match, perf_asserts, run_bench, timed_match)
+                               o_prefix, oracle_match, perf_asserts, run_bench, timed_match)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -150,14 +150,6 @@ def test_match_from_host_reduce_pieces_equal_oracle(workdir):
         h.destroy()
         o.close()
 
-
-def o_prefix(pf, data):
-    from oracle import binding as ob
-    o = ob.Oracle(pf, dense=False, hashed=True)
-    try:
-        return o.match(data, hashed=True, omp=True)
-    finally:
-        o.close()
 
 
 def test_two_host_threads_share_one_handle(workloads, oracle_results):

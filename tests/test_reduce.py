@@ -20,7 +20,7 @@ torch = pytest.importorskip("torch")
 from pfac_amd import api, sharding  # noqa: E402,F401
 from pfac_amd import workloads as wl  # noqa: E402,F401
 from tests.gpu_helpers import (MODES, STAGE, VARIANTS, WALKERS, assert_same, device_match, digest_record, digests, make_handle,  # noqa: E402,F401
-                               oracle_match, perf_asserts, run_bench, timed_match)
+                               o_prefix, oracle_match, perf_asserts, run_bench, timed_match)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

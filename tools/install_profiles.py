@@ -7,6 +7,8 @@ def cp(a, b):
     shutil.copy(os.path.join(src, a), os.path.join("profiles", f"{tag}_{b}"))
 for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json", "bench_c2.json"),
              ("bench_c5_dense.json", "bench_c5_dense.json"), ("bench_c5_hashed.json", "bench_c5_hashed.json"),
+             ("bench_c6.json", "bench_c6.json"), ("bench_c6_walker_window.json", "bench_c6_walker_window.json"), ("bench_c6_walker_stage.json", "bench_c6_walker_stage.json"),
+             ("bench_c6_walker_veto.json", "bench_c6_walker_veto.json"), ("bench_c6_under_rocprof.json", "bench_c6_under_rocprof.json"), ("pmc_full_c6.txt", "pmc_full_result_kernel_c6.txt"),
              ("bench_c3_naive.json", "bench_c3_naive_kernel.json"), ("bench_c2_naive.json", "bench_c2_naive_kernel.json"),
              ("bench_c3_under_rocprof.json", "bench_c3_under_rocprof.json"), ("bench_c2_under_rocprof.json", "bench_c2_under_rocprof.json"),
              ("bench_c3_2ranks_one_gpu_gloo.json", "bench_c3_2ranks_one_gpu_gloo.json"),
@@ -26,7 +28,9 @@ with open(os.path.join("profiles", f"{tag}_pmc_instruction_counts.txt"), "w") as
         f = os.path.join(src, f"pmc_reduce_{w}.txt")
         if os.path.exists(f):
             out.write(f"== {w}\n" + open(f).read() + "\n")
-for w in ("c3", "c2", "c5"):
+for w in ("c3", "c2", "c5", "c6"):
+    if not os.path.exists(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv")):
+        continue
     rows = list(csv.reader(open(os.path.join(src, f"prof_{w}", "prof_kernel_stats.csv"))))
     keep = [rows[0]] + [r for r in rows[1:] if "pfac_scan" in r[0] or "pfac_order" in r[0] or "fillBuffer" in r[0]]
     csv.writer(open(os.path.join("profiles", f"{tag}_{w}_rocprofv3_kernel_stats.csv"), "w")).writerows(keep)

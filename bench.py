@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- input GB/s scanned by the PFAC match path on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5] [--size-mib 1024]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5|c6] [--size-mib 1024]
 
 One "step" = one PFAC_matchFromDevice() pass over the rank's slice of the synthetic stream, input
 and result buffers resident in HBM, transition tables already uploaded.  The stream is sharded as
@@ -23,8 +23,11 @@ Rank 0 prints ONE JSON line (the driver contract) that also carries
                    "traffic_source")
   "cpu_baseline":  the reference's own OpenMP matcher (oracle/_ref, compiled from the unmodified
                    reference sources) timed on this host's cores on a bounded sample, N = 1 only
-  "other_configs": the other single-GPU BASELINE configurations (c2 texture on/off, c5 dense/hashed),
-                   10 launches each on the same GPU, N = 1 only
+  "other_configs": the other single-GPU BASELINE configurations (c2 texture on/off, c5 dense/hashed), c6 = the c5 stream over
+                   c3's set + c5's shared-prefix patterns (the worst input on the FULL set), the reference-layout kernels, c4 as
+                   one 8 GiB workload; 10 launches each on the same GPU, N = 1 only
+  "call_size_sweep": 1 / 4 / 16 / 64 / 256 MiB calls of the headline stream through PFACX_KERNEL_AUTO, and one cold call after
+                   a second of idle GPU, N = 1 only
 
 Bit-exactness (outside the timed region): every rank compares its result with the committed digest of
 the REFERENCE's CPU/OMP result for its slice (tests/golden/full_digests.json: match count, position

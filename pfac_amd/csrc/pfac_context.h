@@ -120,7 +120,7 @@ struct Automaton {
  *      lie below it, or it is the last level; or
  *   G ("go on": test the next level)      -- everything else; only these have their descendants in the ladder.
  * Both kinds live in ONE Bloom bitmap keyed by a rolling hash of the prefix: S nodes set two bits, G nodes one (two
- * at depth 4, where the test decides which level-1 hits become candidates at all).  A candidate walks the levels until it hits an S node (-> walk), or neither kind (-> its result is 0).
+ * at depth 4, where the test decides which level-1 hits become candidates at all) -- since round 6 all in the ONE dword the hash picks (blocked: a level is one LDS read).  A candidate walks the levels until it hits an S node (-> walk), or neither kind (-> its result is 0).
  * Patterns shorter than 4 bytes bypass the ladder: final3 (length exactly 3) and shortBits (length 1-2).
  * All bitmaps are supersets of the exact sets, so a miss proves the result is 0 (a false positive costs a walk or one
  * more level, never correctness: a matching pattern's nodes are S or G at every level up to its first S node). */
@@ -183,15 +183,19 @@ constexpr int kSkipTagsMax = 8, kSkipFromDepth = 6;
 constexpr int kDenseFastMaxStates = 8192;      /* 8 MiB of int[S][256]: stays in L2 */
 
 /* the ladder's hash: h(4) = (first four bytes, little endian) * kLadMul0; h(d) = (h(d-2) ^ (bytes d-2, d-1 as a 16-bit
- * little-endian number)) * kLadMul.  Bit numbers: the top log2BitsLad bits of h (S, first bit), of h * kLadMulS (S, second
- * bit), of h * kLadMulG (G) and, at depth 4 only, of h * kLadMulG2 (G, second bit).  scan_*.hip evaluates exactly this. */
+ * little-endian number)) * kLadMul; h(4) also takes the set's salt (ladderStart).  Where a node's bits lie: ladderWord / ladderBit* below (round 6: all in one
+ * dword).  scan_filter.hip and tests/filter_model.py evaluate exactly this. */
 constexpr int kLadderFirst = 4, kLadderStep = 2, kLadderLast = 20;
 constexpr int kLadderDeepLast = 60;            /* a DEEP ladder (Filter::ladderLast) goes on in steps of two down to here: the levels behind kLadderLast are tested by a rolled loop of the
                                                  VETO kernels only; every other kernel walks what is undecided at kLadderLast */
 constexpr uint32_t kTailMul = 0x9E3779B1u, kTailMul2 = 0x85EBCA77u;      /* the two slots of a tail entry: (tag * mul) >> (32 - log2Tail) */
 constexpr int kTailLog2Max = 12, kTailMinBytes = 6;          /* at most 4096 slots of 12 bytes (LDS); shorter rests are not worth an entry */
-constexpr int kTailMaxBytes = 32;                            /* ... and of a longer rest the LAST 32 bytes are compared (any bytes may be: the veto only has to hold for every match;
-                                                                near misses differ near the end): the kernel reads them in one go */
+#ifndef PFAC_TAIL_MAX_BYTES
+#define PFAC_TAIL_MAX_BYTES 16
+#endif
+constexpr int kTailMaxBytes = PFAC_TAIL_MAX_BYTES;           /* ... and of a longer rest the LAST 16 bytes are compared (any bytes may be: the veto only has to hold for every match;
+                                                                near misses differ near the end): the kernel reads them in one go.  (Round 5: 32 -- twice the hash steps for every
+                                                                batch of candidates; the model's walk counts are the same to the per cent with 16) */
 constexpr uint32_t kTailGInfoMask = 0x7FFu, kTailGFromMask = 0x7F8u;
 constexpr int kTailGLog2Min = 8, kTailGLog2Max = 20;
 inline uint32_t tailGBucket(uint32_t tag, int log2Buckets) { return (uint32_t)(tag * kTailMul) >> (32 - log2Buckets); }

@@ -723,13 +723,14 @@ void pfac_scan_filter(ScanArgs a)
     /* the tail hash of a candidate (pfac::tailRoll): `start` rolled over the nb (a multiple of four, <= kTailMaxBytes) staged bytes from offset `from` of the chunk --
      * nine dwords of the stage in one go, then eight steps in registers */
     auto tailRun = [&](uint32_t start, bool chk, uint32_t from, uint32_t nb) -> uint32_t {
-        static_assert(pfac::kTailMaxBytes == 32, "nine dwords");
+        static_assert(pfac::kTailMaxBytes % 4 == 0 && pfac::kTailMaxBytes >= 8 && pfac::kTailMaxBytes <= 32, "whole dwords, four bytes a step; three bits of the device-memory entry say how many");
+        constexpr int kSteps = pfac::kTailMaxBytes / 4;
         const uint32_t b = chk ? from : 0u, at4 = b >> 2, shb = b & 3u;
-        uint32_t w[9], run = start;
+        uint32_t w[kSteps + 1], run = start;
 #pragma unroll
-        for (int k = 0; k < 9; k++) w[k] = stage[at4 + (uint32_t)k];
+        for (int k = 0; k < kSteps + 1; k++) w[k] = stage[at4 + (uint32_t)k];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < kSteps; k++) {
             const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], shb);
             const uint32_t r1 = (run ^ x) * pfac::kLadMul;
             run = (chk && 4u * (uint32_t)k < nb) ? r1 : run;

@@ -18,7 +18,8 @@ for a, b in (("bench_c3_default.json", "bench_c3_default.json"), ("bench_c2.json
              ("bench_c3_walker_window.json", "bench_c3_walker_window.json"), ("bench_c3_walker_stage.json", "bench_c3_walker_stage.json"),
              ("bench_c2_reftable_dense.json", "bench_c2_reftable_dense.json"), ("bench_c3_reftable_hashed.json", "bench_c3_reftable_hashed.json"),
              ("pmc_full_c5.txt", "pmc_full_result_kernel_c5.txt"), ("pmc_full_c3.txt", "pmc_full_result_kernel_c3.txt"),
-             ("host_numa_probe.txt", "host_numa_probe.txt"), ("small_input_latency.txt", "small_input_latency.txt")):
+             ("host_numa_probe.txt", "host_numa_probe.txt"), ("small_input_latency.txt", "small_input_latency.txt"),
+             ("reduce_ablation.txt", "reduce_kernel_ablation_pmc.txt"), ("level1_floor.txt", "level1_floor.txt")):
     if os.path.exists(os.path.join(src, a)):
         cp(a, b)
 with open(os.path.join("profiles", f"{tag}_pmc_instruction_counts.txt"), "w") as out:

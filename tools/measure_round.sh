@@ -32,6 +32,9 @@ timeout 300 python tools/small_input_latency.py > $O/small_input_latency.txt 2>&
 for w in c3 c5; do
   python3 tools/pmc_run.py --kernel pfac_scan_filter --tag reduce_$w --counters "GRBM_GUI_ACTIVE,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD,SQ_LDS_IDX_ACTIVE,SQ_LDS_BANK_CONFLICT,SQ_WAVE_CYCLES" -- tools/reduce_driver.py $w 4 > $O/pmc_reduce_$w.txt 2>&1
 done
+# round 6: the compacted-output kernel's ablation ladder (tools/build_variant.sh abl1 / abl2 WORK -DPFAC_ABLATE=1 / 2 in the container first) and the floor of its level 1
+[ -d tools/bin/variants/abl1 ] && timeout 600 bash tools/gpu_pmc_variants_reduce.sh c3 tree abl1 abl2 > $O/reduce_ablation.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 -o /tmp/level1_floor tools/level1_floor.hip > /dev/null 2>&1 && timeout 300 /tmp/level1_floor > $O/level1_floor.txt 2>&1
 timeout 400 tools/pmc_traffic.sh c5 $O/traffic_c5 > $O/traffic_c5.log 2>&1
 for w in c3 c2 c5 c6; do
   # 500 timed launches: the ~35 launches in front of them (first launch, settling, warm-up) run at rising clocks, up to 25 % slower, and are in the profiler's average too

@@ -742,6 +742,7 @@ void pfac_scan_filter(ScanArgs a)
     u32x4 pendE = {0, 0, 0, 0};
     uint32_t pendCode = 0, pendHash = 0;
     bool pendAny = false;
+    uint32_t pendCount = 0;                        /* ... how many they are: queue entries a later batch of the same trip must leave them (wave-uniform) */
     /* ... looked at at the top of the next trip: the chunk is still staged (the next one is staged further down the trip), the queue still has the room the
      * batch was cut to.  A candidate whose bytes hash like the rest of its pattern -- or that has no entry, or whose bytes are not all staged -- walks. */
     auto tailResolve = [&]() {
@@ -777,6 +778,7 @@ void pfac_scan_filter(ScanArgs a)
         }
         pendAny = false;
         pendCode = 0u;
+        pendCount = 0u;
     };
     /* One loop, one copy of every stage.  A trip: (1) finish the walkers' transitions issued one trip ago; (2) refill
      * idle walker lanes and issue the next transitions; (3) if the staged chunk is completely listed and tested: level
@@ -1059,7 +1061,7 @@ void pfac_scan_filter(ScanArgs a)
         for (;;) {
             const uint32_t left = listEnd - listAt;
             const uint32_t want = left < 64u ? left : 64u;
-            const uint32_t room = kQCap - (qv - qh);
+            const uint32_t room = kQCap - (qv - qh) - pendCount;    /* (pendCount: the candidates of an earlier batch of this trip that tailResolve may still append) */
             const uint32_t take = room < want ? room : want;
             if (left == 0 || (take != want && take < kAppendMin)) break;
             if (!REDUCE && left < kMergeMin && __ballot(hits != 0) != 0) break;      /* more of this chunk's hits are about to join them (step 4 of the next trip) */
@@ -1169,6 +1171,7 @@ void pfac_scan_filter(ScanArgs a)
                             pendCode = ask ? (0x80000000u | o) : 0u;          /* (the loads themselves: behind the batches of this trip, once) */
                             pendHash = stopHash;
                             pendAny = true;
+                            pendCount = (uint32_t)__popcll(__ballot(ask));
                             walk = ask ? 0u : walk;                 /* decided, and appended if it stands, by tailResolve */
                         }
                     } else if (__ballot(ask) != 0) {
@@ -1180,7 +1183,9 @@ void pfac_scan_filter(ScanArgs a)
                         const uint32_t want = m1 ? h1 : h2, info = m1 ? i1 : (m2 ? i2 : 0u);
                         const uint32_t nb = info & 0xFFu, from = o + (info >> 8);
                         const bool chk = ask && info != 0u && from + nb + 4u <= (uint32_t)kChunkBytes + 4u * (uint32_t)kHaloDwords;   /* the bytes must be staged */
-                        if (chk && tailRun(stopHash, chk, from, nb) != want) walk = 0u;
+                        const bool vetoed = chk && tailRun(stopHash, chk, from, nb) != want;
+                        if (vetoed) walk = 0u;
+                        chunkEvents += (uint32_t)__popcll(__ballot(vetoed));      /* near misses: the wave's evidence of what its stream is (the tiled kernel's table follows the verdict) */
                     }
                 }
             }

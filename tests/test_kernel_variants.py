@@ -376,6 +376,18 @@ def bigset(workdir):
     for k in range(200):                                                # text islands in the last third
         at = int(rng.integers(0, mix.size - 70000))
         mix[at:at + 65536] = cfg3.input_slice(65536, 1 + k % 3)
+    # 2 MiB of the SHORTEST records back to back (32 bytes: 64 near misses per 2 KiB chunk, plus whatever the other 30 000 patterns' prefixes add):
+    # more candidates than one ladder batch takes, so a second batch of the same trip runs while the first one's answers are on their way and has
+    # to leave them their queue entries
+    short = sorted(shared, key=len)[:40]
+    srecs = []
+    for k in range(70000):
+        p = short[int(rng.integers(0, len(short)))]
+        miss = int(rng.integers(1, 4)) if k % 7 else 0
+        srecs.append(np.frombuffer(p[:len(p) - miss], dtype=np.uint8))
+        srecs.append(alnum[rng.integers(0, alnum.size, miss)])
+    sblock = np.concatenate(srecs)[:2 << 20]
+    data[n - (5 << 20):n - (5 << 20) + sblock.size] = sblock
     for k in range(64):                                                 # complete patterns across chunk boundaries, ending 49..63 bytes beyond them
         p = np.frombuffer(shared[k % len(shared)], dtype=np.uint8)
         at = third + 2048 * (100 + 37 * k) - (p.size - 49 - k % 15)

@@ -1,4 +1,4 @@
-"""tools/stress_calls.py [calls] [seed] -- one handle, many calls of changing shape: random slices (any alignment, 1 byte ..
+"""tools/stress_calls.py [calls] [seed] [workload = c3 | c6] -- one handle, many calls of changing shape: random slices (any alignment, 1 byte ..
 48 MiB) of one 64 MiB Snort-style buffer through PFAC_matchFromDevice and PFAC_matchFromDeviceReduce in random order, every
 result against the reference-shaped kernel's (a second handle with PFACX_KERNEL_REFTABLE: the independent implementation) on the same
 slice.  What it is after: state that one launch leaves for the next (launch counters left zero by the last block out,
@@ -11,7 +11,7 @@ from pfac_amd import api, workloads as wl
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 7))
-cfg = wl.make_config("c3")
+cfg = wl.make_config(sys.argv[3] if len(sys.argv) > 3 else "c3")       # c6: near misses over the Snort-scale set (PFAC_TEST_WALKER=veto: the VETO = 2 kernel on every big slice)
 pf = wl.write_pattern_file("/tmp/stress_calls.pat", cfg.patterns)
 N = 64 << 20
 host = cfg.input_slice(N, 0).copy()

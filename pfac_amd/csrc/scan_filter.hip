@@ -135,7 +135,8 @@ void pfac_scan_filter(ScanArgs a)
     constexpr int kTilesPerIter = kGroupTiles;
     constexpr int kChunkBytes = kTilesPerIter * kTileBytes;    /* input bytes a wave stages at a time */
     using WCtx = ChainCtx<TEX>;
-    constexpr uint32_t kEntry = REDUCE ? kEntryBytes : kEntryBytesFull;
+    constexpr uint32_t kEntry = (REDUCE || (!STAGE && VETO == 2)) ? kEntryBytes : kEntryBytesFull;      /* (VETO = 2: see kVetoG below) */
+    constexpr bool kWideEntry = kEntry > kEntryBytes;                                                    /* entries carry bytes 20..35 too (queueC) */
     /* full-result kernel: walks read their input from the wave's two staged chunks (StageLane), a queue entry is {buffer, offset};
      * compacted-output kernel (16 scanning waves, no LDS to spare): the input travels with the entry and lives in registers */
     constexpr bool kStageWalk = !REDUCE && STAGE;
@@ -146,11 +147,16 @@ void pfac_scan_filter(ScanArgs a)
     constexpr bool kVeto = !REDUCE && !STAGE && VETO != 0;
     /* VETO = 2 (round 6): the same kernel for a set whose tail table does not fit the LDS (Snort-scale: the bitmaps take it, and its thin stops outnumber the
      * LDS table's slots): the table lies in device memory (pfac::Filter::tailG), a batch of the ladder with kTailAskMin or more stopped candidates asks it
-     * with ONE gathered 16-byte load per candidate and waits for the answers on the spot (`; pfac_tail_sync`: the wait also takes the walkers' slots of
-     * this trip and the prefetched chunk, which the top of the next trip would have waited for anyway; the other scanning waves of the SIMD fill the
-     * gap).  The lines a near-miss stream asks for stay in L2: it meets the same few hundred stop nodes over and over.  Text does not repay the round
-     * trip: launchChained gives such a set this kernel only while the handle's launches report near misses. */
+     * with ONE gathered 16-byte load per candidate, issued behind the batches of a trip and looked at at the top of the next one (tailResolve).  The lines a
+     * near-miss stream asks for stay in L2: it meets the same few hundred stop nodes over and over.  Text does not repay the round trip: launchChained gives
+     * such a set this kernel only while the handle's launches report near misses.
+     * What is left to walk behind this veto is little (4 M walks per GiB of the near-miss stream over the 31 000-pattern set), so the kernel's walker is the
+     * compacted-output kernel's: 20-byte queue entries, a five-dword window (a walk deeper than that re-fetches its window: rare enough now) -- four registers
+     * less, which the answers on their way need, and 16 bytes per queue entry less, in whose place the wave's LIST lies with 256 codes instead of 128: the
+     * alphanumeric near-miss stream has ~127 level-1 hits per chunk under that set, and every second chunk needed a second list round -- a trip of its own. */
     constexpr bool kVetoG = kVeto && VETO == 2;
+    constexpr uint32_t kListCapK = kVetoG ? 2u * kListCap : kListCap;
+    static_assert(kListCapK * 2 <= kQueueCap * 16 || !kVetoG, "VETO = 2: the list lies in the place of the queue's bytes 20..35");
 #ifndef PFAC_TAIL_ASK_MIN
 #define PFAC_TAIL_ASK_MIN 8
 #endif
@@ -175,7 +181,7 @@ void pfac_scan_filter(ScanArgs a)
     constexpr uint32_t kQCap = REDUCE ? kReduceQueueCap : kQueueCap;
     uint32_t *sQueueBAll = sQueueAll + kScanners * kQCap * (kStageWalk ? 1 : 4);   /* ... second part of the entries: input bytes 12..19 (kStageWalk: an entry is one word) */
     uint32_t *sQueueCAll = sQueueBAll + (kStageWalk ? 0 : kScanners * kQCap * 2);  /* ... register-window walkers of a full-result build: input bytes 20..35 */
-    uint32_t *sStageAll = sQueueCAll + ((REDUCE || kStageWalk) ? 0 : kScanners * kQCap * 4);   /* per scanning wave: the chunk being filtered + the bytes behind it (kStageWalk: and the chunk before it) */
+    uint32_t *sStageAll = sQueueCAll + ((REDUCE || kStageWalk) ? 0 : kScanners * kQCap * 4);      /* (VETO = 2 keeps the room: its list lies there) */   /* per scanning wave: the chunk being filtered + the bytes behind it (kStageWalk: and the chunk before it) */
     uint32_t *sListAll = sStageAll + kScanners * kStageWordsK * kStageBufs;   /* per scanning wave: 16-bit codes of the chunk's level-1 hits */
     uint32_t *sReduceAll = sListAll + kScanners * (kListCap / 2);        /* REDUCE only: per-wave staging of (position, id) */
     uint32_t *sDenseAll = sReduceAll + ((REDUCE || kStagedPatch) ? kScanners * 2 * kReduceCap : 0);   /* full-result kernel: per-wave staging of dense chunk numbers */
@@ -230,7 +236,7 @@ void pfac_scan_filter(ScanArgs a)
      * between two calls; a wave that guesses wrong switches after a few chunks) */
     bool modeStage = kStageWalk && __builtin_amdgcn_readfirstlane((int)a.work[pfac::kModeHintWord]) != 0;
     uint32_t deepRecent = 0, stageHold = modeStage ? 8u : 0u;
-    uint16_t *list = reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
+    uint16_t *list = kVetoG ? reinterpret_cast<uint16_t *>(sQueueCAll + wave * kQCap * 4) : reinterpret_cast<uint16_t *>(sListAll + wave * (kListCap / 2));
     const uint32_t n = (uint32_t)a.n;               /* < 2^32: the launcher splits larger inputs */
     const Lds lds{sGram3, sLadder, sFinal3, sShort,
                   ((1u << ((uint32_t)a.log2Bits - 5u)) - 1u) << 2 /* product's high half -> byte address of the level-1 dword */, 32u - (uint32_t)a.log2BitsLad, 32u - (uint32_t)a.log2BitsF3};
@@ -433,7 +439,7 @@ void pfac_scan_filter(ScanArgs a)
 #ifndef PFAC_WALK_GATE_TRIPS
 #define PFAC_WALK_GATE_TRIPS 6
 #endif
-    constexpr bool kWalkGated = !REDUCE && !kStageWalk && kWalkSets == 1 && PFAC_WALK_GATE > 0;
+    constexpr bool kWalkGated = !REDUCE && !kStageWalk && kWalkSets == 1 && PFAC_WALK_GATE > 0;       /* (the compacted-output kernel's rounds are full: 116 of 128 lanes step per round on C3; gated, 0.589 -> 0.604 ms) */
     constexpr uint32_t kWalkGate = PFAC_WALK_GATE, kWalkGateTrips = PFAC_WALK_GATE_TRIPS;
     uint32_t walkIdleTrips = 0;
     /* hand verified queue entries to idle walker lanes */
@@ -466,7 +472,7 @@ void pfac_scan_filter(ScanArgs a)
                     } else {
                         const u32x2 eb = queueB[qi];
                         u32x4 ec = {0, 0, 0, 0};
-                        if (!REDUCE) ec = queueC[qi];
+                        if (kWideEntry) ec = queueC[qi];
                         walk[s].start(wctx, queue[qi], eb.x, eb.y, ec, HAS_SHORT ? sShort : nullptr);
                     }
                 }
@@ -761,17 +767,14 @@ void pfac_scan_filter(ScanArgs a)
         if (keepMask != 0) {
             if (keep) {
                 const uint32_t at = o >> 2, sh = o & 3u;
-                uint32_t e[10];
+                uint32_t e[6];
 #pragma unroll
-                for (int k = 0; k < 10; k++) e[k] = stage[at + (uint32_t)k];
+                for (int k = 0; k < 6; k++) e[k] = stage[at + (uint32_t)k];
                 const uint32_t qi = (qv + laneRankIn(keepMask)) & kMask;
                 const u32x4 entry = {stagedBase + o, __builtin_amdgcn_alignbyte(e[1], e[0], sh), __builtin_amdgcn_alignbyte(e[2], e[1], sh), __builtin_amdgcn_alignbyte(e[3], e[2], sh)};
                 const u32x2 entryB = {__builtin_amdgcn_alignbyte(e[4], e[3], sh), __builtin_amdgcn_alignbyte(e[5], e[4], sh)};
-                const u32x4 entryC = {__builtin_amdgcn_alignbyte(e[6], e[5], sh), __builtin_amdgcn_alignbyte(e[7], e[6], sh),
-                                      __builtin_amdgcn_alignbyte(e[8], e[7], sh), __builtin_amdgcn_alignbyte(e[9], e[8], sh)};
-                queue[qi] = entry;
+                queue[qi] = entry;                                  /* (20-byte entries: kEntry) */
                 queueB[qi] = entryB;
-                queueC[qi] = entryC;
             }
             qv = uni(qv + (uint32_t)__popcll(keepMask));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1000,13 +1003,13 @@ void pfac_scan_filter(ScanArgs a)
                 hits = 0;
             }
             freshChunk = false;
-            while (hits != 0 && idx < kListCap) {       /* divergent: as many rounds as the busiest lane has hits */
+            while (hits != 0 && idx < kListCapK) {       /* divergent: as many rounds as the busiest lane has hits */
                 list[idx] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)__builtin_ctz(hits));
                 idx++;
                 hits &= hits - 1;
             }
             PFAC_TICK(10);
-            const uint32_t listed = dense ? 0u : (total < kListCap - carry ? total : kListCap - carry);
+            const uint32_t listed = dense ? 0u : (total < kListCapK - carry ? total : kListCapK - carry);
 #ifndef PFAC_COUNT_STALLS
             stHits += listed;
 #endif
@@ -1209,7 +1212,7 @@ void pfac_scan_filter(ScanArgs a)
                 const u32x2 entryB = {x3, x4};
                 queue[qi] = entry;
                 queueB[qi] = entryB;
-                if (!REDUCE) {                                  /* bytes 20..35: read now, for the few that are kept */
+                if (kWideEntry) {                               /* bytes 20..35: read now, for the few that are kept */
                     const uint32_t e6 = stage[at + 6], e7 = stage[at + 7], e8 = stage[at + 8], e9 = stage[at + 9];
                     const u32x4 entryC = {__builtin_amdgcn_alignbyte(e6, e5, sh), __builtin_amdgcn_alignbyte(e7, e6, sh),
                                           __builtin_amdgcn_alignbyte(e8, e7, sh), __builtin_amdgcn_alignbyte(e9, e8, sh)};

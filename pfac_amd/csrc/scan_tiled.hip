@@ -840,6 +840,9 @@ hipError_t launchTiled(const PFAC_context *c, ScanArgs a)
     if (big) {
         hot = (kLdsPerCu - fixed) / sizeof(pfac::ChainSlot);
         if (hot > a.rootRow) hot = a.rootRow;            /* the buckets lie in front of the initial state's row */
+#ifdef PFAC_EXP_HOT_ENV
+        { static const char *cap = getenv("PFAC_EXP_HOT_KIB"); if (cap && a.denseList == nullptr) { const size_t k = (size_t)atoi(cap) * 1024 / sizeof(pfac::ChainSlot); if (hot > k) hot = k; } }
+#endif
     }
     a.hotSlots = (uint32_t)hot;
     size_t blocks = (groups + waves - 1) / waves;

@@ -35,8 +35,12 @@ __global__ __launch_bounds__(1024) void level1(const u32x4 *in, size_t tiles, co
         if (lane == 0) t = atomicAdd(next, 64u);                    // 64 tiles per claim, in order (one device counter answers ~90 atomics per microsecond: 16 K claims per GiB)
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= tiles) break;
-        for (unsigned int k = 0; k < 64 && t + k < tiles; k++) {
-            const u32x4 d = in[(size_t)(t + k) * 64 + lane];
+        // four tiles in flight per wave (the kernel's chunk prefetch is 2 KiB ahead): the loads and their waits are written out so that a wait
+        // leaves the three younger loads in flight (the compiler's own wait would be for all of them).  A claim is 64 whole tiles (2^20 tiles).
+        u32x4 d0, d1, d2, d3;
+        auto fetch = [&](u32x4 &d, unsigned int tileNo) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(in + (size_t)tileNo * 64 + lane) : "memory"); };
+        fetch(d0, t); fetch(d1, t + 1); fetch(d2, t + 2); fetch(d3, t + 3);
+        auto tile = [&](const u32x4 d) {
             const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
             uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dw[0], 0x130, 0xf, 0xf, false);   // the next lane's first dword (the tile's last lane: 0)
             uint32_t hits = 0;
@@ -61,7 +65,14 @@ __global__ __launch_bounds__(1024) void level1(const u32x4 *in, size_t tiles, co
                 __builtin_amdgcn_sched_barrier(0);
             }
             found += (unsigned long long)__builtin_popcount(hits);
+        };
+        for (unsigned int k = 0; k < 64; k += 4) {
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(d0)); tile(d0); fetch(d0, t + k + 4);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(d1)); tile(d1); fetch(d1, t + k + 5);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(d2)); tile(d2); fetch(d2, t + k + 6);
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(d3)); tile(d3); fetch(d3, t + k + 7);
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
     }
     if (found == 0xFFFFFFFFFFFFull) *hitsOut = found;               // keeps the work
     atomicAdd(hitsOut + 1, found);
@@ -116,7 +127,7 @@ int main()
     for (int i = 0; i < 25000; i++) { s = s * 6364136223846793005ull + 1442695040888963407ull; map[(s >> 40) % map.size()] |= 1u << ((s >> 20) & 31); }   // 25 000 3-grams: 4.8 % of 2^19 bits
     u32x4 *d_in;
     uint32_t *d_map;
-    (void)hipMalloc(&d_in, n + 4096);
+    (void)hipMalloc(&d_in, n + 65536);
     (void)hipMalloc(&d_map, kTableBytes);
     (void)hipMemcpy(d_in, text.data(), n, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_map, map.data(), kTableBytes, hipMemcpyHostToDevice);

@@ -388,6 +388,20 @@ def bigset(workdir):
         srecs.append(alnum[rng.integers(0, alnum.size, miss)])
     sblock = np.concatenate(srecs)[:2 << 20]
     data[n - (5 << 20):n - (5 << 20) + sblock.size] = sblock
+    # three blocks of pattern PREFIXES back to back inside the text third: 5 bytes of a pattern + 6..9 / 2..4 / 0..1 other bytes -- ~170 / 257..307 / 310..388
+    # level-1 hits per 2 KiB chunk (tests/filter_model.py), 200..320 of them candidates behind the level-4 test: around and above the list's codes (128; the
+    # VETO = 2 instance: 256), so a chunk takes several list rounds with leftover candidates carried from one to the next and several ladder batches per trip --
+    # and below the 1024 hits at which a chunk goes to the tiled kernel instead
+    longer = [q for q in cfg3.patterns if len(q) >= 8]
+    for blk, (gap_lo, gap_hi) in enumerate(((6, 10), (2, 5), (0, 2))):
+        precs = []
+        for k in range(120000):
+            q = longer[int(rng.integers(0, len(longer)))]
+            precs.append(np.frombuffer(q[:5] if k % 11 else q, dtype=np.uint8))        # one in eleven: the whole pattern
+            precs.append(alnum[rng.integers(0, alnum.size, int(rng.integers(gap_lo, gap_hi)))])
+        pblock = np.concatenate(precs)[:512 << 10]
+        at = (3 + 2 * blk) << 20
+        data[at:at + pblock.size] = pblock
     for k in range(64):                                                 # complete patterns across chunk boundaries, ending 49..63 bytes beyond them
         p = np.frombuffer(shared[k % len(shared)], dtype=np.uint8)
         at = third + 2048 * (100 + 37 * k) - (p.size - 49 - k % 15)

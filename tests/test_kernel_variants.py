@@ -408,7 +408,7 @@ def bigset(workdir):
         data[at:at + p.size] = p
     want = oracle_match(pf, data, omp=True)
     assert np.count_nonzero(want) > 50000
-    return pf, data, want
+    return pf, data, want, pats
 
 
 @pytest.mark.parametrize("perf,tex,mode_name", MODES)
@@ -416,7 +416,7 @@ def test_veto_kernel_with_the_tail_table_in_device_memory(bigset, perf, tex, mod
     """The VETO = 2 instances (PFACX_WALKER_VETO on a set whose tail table lies in device memory) against the oracle in every table mode:
     aligned and misaligned pointers, and the same handle under PFACX_WALKER_AUTO across a stream that changes from text to near misses
     and back inside ONE launch (the kernel's per-batch gate: a batch with fewer than eight stopped candidates does not ask the table)."""
-    pf, data, want = bigset
+    pf, data, want, _ = bigset
     h = make_handle(pf, perf, tex, api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_VETO << 8))
     try:
         info = h.info()
@@ -435,5 +435,35 @@ def test_veto_kernel_with_the_tail_table_in_device_memory(bigset, perf, tex, mod
         h.setWalker(api.PFACX_WALKER_AUTO)
         for k in range(3):
             assert_same(device_match(h, data), want, f"auto / {mode_name} / launch {k}")
+    finally:
+        h.destroy()
+
+
+def test_veto_kernel_with_the_tail_table_in_device_memory_and_short_patterns(bigset, workdir):
+    """The HAS_SHORT instances of the VETO = 2 kernel: the same Snort-scale set plus a one-byte and a two-byte pattern (the exact 2-byte bitmap
+    in LDS, the bypass in the level-4 test), over 2 MiB each of the fixture's prefix blocks, near misses and short records with the two
+    short patterns planted in them -- against the oracle, aligned and misaligned."""
+    _, big, _, pats = bigset
+    pf = wl.write_pattern_file(os.path.join(workdir, "bigset_short.pat"), list(pats) + [b"\x01\x02", b"\x7f"])
+    third = 16 << 20
+    n = big.size
+    data = np.concatenate([big[(3 << 20):(5 << 20)], big[third + (1 << 20):third + (3 << 20)], big[n - (5 << 20):n - (3 << 20)], big[:13]]).copy()
+    rng = np.random.Generator(np.random.PCG64(607))
+    for at in rng.integers(0, data.size - 2, 3000):
+        if at % 3:
+            data[at] = 0x7F
+        else:
+            data[at:at + 2] = (1, 2)
+    want = oracle_match(pf, data, omp=True)
+    short_hits = int(np.count_nonzero(data == 0x7F))
+    assert np.count_nonzero(want) > short_hits > 1500
+    h = make_handle(pf, api.PFAC_SPACE_DRIVEN, api.PFAC_TEXTURE_ON, api.PFACX_KERNEL_FILTER | (api.PFACX_WALKER_VETO << 8))
+    try:
+        info = h.info()
+        assert info.filterHasShort and info.filterTailGlobalEntries > 10000 and info.filterTailEntries == 0, (info.filterHasShort, info.filterTailGlobalEntries)
+        assert_same(device_match(h, data), want, "veto kernel, short patterns / aligned")
+        st = h.scanStats(data.size)
+        assert st["veto"] == 2 and st["walksStarted"] > 0, st
+        assert_same(device_match(h, data, in_offset=5, out_offset=3), want, "veto kernel, short patterns / input +5 B, result +3 ints")
     finally:
         h.destroy()

@@ -699,6 +699,9 @@ def other_configs(args, device, buffers):
         st = run.scan_stats()
         if st:
             entry["walk_stats"] = st
+        if name == "c6":
+            entry["note"] = ("the VETO = 2 kernel runs in one of two classes by where the driver placed the process's buffers: ~1.07 ms (0.63) or ~1.16 ms (0.58); "
+                             "roofline.bare_stream_1r4w.ms of this line -- the same buffers -- shows which (~0.90 / ~0.94): profiles/r06_c6_placement_classes.txt")
         out[key] = entry
         run.close()
         log(f"[bench] {key}: {entry['kernel_ms_avg']} ms, frac {entry['frac']}, exact {ok} ({time.perf_counter() - t0:.1f}s)")

@@ -419,7 +419,7 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
         for (uint32_t t = 0; t < kSaltTries && bestCost != 0; t++) {
             const uint32_t salt = t * 0x9E3779B9u;
             std::vector<uint32_t> bits((size_t(1) << f.log2BitsLad) / 32, 0);
-            std::vector<std::pair<uint32_t, uint32_t>> goOns;           /* (hash, patterns below) */
+            std::vector<std::pair<uint32_t, uint32_t>> goOnNodes;           /* (hash, patterns below) */
             LadderWalk{fa, below, (uint32_t)f.ladderThin, f.ladderExtend, f.ladderLast, salt}.run([&](uint32_t h, int depth, bool stop, int state, bool) {
                 if (stop) {
                     setBit(bits, ladderBitS1(h, f.log2BitsLad));
@@ -427,12 +427,12 @@ static void buildFilterImpl(const Automaton &fa, Filter &f, bool allowDeep)
                 } else {
                     setBit(bits, ladderBitG(h, f.log2BitsLad));
                     if (depth == kLadderFirst) setBit(bits, ladderBitG2(h, f.log2BitsLad));
-                    goOns.emplace_back(h, below[(size_t)state]);
+                    goOnNodes.emplace_back(h, below[(size_t)state]);
                 }
             });
             auto has = [&](uint32_t b) { return (bits[b >> 5] >> (b & 31)) & 1u; };
             uint64_t cost = 0;
-            for (const auto &g : goOns)
+            for (const auto &g : goOnNodes)
                 if (has(ladderBitS1(g.first, f.log2BitsLad)) && has(ladderBitS2(g.first, f.log2BitsLad))) cost += g.second;
             if (cost < bestCost) { bestCost = cost; f.ladderSalt = salt; }
         }
